@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Regenerate the data fixtures under tests/golden/ from /root/reference.
+
+Run in the build container only (the GPU box has no /root/reference).  The
+fixtures are *data* the reference tree holds, down-selected:
+
+* eta79.npz        - L79 ak/bk table
+  [REF examples/notebooks/generate_eta_file_netcdf.ipynb:82-135]
+* c12_restart_tile1.npz - real FV3 C12 L63 state of tile 1 (u, v, W, DZ, T,
+  delp, phis, sphum, liq_wat) + ak/bk(64)
+  [REF tests/main/data/c12_restart/fv_core.res.tile1.nc, fv_tracer.res.tile1.nc, fv_core.res.nc]
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def eta79():
+    nb = json.load(open(os.path.join(REF, "examples/notebooks/generate_eta_file_netcdf.ipynb")))
+    out = {}
+    for cell in nb["cells"]:
+        src = "".join(cell["source"])
+        for name in ("ak", "bk"):
+            m = re.search(name + r"\[:\]\s*=\s*np\.array\(\s*\[(.*?)\]\s*\)", src, re.S)
+            if m:
+                out[name] = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()])
+    assert out["ak"].shape == (80,) and out["bk"].shape == (80,), {k: v.shape for k, v in out.items()}
+    np.savez(os.path.join(OUT, "eta79.npz"), **out)
+    print("eta79.npz", out["ak"][:3], out["bk"][-3:])
+
+
+def c12_restart():
+    from scipy.io import netcdf_file
+
+    d = os.path.join(REF, "tests/main/data/c12_restart")
+    out = {}
+    with netcdf_file(os.path.join(d, "fv_core.res.tile1.nc"), "r", mmap=False) as f:
+        for k in ("u", "v", "W", "DZ", "T", "delp", "phis"):
+            out[k] = np.array(f.variables[k][0], dtype=np.float64)
+    with netcdf_file(os.path.join(d, "fv_tracer.res.tile1.nc"), "r", mmap=False) as f:
+        for k in ("sphum", "liq_wat"):
+            out[k] = np.array(f.variables[k][0], dtype=np.float64)
+    with netcdf_file(os.path.join(d, "fv_core.res.nc"), "r", mmap=False) as f:
+        out["ak"] = np.array(f.variables["ak"][0], dtype=np.float64)
+        out["bk"] = np.array(f.variables["bk"][0], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "c12_restart_tile1.npz"), **out)
+    print("c12_restart_tile1.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference")
+    os.makedirs(OUT, exist_ok=True)
+    eta79()
+    c12_restart()
