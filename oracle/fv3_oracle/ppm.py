@@ -1,0 +1,141 @@
+"""ORACLE (test infrastructure) -- 1-D PPM flux operators, hord/iord 5-6 (unlimited
+PPM with the ``smt5`` linear-scheme fallback)  [SURVEY A.4.2; FV3 tp_core xppm/yppm,
+sw_core xtp_u/ytp_v; pyFV3 ``xppm.py`` / ``yppm.py`` / ``xtp_u.py`` / ``ytp_v.py``
+as used by every reference config: hord_* = 6, REF driver/examples/configs/baroclinic_c12.yaml:57-61].
+The y variants are the x variants on the transposed rank.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .util import Dom, tr
+
+P1 = 7.0 / 12.0
+P2 = -1.0 / 12.0
+C1 = -2.0 / 14.0
+C2 = 11.0 / 14.0
+C3 = 5.0 / 14.0
+
+
+def _col(D, a, i, j0, j1):
+    o = D.o
+    return a[i + o : i + o + 1, j0 + o : j1 + o + 1]
+
+
+def _edge_mean(q_m1, q_0, q_p1, q_p2, d_m1, d_0, d_p1, d_p2):
+    """Two-sided metric-weighted extrapolation to the tile edge between cells 0 and +1."""
+    return 0.5 * (
+        ((2.0 * d_0 + d_m1) * q_0 - d_0 * q_m1) / (d_m1 + d_0)
+        + ((2.0 * d_p1 + d_p2) * q_p1 - d_p1 * q_p2) / (d_p1 + d_p2)
+    )
+
+
+def compute_al(D: Dom, q, dm, j0, j1):
+    """Edge values al(i) (west face of cell i) on rows j0..j1, incl. tile-edge formulas."""
+    S = D.sl
+    npx = D.npx
+    al = np.zeros_like(q)
+    i_lo = 3 if D.west else D.is_ - 1
+    i_hi = npx - 2 if D.east else D.ie + 2
+    if i_hi >= i_lo:
+        al[S(i_lo, i_hi, j0, j1)] = P1 * (q[S(i_lo - 1, i_hi - 1, j0, j1)] + q[S(i_lo, i_hi, j0, j1)]) + P2 * (
+            q[S(i_lo - 2, i_hi - 2, j0, j1)] + q[S(i_lo + 1, i_hi + 1, j0, j1)]
+        )
+
+    def Q(i):
+        return _col(D, q, i, j0, j1)
+
+    def M(i):
+        return _col(D, dm, i, j0, j1)
+
+    def setal(i, v):
+        al[i + D.o : i + D.o + 1, j0 + D.o : j1 + D.o + 1] = v
+
+    if D.west:
+        setal(0, C1 * Q(-2) + C2 * Q(-1) + C3 * Q(0))
+        setal(1, _edge_mean(Q(-1), Q(0), Q(1), Q(2), M(-1), M(0), M(1), M(2)))
+        setal(2, C3 * Q(1) + C2 * Q(2) + C1 * Q(3))
+    if D.east:
+        setal(npx - 1, C1 * Q(npx - 3) + C2 * Q(npx - 2) + C3 * Q(npx - 1))
+        setal(npx, _edge_mean(Q(npx - 2), Q(npx - 1), Q(npx), Q(npx + 1), M(npx - 2), M(npx - 1), M(npx), M(npx + 1)))
+        setal(npx + 1, C3 * Q(npx) + C2 * Q(npx + 1) + C1 * Q(npx + 2))
+    return al
+
+
+def _flux_from_blbr(D, q, c, bl, br, j0, j1, mord, cfl_scale=None):
+    """flux(i) for i = is..ie+1 given bl/br on is-1..ie+1."""
+    S = D.sl
+    b0 = bl + br
+    if mord == 5:
+        smt5 = (bl * br) < 0.0
+    else:
+        smt5 = (3.0 * np.abs(b0)) < np.abs(bl - br)
+    R0 = S(D.is_, D.ie + 1, j0, j1)
+    Rm = S(D.is_ - 1, D.ie, j0, j1)
+    cc = c[R0]
+    if cfl_scale is None:
+        cfl = cc
+    else:
+        cfl = np.where(cc > 0.0, cc * cfl_scale[Rm], cc * cfl_scale[R0])
+    fx1 = np.where(cc > 0.0, (1.0 - cfl) * (br[Rm] - cfl * b0[Rm]), (1.0 + cfl) * (bl[R0] + cfl * b0[R0]))
+    flux = np.where(cc > 0.0, q[Rm], q[R0])
+    flux = np.where(smt5[Rm] | smt5[R0], flux + fx1, flux)
+    out = np.zeros_like(q)
+    out[R0] = flux
+    return out
+
+
+def xppm(D: Dom, q, c, j0, j1, iord=6):
+    """Flux-form PPM value at x faces i = is..ie+1 on rows j0..j1 (Courant number c)."""
+    if iord not in (5, 6):
+        raise NotImplementedError("oracle restates hord 5/6 only (all reference configs use 6)")
+    S = D.sl
+    al = compute_al(D, q, D.m.dxa, j0, j1)
+    bl = np.zeros_like(q)
+    br = np.zeros_like(q)
+    R = S(D.is_ - 1, D.ie + 1, j0, j1)
+    Rp = S(D.is_, D.ie + 2, j0, j1)
+    bl[R] = al[R] - q[R]
+    br[R] = al[Rp] - q[R]
+    return _flux_from_blbr(D, q, c, bl, br, j0, j1, iord)
+
+
+def yppm(D: Dom, q, c, i0, i1, jord=6):
+    return tr(xppm(D.T, tr(q), tr(c), i0, i1, jord))
+
+
+def xtp_u(D: Dom, c, u, iord=6):
+    """Advective-form PPM of the D-grid wind u along x (FV3 xtp_u): value of u carried
+    across corner (i, j) by the corner wind c, i = is..ie+1, j = js..je+1."""
+    if iord not in (5, 6):
+        raise NotImplementedError
+    S = D.sl
+    o = D.o
+    npx, npy = D.npx, D.npy
+    j0, j1 = D.js, D.je + 1
+    dx = D.m.dx
+    al = compute_al(D, u, dx, j0, j1)
+    bl = np.zeros_like(u)
+    br = np.zeros_like(u)
+    R = S(D.is_ - 1, D.ie + 1, j0, j1)
+    Rp = S(D.is_, D.ie + 2, j0, j1)
+    bl[R] = al[R] - u[R]
+    br[R] = al[Rp] - u[R]
+    # at the tile's own corners the edge-row values are not defined: zero the slopes
+    rows = []
+    if D.south:
+        rows.append(1)
+    if D.north:
+        rows.append(npy)
+    for j in rows:
+        if D.west:
+            bl[0 + o : 2 + o, j + o] = 0.0
+            br[0 + o : 2 + o, j + o] = 0.0
+        if D.east:
+            bl[npx - 1 + o : npx + 1 + o, j + o] = 0.0
+            br[npx - 1 + o : npx + 1 + o, j + o] = 0.0
+    return _flux_from_blbr(D, u, c, bl, br, j0, j1, iord, cfl_scale=D.m.rdx)
+
+
+def ytp_v(D: Dom, c, v, jord=6):
+    return tr(xtp_u(D.T, tr(c), tr(v), jord))

@@ -391,7 +391,7 @@ def make_grid(
         for i in range(npy, npy + 3):
             sin[3][0 + o, i + o] = sin[4][npy - i + o, npy - 1 + o]
         for i in range(-2, 1):
-            sin[2][i + o, npy + o] = sin[1][1 + o, npx + i + o]
+            sin[2][i + o, npy + o] = sin[1][1 + o, npy - i + o]
     if flags["east"] and flags["south"]:
         for j in range(-2, 1):
             sin[1][npx + o, j + o] = sin[2][npx - j + o, 1 + o]
