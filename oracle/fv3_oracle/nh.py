@@ -342,8 +342,10 @@ def pk3_halo(D: Dom, pk3, delp, ptop, akap):
     is_, ie, js, je = D.is_, D.ie, D.js, D.je
 
     def column(si, sj):
-        pei = ptop + np.cumsum(delp[si, sj, :nz], axis=-1)
-        pk3[si, sj, 1 : nz + 1] = np.exp(akap * np.log(pei))
+        pei = np.full(delp[si, sj, 0].shape, ptop)
+        for k in range(nz):
+            pei = pei + delp[si, sj, k]
+            pk3[si, sj, k + 1] = np.exp(akap * np.log(pei))
 
     jr = slice(js + o, je + o + 1)
     column(slice(is_ - 2 + o, is_ + o), jr)
@@ -360,8 +362,11 @@ def pe_halo(D: Dom, pe, delp, ptop):
     is_, ie, js, je = D.is_, D.ie, D.js, D.je
 
     def column(si, sj):
-        pe[si, sj, 0] = ptop
-        pe[si, sj, 1 : nz + 1] = ptop + np.cumsum(delp[si, sj, :nz], axis=-1)
+        pei = np.full(delp[si, sj, 0].shape, ptop)
+        pe[si, sj, 0] = pei
+        for k in range(nz):
+            pei = pei + delp[si, sj, k]
+            pe[si, sj, k + 1] = pei
 
     jr = slice(js + o, je + o + 1)
     column(slice(is_ - 1 + o, is_ + o), jr)

@@ -1,0 +1,187 @@
+// fv3_a2b.hip -- 4th-order cell-centre -> corner interpolation (a2b_ord4).
+// CPU twin: oracle/fv3_oracle/a2b_ord4.py.  [SURVEY A.13; reference operator AGrid2BGridFourthOrder]
+//
+// The reference runs ~10 dependent stencils (qx, qy, edge values, qxx, qyy, average); every one
+// of them is a pure function of qin and 2-D metric terms, so a single launch evaluates the chain
+// per output corner from L1/L2-resident qin -- no intermediate field ever reaches HBM.
+#include "fv3_ops.h"
+
+#define A2B_A1 ((Real)0.5625)
+#define A2B_A2 ((Real)-0.0625)
+#define A2B_B1 ((Real)(7.0 / 12.0))
+#define A2B_B2 ((Real)(-1.0 / 12.0))
+#define A2B_C1 ((Real)(2.0 / 3.0))
+#define A2B_C2 ((Real)(-1.0 / 6.0))
+#define A2B_R3 ((Real)(1.0 / 3.0))
+
+namespace {
+
+struct A2B {
+  Geo g;
+  const Real *q;    // level base of qin for this (t, k)
+  const Real *dxa;  // metric planes for this t
+  const Real *dya;
+  bool W, E, S, N;
+
+  FV3_HD Real Q(int i, int j) const { return q[IX(i, j)]; }
+
+  FV3_HD Real qx_int(int i, int j) const { return A2B_B2 * (Q(i - 2, j) + Q(i + 1, j)) + A2B_B1 * (Q(i - 1, j) + Q(i, j)); }
+  FV3_HD Real qy_int(int i, int j) const { return A2B_B2 * (Q(i, j - 2) + Q(i, j + 1)) + A2B_B1 * (Q(i, j - 1) + Q(i, j)); }
+
+  FV3_HD Real qx_w1(int j) const {
+    const Real g_in = dxa[IX(2, j)] / dxa[IX(1, j)], g_ou = dxa[IX(-1, j)] / dxa[IX(0, j)];
+    return (Real)0.5 * ((((Real)2 + g_in) * Q(1, j) - Q(2, j)) / ((Real)1 + g_in) + (((Real)2 + g_ou) * Q(0, j) - Q(-1, j)) / ((Real)1 + g_ou));
+  }
+  FV3_HD Real qx_e1(int j) const {
+    const int npx = g.npx;
+    const Real g_in = dxa[IX(npx - 2, j)] / dxa[IX(npx - 1, j)], g_ou = dxa[IX(npx + 1, j)] / dxa[IX(npx, j)];
+    return (Real)0.5 *
+           ((((Real)2 + g_in) * Q(npx - 1, j) - Q(npx - 2, j)) / ((Real)1 + g_in) + (((Real)2 + g_ou) * Q(npx, j) - Q(npx + 1, j)) / ((Real)1 + g_ou));
+  }
+  FV3_HD Real qx(int i, int j) const {
+    const int npx = g.npx;
+    if (W) {
+      if (i == 1) return qx_w1(j);
+      if (i == 2) {
+        const Real g_in = dxa[IX(2, j)] / dxa[IX(1, j)];
+        return ((Real)3 * (g_in * Q(1, j) + Q(2, j)) - (g_in * qx_w1(j) + qx_int(3, j))) / ((Real)2 + (Real)2 * g_in);
+      }
+    }
+    if (E) {
+      if (i == npx) return qx_e1(j);
+      if (i == npx - 1) {
+        const Real g_in = dxa[IX(npx - 2, j)] / dxa[IX(npx - 1, j)];
+        return ((Real)3 * (Q(npx - 2, j) + g_in * Q(npx - 1, j)) - (g_in * qx_e1(j) + qx_int(npx - 2, j))) / ((Real)2 + (Real)2 * g_in);
+      }
+    }
+    return qx_int(i, j);
+  }
+  FV3_HD Real qy_s1(int i) const {
+    const Real g_in = dya[IX(i, 2)] / dya[IX(i, 1)], g_ou = dya[IX(i, -1)] / dya[IX(i, 0)];
+    return (Real)0.5 * ((((Real)2 + g_in) * Q(i, 1) - Q(i, 2)) / ((Real)1 + g_in) + (((Real)2 + g_ou) * Q(i, 0) - Q(i, -1)) / ((Real)1 + g_ou));
+  }
+  FV3_HD Real qy_n1(int i) const {
+    const int npy = g.npy;
+    const Real g_in = dya[IX(i, npy - 2)] / dya[IX(i, npy - 1)], g_ou = dya[IX(i, npy + 1)] / dya[IX(i, npy)];
+    return (Real)0.5 *
+           ((((Real)2 + g_in) * Q(i, npy - 1) - Q(i, npy - 2)) / ((Real)1 + g_in) + (((Real)2 + g_ou) * Q(i, npy) - Q(i, npy + 1)) / ((Real)1 + g_ou));
+  }
+  FV3_HD Real qy(int i, int j) const {
+    const int npy = g.npy;
+    if (S) {
+      if (j == 1) return qy_s1(i);
+      if (j == 2) {
+        const Real g_in = dya[IX(i, 2)] / dya[IX(i, 1)];
+        return ((Real)3 * (g_in * Q(i, 1) + Q(i, 2)) - (g_in * qy_s1(i) + qy_int(i, 3))) / ((Real)2 + (Real)2 * g_in);
+      }
+    }
+    if (N) {
+      if (j == npy) return qy_n1(i);
+      if (j == npy - 1) {
+        const Real g_in = dya[IX(i, npy - 2)] / dya[IX(i, npy - 1)];
+        return ((Real)3 * (Q(i, npy - 2) + g_in * Q(i, npy - 1)) - (g_in * qy_n1(i) + qy_int(i, npy - 2))) / ((Real)2 + (Real)2 * g_in);
+      }
+    }
+    return qy_int(i, j);
+  }
+  // values on the tile edge lines (linear in the along-edge direction)
+  FV3_HD Real q2x(int ie_, int j) const {  // between cell columns ie_-1 and ie_
+    return (Q(ie_ - 1, j) * dxa[IX(ie_, j)] + Q(ie_, j) * dxa[IX(ie_ - 1, j)]) / (dxa[IX(ie_ - 1, j)] + dxa[IX(ie_, j)]);
+  }
+  FV3_HD Real q1y(int i, int je_) const {
+    return (Q(i, je_ - 1) * dya[IX(i, je_)] + Q(i, je_) * dya[IX(i, je_ - 1)]) / (dya[IX(i, je_ - 1)] + dya[IX(i, je_)]);
+  }
+  FV3_HD Real edge_x(int ie_, int j, Real w) const { return w * q2x(ie_, j - 1) + ((Real)1 - w) * q2x(ie_, j); }
+  FV3_HD Real edge_y(int i, int je_, Real w) const { return w * q1y(i - 1, je_) + ((Real)1 - w) * q1y(i, je_); }
+  FV3_HD Real qxx_int(int i, int j) const { return A2B_A2 * (qx(i, j - 2) + qx(i, j + 1)) + A2B_A1 * (qx(i, j - 1) + qx(i, j)); }
+  FV3_HD Real qyy_int(int i, int j) const { return A2B_A2 * (qy(i - 2, j) + qy(i + 1, j)) + A2B_A1 * (qy(i - 1, j) + qy(i, j)); }
+};
+
+FV3_HD inline Real extrap(Real fac, Real q1, Real q2) { return q1 + fac * (q1 - q2); }
+
+}  // namespace
+
+void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace) {
+  const Geo g = c->g;
+  Real *out = replace ? c->scratch[SC_K] : qout;
+  const int kshift = replace ? 0 : (kout0 - kin0);
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    A2B a;
+    a.g = g;
+    a.q = qin + t * g.st + k * g.sk;
+    a.dxa = g.dxa + t * g.st2;
+    a.dya = g.dya + t * g.st2;
+    a.W = fl & FV3_W;
+    a.E = fl & FV3_E;
+    a.S = fl & FV3_S;
+    a.N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const bool onW = a.W && i == 1, onE = a.E && i == npx, onS = a.S && j == 1, onN = a.N && j == npy;
+    const Real *ce = g.corner_extrap + t * 12;
+    Real r;
+    if (onW && onS) {
+      r = (extrap(ce[0], a.Q(1, 1), a.Q(2, 2)) + extrap(ce[1], a.Q(0, 1), a.Q(-1, 2)) + extrap(ce[2], a.Q(1, 0), a.Q(2, -1))) * A2B_R3;
+    } else if (onE && onS) {
+      r = (extrap(ce[3], a.Q(npx - 1, 1), a.Q(npx - 2, 2)) + extrap(ce[4], a.Q(npx - 1, 0), a.Q(npx - 2, -1)) + extrap(ce[5], a.Q(npx, 1), a.Q(npx + 1, 2))) *
+          A2B_R3;
+    } else if (onE && onN) {
+      r = (extrap(ce[6], a.Q(npx - 1, npy - 1), a.Q(npx - 2, npy - 2)) + extrap(ce[7], a.Q(npx, npy - 1), a.Q(npx + 1, npy - 2)) +
+           extrap(ce[8], a.Q(npx - 1, npy), a.Q(npx - 2, npy + 1))) *
+          A2B_R3;
+    } else if (onW && onN) {
+      r = (extrap(ce[9], a.Q(1, npy - 1), a.Q(2, npy - 2)) + extrap(ce[10], a.Q(0, npy - 1), a.Q(-1, npy - 2)) + extrap(ce[11], a.Q(1, npy), a.Q(2, npy + 1))) *
+          A2B_R3;
+    } else if (onW) {
+      r = a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]);
+    } else if (onE) {
+      r = a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]);
+    } else if (onS) {
+      r = a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]);
+    } else if (onN) {
+      r = a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]);
+    } else {
+      Real qxx, qyy;
+      if (a.S && j == 2)
+        qxx = A2B_C1 * (a.qx(i, 1) + a.qx(i, 2)) + A2B_C2 * (a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]) + a.qxx_int(i, 3));
+      else if (a.N && j == npy - 1)
+        qxx = A2B_C1 * (a.qx(i, npy - 2) + a.qx(i, npy - 1)) + A2B_C2 * (a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]) + a.qxx_int(i, npy - 2));
+      else
+        qxx = a.qxx_int(i, j);
+      if (a.W && i == 2)
+        qyy = A2B_C1 * (a.qy(1, j) + a.qy(2, j)) + A2B_C2 * (a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]) + a.qyy_int(3, j));
+      else if (a.E && i == npx - 1)
+        qyy = A2B_C1 * (a.qy(npx - 2, j) + a.qy(npx - 1, j)) + A2B_C2 * (a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]) + a.qyy_int(npx - 2, j));
+      else
+        qyy = a.qyy_int(i, j);
+      r = (Real)0.5 * (qxx + qyy);
+    }
+    out[t * g.st + (k + kshift) * g.sk + IX(i, j)] = r;
+  });
+  if (replace) {
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      qin[p] = out[p];
+    });
+  }
+}
+
+extern "C" int fv3_a2b_ord4(fv3_ctx *c, const fv3_field *qin_, const fv3_field *qout_, int kstart, int nk, int replace, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(qin, qin_) FV3_FIELD(qout, qout_)
+  if (kstart < 0 || nk < 1 || kstart + nk > c->g.nkA) return fv3_fail(c, FV3_ERR_ARG, "a2b_ord4: vertical range outside the allocation");
+  if (qin == qout) {
+    if (!replace) return fv3_fail(c, FV3_ERR_ARG, "a2b_ord4: qin and qout alias but replace is off");
+    a2b_ord4(c, (fv3_stream_t)stream, qin, qout, kstart, kstart, nk, true);
+  } else {
+    a2b_ord4(c, (fv3_stream_t)stream, qin, qout, kstart, kstart, nk, false);
+    if (replace) {
+      const Geo g = c->g;
+      launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, kstart, kstart + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+        const long p = t * g.st + k * g.sk + IX(i, j);
+        qin[p] = qout[p];
+      });
+    }
+  }
+  return fv3_post(c, (fv3_stream_t)stream, "a2b_ord4");
+}

@@ -1,0 +1,294 @@
+// fv3_common.h -- shared device/host definitions of the MI355X FV3 acoustic kernels.
+//
+// Layout: every 3-D field is [n_sub][nk_alloc][nj_alloc][ni_alloc], i fastest, so the 64
+// lanes of a wavefront read 64 consecutive i (512 B rows for fp64).  Kernels are written in
+// the reference's local Fortran numbering (first compute cell 1, npx = nx+1) through the
+// IX() macro so that every loop bound can be checked against the oracle / FV3 source.
+//
+// The stage bodies are lambdas handed to launch3()/launch2(); under hipcc they run as
+// gfx950 kernels, and the SAME source can be compiled with g++ (-DFV3_HOST_EMU) into a
+// test-only library that executes the lambdas as host loops, so kernel logic is checked
+// against the oracle in the GPU-less build container.  The host-emulation build is test
+// infrastructure: the product loader refuses it (see pace_amd/lib.py).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fv3_mi355x.h"
+
+#ifdef FV3_HOST_EMU
+#define FV3_HD
+#define FV3_DEV
+typedef void *fv3_stream_t;
+#else
+#include <hip/hip_runtime.h>
+#define FV3_HD __host__ __device__
+#define FV3_DEV __device__
+typedef hipStream_t fv3_stream_t;
+#endif
+
+#ifndef FV3_REAL
+#define FV3_REAL double
+#endif
+typedef FV3_REAL Real;
+
+#define FV3_W 1
+#define FV3_E 2
+#define FV3_S 4
+#define FV3_N 8
+
+// Geometry + metric terms, captured by value in every stage lambda.
+struct Geo {
+  int nx, ny, nz, nh, nsub;
+  int npx, npy;
+  int ni, nj, nkA;  // allocation extents
+  int o;            // nh - 1: Fortran-local index -> storage index offset
+  long sj, sk, st;  // strides of 3-D fields: j, k, sub
+  long st2;         // sub stride of 2-D fields
+  unsigned char flags[FV3_MAX_SUB];
+  const Real *dx, *dy, *dxa, *dya, *dxc, *dyc, *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
+  const Real *area, *rarea, *area_c, *rarea_c;
+  const Real *cosa, *sina, *rsina, *cosa_u, *cosa_v, *cosa_s, *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
+  const Real *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4, *cos_sg1, *cos_sg2, *cos_sg3, *cos_sg4;
+  const Real *fC, *f0, *del6_u, *del6_v, *divg_u, *divg_v;
+  const Real *edge_w, *edge_e, *edge_s, *edge_n;
+  const Real *corner_extrap;  // [nsub][4][3]
+  const Real *dp_ref, *pfull; // [nz]
+  const Real *ep_gam;         // [nz+1] edge_profile back-substitution factors (function of dp_ref)
+  // per-level parameters (get_column_namelist), device arrays [nz+1]
+  const int *nord, *nord_v, *nord_w, *nord_t;
+  const Real *damp_vt, *damp_w, *damp_t, *d2_divg, *d_con, *ke_bg;
+  Real da_min, da_min_c;
+};
+
+// storage offset of Fortran-local (i, j) inside one k-plane
+#define IX(i, j) ((long)((j) + g.o) * g.sj + ((i) + g.o))
+
+struct Box {
+  int i0, i1, j0, j1, k0, k1;  // inclusive; i, j Fortran-local; k 0-based
+};
+
+// per-level coefficient tables precomputed on the host at context creation (device arrays [nz+1])
+struct DampTables {
+  const Real *tp_vt;  // (damp_vt * da_min)^(nord_v+1)   fv_tp_2d of delp, pt
+  const Real *tp_t;   // (damp_t  * da_min)^(nord_t+1)   fv_tp_2d of q_con
+  const Real *d6_w;   // (damp_w  * da_min_c)^(nord_w+1) del6_vt_flux of w
+  const Real *d6_vt;  // (damp_vt * da_min_c)^(nord_v+1) del6_vt_flux of vorticity
+  const Real *dd8;    // (da_min_c * d4_bg)^(nord+1)     divergence damping
+};
+
+struct fv3_ctx {
+  Geo g;
+  DampTables tab;
+  fv3_acoustic_config cfg;
+  fv3_constants cst;
+  int device;
+  int dtype;
+  int device_sync;
+  double ptop;
+  std::vector<double> ak, bk, dp_ref_h, pfull_h;
+  std::vector<int> nord_h, nord_v_h, nord_w_h, nord_t_h;
+  std::vector<double> damp_vt_h, damp_w_h, damp_t_h, d2_divg_h, d_con_h, ke_bg_h;
+  std::vector<void *> owned;   // device allocations owned by the context
+  std::vector<Real *> scratch; // 3-D scratch fields (full layout)
+  int64_t scratch_bytes;
+  // Rayleigh-damping table cache (ray_fast)
+  void *tab_rf = nullptr;
+  double rf_dt = 0.0, rf_ptop = 0.0, rf_dm = 0.0;
+  int rf_nd = 0, rf_nn = 0;
+  std::string err;
+};
+
+struct fv3_gather_plan {
+  int64_t n;
+  int64_t *dst_off;
+  int64_t *src_off;
+  signed char *sign;
+};
+
+// ---------------------------------------------------------------------------------------------
+// error helpers
+// ---------------------------------------------------------------------------------------------
+extern std::string g_fv3_create_error;
+int fv3_fail(fv3_ctx *c, int code, const std::string &msg);
+void *fv3_dev_alloc(fv3_ctx *c, size_t bytes);
+void fv3_h2d(void *dst, const void *src, size_t bytes);
+int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what);
+// validate one field against the context layout; returns typed base pointer or nullptr
+Real *fv3_chk(fv3_ctx *c, const fv3_field *f, const char *name, bool is2d = false);
+
+#define FV3_FIELD(var, f)                \
+  Real *var = fv3_chk(c, f, #f);         \
+  if (!var) return FV3_ERR_ARG;
+#define FV3_FIELD2D(var, f)              \
+  Real *var = fv3_chk(c, f, #f, true);   \
+  if (!var) return FV3_ERR_ARG;
+
+// ---------------------------------------------------------------------------------------------
+// launch: f(t, k, i, j) over a box for every sub-domain; f2(t, i, j) for column kernels
+// ---------------------------------------------------------------------------------------------
+#ifndef FV3_HOST_EMU
+template <class F>
+__global__ void __launch_bounds__(256) fv3_k3(Box b, int nk, F f) {
+  const int i = b.i0 + (int)(blockIdx.x * 64 + threadIdx.x);
+  const int j = b.j0 + (int)(blockIdx.y * 4 + threadIdx.y);
+  const int kz = (int)blockIdx.z;
+  const int t = kz / nk;
+  const int k = b.k0 + (kz - t * nk);
+  if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+}
+template <class F>
+__global__ void __launch_bounds__(256) fv3_k2(Box b, F f) {
+  const int i = b.i0 + (int)(blockIdx.x * 64 + threadIdx.x);
+  const int j = b.j0 + (int)(blockIdx.y * 4 + threadIdx.y);
+  const int t = (int)blockIdx.z;
+  if (i <= b.i1 && j <= b.j1) f(t, i, j);
+}
+#endif
+
+template <class F>
+inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
+  const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nk = b.k1 - b.k0 + 1;
+  if (ni <= 0 || nj <= 0 || nk <= 0) return;
+#ifdef FV3_HOST_EMU
+  (void)s;
+  const int nsub = c->g.nsub;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int t = 0; t < nsub; ++t)
+    for (int k = b.k0; k <= b.k1; ++k)
+      for (int j = b.j0; j <= b.j1; ++j)
+        for (int i = b.i0; i <= b.i1; ++i) f(t, k, i, j);
+#else
+  dim3 block(64, 4, 1);
+  dim3 grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nk);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3<F>), grid, block, 0, s, b, nk, f);
+#endif
+}
+
+template <class F>
+inline void launch2(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
+  const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1;
+  if (ni <= 0 || nj <= 0) return;
+#ifdef FV3_HOST_EMU
+  (void)s;
+  const int nsub = c->g.nsub;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int t = 0; t < nsub; ++t)
+    for (int j = b.j0; j <= b.j1; ++j)
+      for (int i = b.i0; i <= b.i1; ++i) f(t, i, j);
+#else
+  dim3 block(64, 4, 1);
+  dim3 grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k2<F>), grid, block, 0, s, b, f);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// cube-corner halo reads.  The reference fills the 3x3 corner block in place before every
+// directional sweep (copy_corners / fill_4corners / fill_corners); the fills are pure
+// functions of edge-halo cells, so here the *read* is redirected instead: no extra launch,
+// no in-place race.  DIR 1 = x sweep, 2 = y sweep.  [SURVEY A.13]
+// ---------------------------------------------------------------------------------------------
+template <int DIR>
+FV3_HD inline long cc_index(const Geo &g, int fl, int i, int j) {
+  // returns IX of the cell a copy_corners'ed read of cell (i, j) resolves to
+  if ((i >= 1 && i <= g.nx) || (j >= 1 && j <= g.ny)) return IX(i, j);
+  const int npx = g.npx, npy = g.npy;
+  if (i < 1 && j < 1) {
+    if ((fl & (FV3_W | FV3_S)) != (FV3_W | FV3_S)) return IX(i, j);
+    return DIR == 1 ? IX(j, 1 - i) : IX(1 - j, i);
+  }
+  if (i > g.nx && j < 1) {
+    if ((fl & (FV3_E | FV3_S)) != (FV3_E | FV3_S)) return IX(i, j);
+    return DIR == 1 ? IX(npx - j, i - npx + 1) : IX(npx - 1 + j, npx - i);
+  }
+  if (i > g.nx && j > g.ny) {
+    if ((fl & (FV3_E | FV3_N)) != (FV3_E | FV3_N)) return IX(i, j);
+    return DIR == 1 ? IX(npx + (j - npy), npy - 1 - (i - npx)) : IX(npx - 1 - (j - npy), npy + (i - npx));
+  }
+  if ((fl & (FV3_W | FV3_N)) != (FV3_W | FV3_N)) return IX(i, j);
+  return DIR == 1 ? IX(npy - j, npy - 1 + i) : IX(j - npy + 1, npy - i);
+}
+
+template <int DIR>
+FV3_HD inline Real cc(const Real *q, const Geo &g, int fl, int i, int j) {
+  return q[cc_index<DIR>(g, fl, i, j)];
+}
+
+// fill_4corners read (c_sw, update_dz_c): only the two corner cells next to the edge exist
+template <int DIR>
+FV3_HD inline long f4_index(const Geo &g, int fl, int i, int j) {
+  if ((i >= 1 && i <= g.nx) || (j >= 1 && j <= g.ny)) return IX(i, j);
+  const int npx = g.npx, npy = g.npy;
+  if (i < 1 && j < 1 && (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S)) {
+    if (DIR == 1) {
+      if (j == 0 && i == 0) return IX(0, 1);
+      if (j == 0 && i == -1) return IX(0, 2);
+    } else {
+      if (i == 0 && j == 0) return IX(1, 0);
+      if (i == 0 && j == -1) return IX(2, 0);
+    }
+  } else if (i > g.nx && j < 1 && (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S)) {
+    if (DIR == 1) {
+      if (j == 0 && i == npx) return IX(npx, 1);
+      if (j == 0 && i == npx + 1) return IX(npx, 2);
+    } else {
+      if (i == npx && j == 0) return IX(npx - 1, 0);
+      if (i == npx && j == -1) return IX(npx - 2, 0);
+    }
+  } else if (i > g.nx && j > g.ny && (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N)) {
+    if (DIR == 1) {
+      if (j == npy && i == npx) return IX(npx, npy - 1);
+      if (j == npy && i == npx + 1) return IX(npx, npy - 2);
+    } else {
+      if (i == npx && j == npy) return IX(npx - 1, npy);
+      if (i == npx && j == npy + 1) return IX(npx - 2, npy);
+    }
+  } else if (i < 1 && j > g.ny && (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N)) {
+    if (DIR == 1) {
+      if (j == npy && i == 0) return IX(0, npy - 1);
+      if (j == npy && i == -1) return IX(0, npy - 2);
+    } else {
+      if (i == 0 && j == npy) return IX(1, npy);
+      if (i == 0 && j == npy + 1) return IX(2, npy);
+    }
+  }
+  return IX(i, j);
+}
+
+// fill_corners for a corner-staggered (B-grid) scalar: points (i, j) with both indices
+// strictly outside [1, npx] x [1, npy]
+template <int DIR>
+FV3_HD inline long bc_index(const Geo &g, int fl, int i, int j) {
+  const int npx = g.npx, npy = g.npy;
+  if ((i >= 1 && i <= npx) || (j >= 1 && j <= npy)) return IX(i, j);
+  if (i < 1 && j < 1) {
+    if ((fl & (FV3_W | FV3_S)) != (FV3_W | FV3_S)) return IX(i, j);
+    // target (1-a, 1-b), a,b >= 1
+    const int a = 1 - i, b = 1 - j;
+    return DIR == 1 ? IX(1 - b, a + 1) : IX(b + 1, 1 - a);
+  }
+  if (i < 1 && j > npy) {
+    if ((fl & (FV3_W | FV3_N)) != (FV3_W | FV3_N)) return IX(i, j);
+    const int a = 1 - i, b = j - npy;
+    return DIR == 1 ? IX(1 - b, npy - a) : IX(b + 1, npy + a);
+  }
+  if (i > npx && j < 1) {
+    if ((fl & (FV3_E | FV3_S)) != (FV3_E | FV3_S)) return IX(i, j);
+    const int a = i - npx, b = 1 - j;
+    return DIR == 1 ? IX(npx + b, a + 1) : IX(npx - b, 1 - a);
+  }
+  if ((fl & (FV3_E | FV3_N)) != (FV3_E | FV3_N)) return IX(i, j);
+  const int a = i - npx, b = j - npy;
+  return DIR == 1 ? IX(npx + b, npy - a) : IX(npx - b, npy + a);
+}
+
+FV3_HD inline Real fv3_sign(Real a, Real b) { return b >= (Real)0 ? fabs(a) : -fabs(a); }
+FV3_HD inline Real fv3_max(Real a, Real b) { return a > b ? a : b; }
+FV3_HD inline Real fv3_min(Real a, Real b) { return a < b ? a : b; }

@@ -1,0 +1,326 @@
+// fv3_csw.hip -- C-grid half step c_sw (d2a2c_vect, divergence_corner, upwind transport of
+// delp / pt / w, C-grid kinetic energy + absolute vorticity, time-centred uc / vc).
+// CPU twin: oracle/fv3_oracle/c_sw.py.  [SURVEY A.2; reference operator CGridShallowWaterDynamics,
+// checkpoint variables REF tests/savepoint/thresholds/fv_dynamics.yaml:2-75]
+//
+// 5 launches: (A) ua/va  (B) uc,ut / vc,vt with the dt2*dy*sin geometry factor folded in
+// (C) corner divergence  (D) delpc, ptc, wc, ke + absolute vorticity  (E) uc/vc update.
+// utmp / vtmp of d2a2c_vect are pure functions of (u, v) and are evaluated in registers.
+#include "fv3_ops.h"
+
+#define CSW_A1 ((Real)0.5625)
+#define CSW_A2 ((Real)-0.0625)
+#define CSW_C1 ((Real)(-2.0 / 14.0))
+#define CSW_C2 ((Real)(11.0 / 14.0))
+#define CSW_C3 ((Real)(5.0 / 14.0))
+
+namespace {
+
+struct D2A {
+  Geo g;
+  const Real *u, *v;  // level bases
+  bool W, E, S, N;
+
+  FV3_HD bool two_pt(int i, int j) const {
+    return (S && j <= 3) || (N && j >= g.npy - 3) || (W && i <= 3) || (E && i >= g.npx - 3);
+  }
+  // raw (no corner fix) utmp / vtmp
+  FV3_HD Real utmp0(int i, int j) const {
+    if (two_pt(i, j)) return (Real)0.5 * (u[IX(i, j)] + u[IX(i, j + 1)]);
+    return CSW_A2 * (u[IX(i, j - 1)] + u[IX(i, j + 2)]) + CSW_A1 * (u[IX(i, j)] + u[IX(i, j + 1)]);
+  }
+  FV3_HD Real vtmp0(int i, int j) const {
+    if (two_pt(i, j)) return (Real)0.5 * (v[IX(i, j)] + v[IX(i + 1, j)]);
+    return CSW_A2 * (v[IX(i - 1, j)] + v[IX(i + 2, j)]) + CSW_A1 * (v[IX(i, j)] + v[IX(i + 1, j)]);
+  }
+  // utmp as seen by the x-direction A->C interpolation (corner halo rows fixed from vtmp)
+  FV3_HD Real utmp_x(int i, int j) const {
+    const int npx = g.npx, npy = g.npy, je = g.ny;
+    if (S && j == 0) {
+      if (W && i >= -2 && i <= 0) return -vtmp0(0, 1 - i);
+      if (E && i >= npx && i <= npx + 2) return vtmp0(npx, i - npx + 1);
+    }
+    if (N && j == npy) {
+      if (E && i >= npx && i <= npx + 2) return -vtmp0(npx, je - (i - npx));
+      if (W && i >= -2 && i <= 0) return vtmp0(0, je + i);
+    }
+    return utmp0(i, j);
+  }
+  FV3_HD Real vtmp_y(int i, int j) const {
+    const int npx = g.npx, npy = g.npy, ie = g.nx;
+    if (W && i == 0) {
+      if (S && j >= -2 && j <= 0) return -utmp0(1 - j, 0);
+      if (N && j >= npy && j <= npy + 2) return utmp0(j - npy + 1, npy);
+    }
+    if (E && i == npx) {
+      if (S && j >= -2 && j <= 0) return utmp0(ie + j, 0);
+      if (N && j >= npy && j <= npy + 2) return -utmp0(ie - (j - npy), npy);
+    }
+    return vtmp0(i, j);
+  }
+};
+
+FV3_HD inline Real edge_interp4(Real u1, Real u2, Real u3, Real u4, Real d1, Real d2, Real d3, Real d4) {
+  return (Real)0.5 * ((((Real)2 * d2 + d1) * u2 - d2 * u1) / (d1 + d2) + (((Real)2 * d3 + d4) * u3 - d3 * u4) / (d3 + d4));
+}
+
+}  // namespace
+
+extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_, const fv3_field *w_,
+                        const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_, const fv3_field *ut_, const fv3_field *vt_,
+                        const fv3_field *divgd_, const fv3_field *omga_, const fv3_field *delpc_, const fv3_field *ptc_, double dt2d, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(delp, delp_) FV3_FIELD(pt, pt_) FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(w, w_) FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_)
+  FV3_FIELD(ua, ua_) FV3_FIELD(va, va_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_) FV3_FIELD(divgd, divgd_) FV3_FIELD(omga, omga_)
+  FV3_FIELD(delpc, delpc_) FV3_FIELD(ptc, ptc_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt2 = (Real)dt2d;
+  const int nz1 = g.nz - 1;
+  const int nord = c->cfg.nord;
+  Real *ke = c->scratch[SC_A], *vort = c->scratch[SC_B];
+
+  // (A) contravariant A-grid winds on is-2..ie+2
+  launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
+    const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
+    const long p = IX(i, j);
+    ua[b + p] = (ut_ - vt_ * g.cosa_s[m2 + p]) * g.rsin2[m2 + p];
+    va[b + p] = (vt_ - ut_ * g.cosa_s[m2 + p]) * g.rsin2[m2 + p];
+  });
+
+  // (B) C-grid winds + contravariant ut, vt (already scaled: dt2 * ut * dy * sin_sg)
+  launch3(c, s, Box{0, g.nx + 2, 0, g.ny + 2, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    D2A d{g, u + b, v + b, W, E, S, N};
+    const int npx = g.npx, npy = g.npy;
+    const Real *uaa = ua + b, *vaa = va + b;
+    // ua / va with the corner fixes the edge interpolation reads
+    auto UA = [&](int ii, int jj) -> Real {
+      if (S && jj == 0) {
+        if (W && ii == -1) return -vaa[IX(0, 2)];
+        if (W && ii == 0) return -vaa[IX(0, 1)];
+        if (E && ii == npx) return vaa[IX(npx, 1)];
+        if (E && ii == npx + 1) return vaa[IX(npx, 2)];
+      }
+      if (N && jj == npy) {
+        if (E && ii == npx) return -vaa[IX(npx, npy - 1)];
+        if (E && ii == npx + 1) return -vaa[IX(npx, npy - 2)];
+        if (W && ii == -1) return vaa[IX(0, npy - 2)];
+        if (W && ii == 0) return vaa[IX(0, npy - 1)];
+      }
+      return uaa[IX(ii, jj)];
+    };
+    auto VA = [&](int ii, int jj) -> Real {
+      if (W && ii == 0) {
+        if (S && jj == -1) return -uaa[IX(2, 0)];
+        if (S && jj == 0) return -uaa[IX(1, 0)];
+        if (N && jj == npy) return uaa[IX(1, npy)];
+        if (N && jj == npy + 1) return uaa[IX(2, npy)];
+      }
+      if (E && ii == npx) {
+        if (S && jj == 0) return uaa[IX(npx - 1, 0)];
+        if (S && jj == -1) return uaa[IX(npx - 2, 0)];
+        if (N && jj == npy) return -uaa[IX(npx - 1, npy)];
+        if (N && jj == npy + 1) return -uaa[IX(npx - 2, npy)];
+      }
+      return vaa[IX(ii, jj)];
+    };
+    const long p = IX(i, j);
+    if (j <= g.ny + 1) {  // uc, ut on i = is-1..ie+2, j = js-1..je+1
+      Real ucv = (Real)0, utv;
+      bool edge = false;
+      if (W && i <= 2) {
+        edge = true;
+        if (i == 0)
+          ucv = CSW_C1 * d.utmp_x(-2, j) + CSW_C2 * d.utmp_x(-1, j) + CSW_C3 * d.utmp_x(0, j);
+        else if (i == 2)
+          ucv = CSW_C1 * d.utmp_x(3, j) + CSW_C2 * d.utmp_x(2, j) + CSW_C3 * d.utmp_x(1, j);
+      } else if (E && i >= npx - 1) {
+        edge = true;
+        if (i == npx - 1)
+          ucv = CSW_C1 * d.utmp_x(npx - 3, j) + CSW_C2 * d.utmp_x(npx - 2, j) + CSW_C3 * d.utmp_x(npx - 1, j);
+        else if (i == npx + 1)
+          ucv = CSW_C3 * d.utmp_x(npx, j) + CSW_C2 * d.utmp_x(npx + 1, j) + CSW_C1 * d.utmp_x(npx + 2, j);
+      }
+      if (edge && (i == 1 || i == npx)) {
+        utv = edge_interp4(UA(i - 2, j), UA(i - 1, j), UA(i, j), UA(i + 1, j), g.dxa[m2 + IX(i - 2, j)], g.dxa[m2 + IX(i - 1, j)], g.dxa[m2 + IX(i, j)],
+                           g.dxa[m2 + IX(i + 1, j)]);
+        ucv = utv > (Real)0 ? utv * g.sin_sg3[m2 + IX(i - 1, j)] : utv * g.sin_sg1[m2 + p];
+      } else {
+        if (!edge) ucv = CSW_A2 * (d.utmp_x(i - 2, j) + d.utmp_x(i + 1, j)) + CSW_A1 * (d.utmp_x(i - 1, j) + d.utmp_x(i, j));
+        utv = (ucv - v[b + p] * g.cosa_u[m2 + p]) * g.rsin_u[m2 + p];
+      }
+      uc[b + p] = ucv;
+      ut[b + p] = utv > (Real)0 ? dt2 * utv * g.dy[m2 + p] * g.sin_sg3[m2 + IX(i - 1, j)] : dt2 * utv * g.dy[m2 + p] * g.sin_sg1[m2 + p];
+    }
+    if (i <= g.nx + 1) {  // vc, vt on i = is-1..ie+1, j = js-1..je+2
+      Real vcv = (Real)0, vtv;
+      bool edge = false;
+      if (S && j <= 2) {
+        edge = true;
+        if (j == 0)
+          vcv = CSW_C1 * d.vtmp_y(i, -2) + CSW_C2 * d.vtmp_y(i, -1) + CSW_C3 * d.vtmp_y(i, 0);
+        else if (j == 2)
+          vcv = CSW_C1 * d.vtmp_y(i, 3) + CSW_C2 * d.vtmp_y(i, 2) + CSW_C3 * d.vtmp_y(i, 1);
+      } else if (N && j >= npy - 1) {
+        edge = true;
+        if (j == npy - 1)
+          vcv = CSW_C1 * d.vtmp_y(i, npy - 3) + CSW_C2 * d.vtmp_y(i, npy - 2) + CSW_C3 * d.vtmp_y(i, npy - 1);
+        else if (j == npy + 1)
+          vcv = CSW_C1 * d.vtmp_y(i, npy + 2) + CSW_C2 * d.vtmp_y(i, npy + 1) + CSW_C3 * d.vtmp_y(i, npy);
+      }
+      if (edge && (j == 1 || j == npy)) {
+        vtv = edge_interp4(VA(i, j - 2), VA(i, j - 1), VA(i, j), VA(i, j + 1), g.dya[m2 + IX(i, j - 2)], g.dya[m2 + IX(i, j - 1)], g.dya[m2 + IX(i, j)],
+                           g.dya[m2 + IX(i, j + 1)]);
+        vcv = vtv > (Real)0 ? vtv * g.sin_sg4[m2 + IX(i, j - 1)] : vtv * g.sin_sg2[m2 + p];
+      } else {
+        if (!edge) vcv = CSW_A2 * (d.vtmp_y(i, j - 2) + d.vtmp_y(i, j + 1)) + CSW_A1 * (d.vtmp_y(i, j - 1) + d.vtmp_y(i, j));
+        vtv = (vcv - u[b + p] * g.cosa_v[m2 + p]) * g.rsin_v[m2 + p];
+      }
+      vc[b + p] = vcv;
+      vt[b + p] = vtv > (Real)0 ? dt2 * vtv * g.dx[m2 + p] * g.sin_sg4[m2 + IX(i, j - 1)] : dt2 * vtv * g.dx[m2 + p] * g.sin_sg2[m2 + p];
+    }
+  });
+
+  // the in-place corner fixes of ua / va the reference leaves behind (checkpointed as uad / vad)
+  launch3(c, s, Box{1, 1, 1, 1, 0, nz1}, [=] FV3_HD(int t, int k, int, int) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    Real *uaa = ua + b, *vaa = va + b;
+    Real n_ua[8], n_va[8];
+    // read everything first (sources are never targets of the other set's sources)
+    if (W && S) { n_ua[0] = -vaa[IX(0, 2)]; n_ua[1] = -vaa[IX(0, 1)]; }
+    if (E && S) { n_ua[2] = vaa[IX(npx, 1)]; n_ua[3] = vaa[IX(npx, 2)]; }
+    if (E && N) { n_ua[4] = -vaa[IX(npx, npy - 1)]; n_ua[5] = -vaa[IX(npx, npy - 2)]; }
+    if (W && N) { n_ua[6] = vaa[IX(0, npy - 2)]; n_ua[7] = vaa[IX(0, npy - 1)]; }
+    if (W && S) { uaa[IX(-1, 0)] = n_ua[0]; uaa[IX(0, 0)] = n_ua[1]; }
+    if (E && S) { uaa[IX(npx, 0)] = n_ua[2]; uaa[IX(npx + 1, 0)] = n_ua[3]; }
+    if (E && N) { uaa[IX(npx, npy)] = n_ua[4]; uaa[IX(npx + 1, npy)] = n_ua[5]; }
+    if (W && N) { uaa[IX(-1, npy)] = n_ua[6]; uaa[IX(0, npy)] = n_ua[7]; }
+    if (W && S) { n_va[0] = -uaa[IX(2, 0)]; n_va[1] = -uaa[IX(1, 0)]; }
+    if (E && S) { n_va[2] = uaa[IX(npx - 1, 0)]; n_va[3] = uaa[IX(npx - 2, 0)]; }
+    if (E && N) { n_va[4] = -uaa[IX(npx - 1, npy)]; n_va[5] = -uaa[IX(npx - 2, npy)]; }
+    if (W && N) { n_va[6] = uaa[IX(1, npy)]; n_va[7] = uaa[IX(2, npy)]; }
+    if (W && S) { vaa[IX(0, -1)] = n_va[0]; vaa[IX(0, 0)] = n_va[1]; }
+    if (E && S) { vaa[IX(npx, 0)] = n_va[2]; vaa[IX(npx, -1)] = n_va[3]; }
+    if (E && N) { vaa[IX(npx, npy)] = n_va[4]; vaa[IX(npx, npy + 1)] = n_va[5]; }
+    if (W && N) { vaa[IX(0, npy)] = n_va[6]; vaa[IX(0, npy + 1)] = n_va[7]; }
+  });
+
+  // (C) divergence on corners
+  if (nord > 0) {
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+      const int npx = g.npx, npy = g.npy;
+      auto UF = [&](int ii, int jj) -> Real {
+        const long q = IX(ii, jj), qm = IX(ii, jj - 1);
+        if ((S && jj == 1) || (N && jj == npy)) return u[b + q] * g.dyc[m2 + q] * (Real)0.5 * (g.sin_sg4[m2 + qm] + g.sin_sg2[m2 + q]);
+        return (u[b + q] - (Real)0.25 * (va[b + qm] + va[b + q]) * (g.cos_sg4[m2 + qm] + g.cos_sg2[m2 + q])) * g.dyc[m2 + q] * (Real)0.5 *
+               (g.sin_sg4[m2 + qm] + g.sin_sg2[m2 + q]);
+      };
+      auto VF = [&](int ii, int jj) -> Real {
+        const long q = IX(ii, jj), qm = IX(ii - 1, jj);
+        if ((W && ii == 1) || (E && ii == npx)) return v[b + q] * g.dxc[m2 + q] * (Real)0.5 * (g.sin_sg3[m2 + qm] + g.sin_sg1[m2 + q]);
+        return (v[b + q] - (Real)0.25 * (ua[b + qm] + ua[b + q]) * (g.cos_sg3[m2 + qm] + g.cos_sg1[m2 + q])) * g.dxc[m2 + q] * (Real)0.5 *
+               (g.sin_sg3[m2 + qm] + g.sin_sg1[m2 + q]);
+      };
+      Real dv = VF(i, j - 1) - VF(i, j) + UF(i - 1, j) - UF(i, j);
+      if (W && S && i == 1 && j == 1) dv -= VF(1, 0);
+      if (E && S && i == npx && j == 1) dv -= VF(npx, 0);
+      if (E && N && i == npx && j == npy) dv += VF(npx, npy);
+      if (W && N && i == 1 && j == npy) dv += VF(1, npy);
+      divgd[b + IX(i, j)] = g.rarea_c[m2 + IX(i, j)] * dv;
+    });
+  }
+
+  // (D) upwind transport (delpc, ptc, wc), kinetic energy, absolute vorticity
+  launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const long p = IX(i, j);
+    {
+      // x fluxes at faces i and i+1 (fill_4corners x), y fluxes at j and j+1 (fill_4corners y)
+      Real fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
+      for (int a = 0; a < 2; ++a) {
+        const int ii = i + a;
+        const Real utv = ut[b + IX(ii, j)];
+        const long src = utv > (Real)0 ? f4_index<1>(g, fl, ii - 1, j) : f4_index<1>(g, fl, ii, j);
+        fx1[a] = utv * delp[b + src];
+        fx[a] = fx1[a] * pt[b + src];
+        fx2[a] = fx1[a] * w[b + src];
+        const int jj = j + a;
+        const Real vtv = vt[b + IX(i, jj)];
+        const long srcy = vtv > (Real)0 ? f4_index<2>(g, fl, i, jj - 1) : f4_index<2>(g, fl, i, jj);
+        fy1[a] = vtv * delp[b + srcy];
+        fy[a] = fy1[a] * pt[b + srcy];
+        fy2[a] = fy1[a] * w[b + srcy];
+      }
+      const Real ra = g.rarea[m2 + p];
+      const Real dpc = delp[b + p] + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
+      delpc[b + p] = dpc;
+      ptc[b + p] = (pt[b + p] * delp[b + p] + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
+      omga[b + p] = (w[b + p] * delp[b + p] + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
+    }
+    {
+      const Real uav = ua[b + p], vav = va[b + p];
+      Real kev = uav > (Real)0 ? uc[b + p] : uc[b + IX(i + 1, j)];
+      Real vov = vav > (Real)0 ? vc[b + p] : vc[b + IX(i, j + 1)];
+      if ((W && i == 1) || (E && i == npx)) {
+        if (uav > (Real)0) kev = uc[b + p] * g.sin_sg1[m2 + p] + v[b + p] * g.cos_sg1[m2 + p];
+      }
+      if ((W && i == 0) || (E && i == npx - 1)) {
+        if (!(uav > (Real)0)) kev = uc[b + IX(i + 1, j)] * g.sin_sg3[m2 + p] + v[b + IX(i + 1, j)] * g.cos_sg3[m2 + p];
+      }
+      if ((S && j == 1) || (N && j == npy)) {
+        if (vav > (Real)0) vov = vc[b + p] * g.sin_sg2[m2 + p] + u[b + p] * g.cos_sg2[m2 + p];
+      }
+      if ((S && j == 0) || (N && j == npy - 1)) {
+        if (!(vav > (Real)0)) vov = vc[b + IX(i, j + 1)] * g.sin_sg4[m2 + p] + u[b + IX(i, j + 1)] * g.cos_sg4[m2 + p];
+      }
+      ke[b + p] = (Real)0.5 * dt2 * (uav * kev + vav * vov);
+    }
+    if (i >= 1 && j >= 1) {  // absolute vorticity on corners is..ie+1, js..je+1
+      auto FX = [&](int ii, int jj) { return uc[b + IX(ii, jj)] * g.dxc[m2 + IX(ii, jj)]; };
+      auto FY = [&](int ii, int jj) { return vc[b + IX(ii, jj)] * g.dyc[m2 + IX(ii, jj)]; };
+      Real vo = FX(i, j - 1) - FX(i, j) - FY(i - 1, j) + FY(i, j);
+      if (W && S && i == 1 && j == 1) vo += FY(0, 1);
+      if (E && S && i == npx && j == 1) vo -= FY(npx, 1);
+      if (E && N && i == npx && j == npy) vo -= FY(npx, npy);
+      if (W && N && i == 1 && j == npy) vo += FY(0, npy);
+      vort[b + p] = g.fC[m2 + p] + g.rarea_c[m2 + p] * vo;
+    }
+  });
+
+  // (E) time-centred C-grid winds
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const long p = IX(i, j);
+    if (j <= g.ny) {
+      const Real ucv = uc[b + p];
+      Real fy1 = ((W && i == 1) || (E && i == npx)) ? dt2 * v[b + p] : dt2 * (v[b + p] - ucv * g.cosa_u[m2 + p]) / g.sina_u[m2 + p];
+      const Real fyv = fy1 > (Real)0 ? vort[b + p] : vort[b + IX(i, j + 1)];
+      uc[b + p] = ucv + fy1 * fyv + g.rdxc[m2 + p] * (ke[b + IX(i - 1, j)] - ke[b + p]);
+    }
+    if (i <= g.nx) {
+      const Real vcv = vc[b + p];
+      Real fx1 = ((S && j == 1) || (N && j == npy)) ? dt2 * u[b + p] : dt2 * (u[b + p] - vcv * g.cosa_v[m2 + p]) / g.sina_v[m2 + p];
+      const Real fxv = fx1 > (Real)0 ? vort[b + p] : vort[b + IX(i + 1, j)];
+      vc[b + p] = vcv - fx1 * fxv + g.rdyc[m2 + p] * (ke[b + IX(i, j - 1)] - ke[b + p]);
+    }
+  });
+  return fv3_post(c, s, "c_sw");
+}

@@ -1,0 +1,401 @@
+// fv3_ctx.hip -- context life cycle, argument validation, glue stencils, gather (halo) kernel.
+#include "fv3_common.h"
+
+std::string g_fv3_create_error;
+
+int fv3_fail(fv3_ctx *c, int code, const std::string &msg) {
+  if (c)
+    c->err = msg;
+  else
+    g_fv3_create_error = msg;
+  return code;
+}
+
+#ifdef FV3_HOST_EMU
+static void *raw_alloc(size_t bytes) { return calloc(1, bytes ? bytes : 1); }
+static void raw_free(void *p) { free(p); }
+void fv3_h2d(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+#else
+static void *raw_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  (void)hipMemset(p, 0, bytes ? bytes : 1);
+  return p;
+}
+static void raw_free(void *p) { (void)hipFree(p); }
+void fv3_h2d(void *dst, const void *src, size_t bytes) { (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+#endif
+
+void *fv3_dev_alloc(fv3_ctx *c, size_t bytes) {
+  void *p = raw_alloc(bytes);
+  if (p) {
+    c->owned.push_back(p);
+    c->scratch_bytes += (int64_t)bytes;
+  }
+  return p;
+}
+
+int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what) {
+#ifdef FV3_HOST_EMU
+  (void)c;
+  (void)s;
+  (void)what;
+  return FV3_OK;
+#else
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fv3_fail(c, FV3_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  if (c->device_sync) {
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fv3_fail(c, FV3_ERR_HIP, std::string(what) + " (sync): " + hipGetErrorString(e));
+  }
+  return FV3_OK;
+#endif
+}
+
+Real *fv3_chk(fv3_ctx *c, const fv3_field *f, const char *name, bool is2d) {
+  const Geo &g = c->g;
+  auto bad = [&](const char *why) -> Real * {
+    fv3_fail(c, FV3_ERR_ARG, std::string("field '") + name + "': " + why);
+    return nullptr;
+  };
+  if (!f || !f->ptr) return bad("null");
+  if (f->dtype != c->dtype) return bad("dtype differs from the context's");
+  if (f->n_sub != g.nsub) return bad("n_sub differs from the context's");
+  if (f->shape[0] != g.ni || f->shape[1] != g.nj) return bad("horizontal shape differs from the context layout");
+  if (f->stride[0] != 1 || f->stride[1] != g.sj) return bad("horizontal strides differ from the context layout (i must be fastest)");
+  if (is2d) {
+    if (f->shape[2] != 1) return bad("expected a 2-D field (shape[2] == 1)");
+    if (f->sub_stride != g.st2) return bad("sub-domain stride differs from the 2-D layout");
+  } else {
+    if (f->shape[2] != g.nkA || f->stride[2] != g.sk) return bad("vertical shape/stride differs from the context layout");
+    if (f->sub_stride != g.st) return bad("sub-domain stride differs from the 3-D layout");
+  }
+  return (Real *)f->ptr;
+}
+
+template <class T>
+static const T *upload(fv3_ctx *c, const std::vector<T> &h) {
+  void *d = fv3_dev_alloc(c, h.size() * sizeof(T));
+  if (d) fv3_h2d(d, h.data(), h.size() * sizeof(T));
+  return (const T *)d;
+}
+
+// get_column_namelist [SURVEY A.3.9]
+static void column_namelist(fv3_ctx *c) {
+  const fv3_acoustic_config &cf = c->cfg;
+  const int nz = c->g.nz, n = nz + 1;
+  auto &nord = c->nord_h, &nord_v = c->nord_v_h, &nord_w = c->nord_w_h, &nord_t = c->nord_t_h;
+  auto &damp_vt = c->damp_vt_h, &damp_w = c->damp_w_h, &damp_t = c->damp_t_h, &d2 = c->d2_divg_h, &d_con = c->d_con_h, &ke_bg = c->ke_bg_h;
+  nord.assign(n, cf.nord);
+  nord_v.assign(n, cf.nord < 2 ? cf.nord : 2);
+  nord_w = nord_v;
+  nord_t = nord_v;
+  damp_vt.assign(n, cf.do_vort_damp ? cf.vtdm4 : 0.0);
+  damp_w = damp_vt;
+  damp_t = damp_vt;
+  d2.assign(n, cf.d2_bg < 0.2 ? cf.d2_bg : 0.2);
+  d_con.assign(n, cf.d_con);
+  ke_bg.assign(n, cf.ke_bg);
+  auto set_low = [&](int k) {
+    nord[k] = 0;
+    nord_w[k] = 0;
+    d_con[k] = 0.0;
+    damp_w[k] = d2[k];
+  };
+  auto lowest = [&](int k) {
+    set_low(k);
+    if (cf.do_vort_damp) {
+      nord_v[k] = 0;
+      damp_vt[k] = 0.5 * d2[k];
+    }
+  };
+  if (nz == 1 || cf.n_sponge < 0) {
+    d2[0] = cf.d2_bg;
+  } else {
+    d2[0] = std::fmax(0.01, std::fmax(cf.d2_bg, cf.d2_bg_k1));
+    lowest(0);
+    if (cf.d2_bg_k2 > 0.01 && nz > 1) {
+      d2[1] = std::fmax(cf.d2_bg, cf.d2_bg_k2);
+      lowest(1);
+    }
+    if (cf.d2_bg_k2 > 0.05 && nz > 2) {
+      d2[2] = std::fmax(cf.d2_bg, 0.2 * cf.d2_bg_k2);
+      set_low(2);
+    }
+  }
+  // interface nz (used by update_dz_d) repeats the last layer
+  nord_v[nz] = nord_v[nz - 1];
+  damp_vt[nz] = damp_vt[nz - 1];
+}
+
+extern "C" {
+
+int fv3_version(void) { return FV3_ABI_VERSION; }
+
+const char *fv3_backend(void) {
+#ifdef FV3_HOST_EMU
+  return "hostemu";
+#else
+  return "hip:gfx950";
+#endif
+}
+
+const char *fv3_last_error(const fv3_ctx *ctx) { return ctx ? ctx->err.c_str() : g_fv3_create_error.c_str(); }
+
+int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *grid, const fv3_acoustic_config *cfg,
+                   const fv3_constants *consts, int device, int dtype) {
+  if (!out || !spec || !grid || !cfg || !consts) return fv3_fail(nullptr, FV3_ERR_ARG, "null argument");
+  if (dtype != (sizeof(Real) == 8 ? FV3_F64 : FV3_F32))
+    return fv3_fail(nullptr, FV3_ERR_ARG, "dtype does not match this library build (one .so per precision)");
+  if (spec->n_sub < 1 || spec->n_sub > FV3_MAX_SUB) return fv3_fail(nullptr, FV3_ERR_ARG, "n_sub outside 1..FV3_MAX_SUB");
+  if (spec->n_halo != 3) return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "n_halo must be 3");
+  if (spec->nx < 4 || spec->ny < 4 || spec->nz < 3) return fv3_fail(nullptr, FV3_ERR_ARG, "need nx, ny >= 4 and nz >= 3");
+  // specialisation of the kernels == every reference config
+  if (cfg->hydrostatic) return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "hydrostatic=true is not on the accelerated path");
+  if (cfg->a_imp <= 0.999) return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "a_imp <= 0.999: only the SIM1 solver is implemented");
+  if (cfg->beta != 0.0 || cfg->d_ext != 0.0 || cfg->use_logp || cfg->grid_type != 0)
+    return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "beta/d_ext/use_logp/grid_type outside the supported set");
+  const int hords[4] = {cfg->hord_dp, cfg->hord_mt, cfg->hord_tm, cfg->hord_vt};
+  for (int h : hords)
+    if (h != 5 && h != 6) return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "hord_* must be 5 or 6");
+  if (cfg->nord < 0 || cfg->nord > 3) return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED, "nord outside 0..3");
+#ifndef FV3_HOST_EMU
+  if (hipSetDevice(device) != hipSuccess) return fv3_fail(nullptr, FV3_ERR_HIP, "hipSetDevice failed");
+#endif
+  fv3_ctx *c = new fv3_ctx();
+  c->cfg = *cfg;
+  c->cst = *consts;
+  c->device = device;
+  c->dtype = dtype;
+  c->device_sync = 0;
+  c->scratch_bytes = 0;
+  Geo &g = c->g;
+  memset(&g, 0, sizeof(g));
+  g.nx = spec->nx;
+  g.ny = spec->ny;
+  g.nz = spec->nz;
+  g.nh = spec->n_halo;
+  g.nsub = spec->n_sub;
+  g.npx = g.nx + 1;
+  g.npy = g.ny + 1;
+  g.ni = g.nx + 2 * g.nh + 1;
+  g.nj = g.ny + 2 * g.nh + 1;
+  g.nkA = g.nz + 1;
+  g.o = g.nh - 1;
+  g.sj = g.ni;
+  g.sk = (long)g.ni * g.nj;
+  g.st = g.sk * g.nkA;
+  g.st2 = g.sk;
+  for (int t = 0; t < g.nsub; ++t) g.flags[t] = (unsigned char)(spec->edge_flags[t] & 15);
+#define CP(n)                                                              \
+  g.n = (const Real *)grid->n;                                             \
+  if (!g.n) {                                                              \
+    delete c;                                                              \
+    return fv3_fail(nullptr, FV3_ERR_ARG, "griddata." #n " is null");      \
+  }
+  CP(dx) CP(dy) CP(dxa) CP(dya) CP(dxc) CP(dyc) CP(rdx) CP(rdy) CP(rdxa) CP(rdya) CP(rdxc) CP(rdyc)
+  CP(area) CP(rarea) CP(area_c) CP(rarea_c) CP(cosa) CP(sina) CP(rsina) CP(cosa_u) CP(cosa_v) CP(cosa_s)
+  CP(sina_u) CP(sina_v) CP(rsin_u) CP(rsin_v) CP(rsin2) CP(sin_sg1) CP(sin_sg2) CP(sin_sg3) CP(sin_sg4)
+  CP(cos_sg1) CP(cos_sg2) CP(cos_sg3) CP(cos_sg4) CP(fC) CP(f0) CP(del6_u) CP(del6_v) CP(divg_u) CP(divg_v)
+  CP(edge_w) CP(edge_e) CP(edge_s) CP(edge_n)
+#undef CP
+  if (!grid->corner_extrap || !grid->ak || !grid->bk) {
+    delete c;
+    return fv3_fail(nullptr, FV3_ERR_ARG, "griddata host arrays (corner_extrap, ak, bk) are null");
+  }
+  g.da_min = (Real)grid->da_min;
+  g.da_min_c = (Real)grid->da_min_c;
+  const int nz = g.nz;
+  c->ak.assign(grid->ak, grid->ak + nz + 1);
+  c->bk.assign(grid->bk, grid->bk + nz + 1);
+  c->ptop = c->ak[0];
+  c->dp_ref_h.resize(nz);
+  c->pfull_h.resize(nz);
+  for (int k = 0; k < nz; ++k) {
+    c->dp_ref_h[k] = (c->ak[k + 1] - c->ak[k]) + (c->bk[k + 1] - c->bk[k]) * 1.0e5;
+    const double ph1 = c->ak[k] + c->bk[k] * 1.0e5, ph2 = c->ak[k + 1] + c->bk[k + 1] * 1.0e5;
+    c->pfull_h[k] = (ph2 - ph1) / std::log(ph2 / ph1);
+  }
+  column_namelist(c);
+  auto toReal = [](const std::vector<double> &v) { return std::vector<Real>(v.begin(), v.end()); };
+  g.dp_ref = upload(c, toReal(c->dp_ref_h));
+  g.pfull = upload(c, toReal(c->pfull_h));
+  {
+    // FV3 edge_profile: gam[k] of the layer -> interface spline (update_dz_d)
+    const std::vector<double> &dp0 = c->dp_ref_h;
+    std::vector<double> gd(nz + 1, 0.0);
+    const double g0 = dp0[1] / dp0[0];
+    double bet = g0 * (g0 + 0.5);
+    gd[0] = (1.0 + g0 * (g0 + 1.5)) / bet;
+    for (int k = 1; k < nz; ++k) {
+      const double gk = dp0[k - 1] / dp0[k];
+      bet = 2.0 + 2.0 * gk - gd[k - 1];
+      gd[k] = gk / bet;
+    }
+    g.ep_gam = upload(c, toReal(gd));
+  }
+  g.nord = upload(c, c->nord_h);
+  g.nord_v = upload(c, c->nord_v_h);
+  g.nord_w = upload(c, c->nord_w_h);
+  g.nord_t = upload(c, c->nord_t_h);
+  g.damp_vt = upload(c, toReal(c->damp_vt_h));
+  g.damp_w = upload(c, toReal(c->damp_w_h));
+  g.damp_t = upload(c, toReal(c->damp_t_h));
+  g.d2_divg = upload(c, toReal(c->d2_divg_h));
+  g.d_con = upload(c, toReal(c->d_con_h));
+  g.ke_bg = upload(c, toReal(c->ke_bg_h));
+  {
+    const int n = nz + 1;
+    std::vector<Real> tp_vt(n), tp_t(n), d6_w(n), d6_vt(n), dd8(n);
+    for (int k = 0; k < n; ++k) {
+      tp_vt[k] = (Real)std::pow(c->damp_vt_h[k] * grid->da_min, (double)(c->nord_v_h[k] + 1));
+      tp_t[k] = (Real)std::pow(c->damp_t_h[k] * grid->da_min, (double)(c->nord_t_h[k] + 1));
+      d6_w[k] = (Real)std::pow(c->damp_w_h[k] * grid->da_min_c, (double)(c->nord_w_h[k] + 1));
+      d6_vt[k] = (Real)std::pow(c->damp_vt_h[k] * grid->da_min_c, (double)(c->nord_v_h[k] + 1));
+      dd8[k] = (Real)std::pow(grid->da_min_c * cfg->d4_bg, (double)(c->nord_h[k] + 1));
+    }
+    c->tab.tp_vt = upload(c, tp_vt);
+    c->tab.tp_t = upload(c, tp_t);
+    c->tab.d6_w = upload(c, d6_w);
+    c->tab.d6_vt = upload(c, d6_vt);
+    c->tab.dd8 = upload(c, dd8);
+  }
+  {
+    std::vector<Real> ce(grid->corner_extrap, grid->corner_extrap + (size_t)g.nsub * 12);
+    g.corner_extrap = upload(c, ce);
+  }
+  // scratch: full-layout 3-D work fields shared by the operators (never allocated at call time)
+  const int n_scratch = 18;
+  for (int s = 0; s < n_scratch; ++s) {
+    Real *p = (Real *)fv3_dev_alloc(c, (size_t)g.st * g.nsub * sizeof(Real));
+    if (!p) {
+      fv3_ctx_destroy(c);
+      return fv3_fail(nullptr, FV3_ERR_NOMEM, "device scratch allocation failed");
+    }
+    c->scratch.push_back(p);
+  }
+  *out = c;
+  return FV3_OK;
+}
+
+int fv3_ctx_destroy(fv3_ctx *c) {
+  if (!c) return FV3_OK;
+  for (void *p : c->owned) raw_free(p);
+  delete c;
+  return FV3_OK;
+}
+
+int64_t fv3_ctx_scratch_bytes(const fv3_ctx *c) { return c ? c->scratch_bytes : 0; }
+
+int fv3_ctx_set_device_sync(fv3_ctx *c, int on) {
+  if (!c) return FV3_ERR_ARG;
+  c->device_sync = on;
+  return FV3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// glue stencils of dyn_core  [SURVEY a14]
+// ---------------------------------------------------------------------------------------------
+int fv3_copy(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, void *stream) {
+  FV3_FIELD(a, src) FV3_FIELD(b, dst)
+  const Geo g = c->g;
+  launch3(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    b[p] = a[p];
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "copy");
+}
+
+int fv3_zero(fv3_ctx *c, const fv3_field *dst, void *stream) {
+  FV3_FIELD(b, dst)
+  const Geo g = c->g;
+  launch3(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    b[t * g.st + k * g.sk + IX(i, j)] = (Real)0;
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "zero");
+}
+
+int fv3_set_gz(fv3_ctx *c, const fv3_field *zs_, const fv3_field *delz_, const fv3_field *gz_, void *stream) {
+  FV3_FIELD2D(zs, zs_) FV3_FIELD(delz, delz_) FV3_FIELD(gz, gz_)
+  const Geo g = c->g;
+  launch2(c, (fv3_stream_t)stream, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p2 = t * g.st2 + IX(i, j);
+    const long p = t * g.st + IX(i, j);
+    Real z = zs[p2];
+    gz[p + g.nz * g.sk] = z;
+    for (int k = g.nz - 1; k >= 0; --k) {
+      z -= delz[p + k * g.sk];
+      gz[p + k * g.sk] = z;
+    }
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "set_gz");
+}
+
+int fv3_compute_geopotential(fv3_ctx *c, const fv3_field *zh_, const fv3_field *gz_, void *stream) {
+  FV3_FIELD(zh, zh_) FV3_FIELD(gz, gz_)
+  const Geo g = c->g;
+  const Real grav = (Real)c->cst.grav;
+  launch3(c, (fv3_stream_t)stream, Box{-1, g.nx + 2, -1, g.ny + 2, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    gz[p] = zh[p] * grav;
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "compute_geopotential");
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather: pack / unpack / device-local halo copy
+// ---------------------------------------------------------------------------------------------
+int fv3_gather_plan_create(fv3_ctx *c, fv3_gather_plan **out, int64_t n, const int64_t *dst_off, const int64_t *src_off, const int8_t *sign) {
+  if (!c || !out || n < 0) return FV3_ERR_ARG;
+  fv3_gather_plan *p = new fv3_gather_plan();
+  p->n = n;
+  p->dst_off = (int64_t *)raw_alloc(n * sizeof(int64_t));
+  p->src_off = (int64_t *)raw_alloc(n * sizeof(int64_t));
+  p->sign = (signed char *)raw_alloc(n);
+  if (!p->dst_off || !p->src_off || !p->sign) return fv3_fail(c, FV3_ERR_NOMEM, "gather plan allocation failed");
+  if (n) {
+    fv3_h2d(p->dst_off, dst_off, n * sizeof(int64_t));
+    fv3_h2d(p->src_off, src_off, n * sizeof(int64_t));
+    fv3_h2d(p->sign, sign, n);
+  }
+  *out = p;
+  return FV3_OK;
+}
+
+int fv3_gather_plan_destroy(fv3_gather_plan *p) {
+  if (!p) return FV3_OK;
+  raw_free(p->dst_off);
+  raw_free(p->src_off);
+  raw_free(p->sign);
+  delete p;
+  return FV3_OK;
+}
+
+#ifndef FV3_HOST_EMU
+__global__ void __launch_bounds__(256) fv3_gather_kernel(int64_t n, const int64_t *__restrict__ dst_off, const int64_t *__restrict__ src_off,
+                                                         const signed char *__restrict__ sign, Real *dst, int64_t dks, const Real *src, int64_t sks, int nk) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (e < n) dst[dst_off[e] + k * dks] = (Real)sign[e] * src[src_off[e] + k * sks];
+}
+#endif
+
+int fv3_gather_run(fv3_ctx *c, const fv3_gather_plan *p, void *dst, int64_t dks, const void *src, int64_t sks, int nk, void *stream) {
+  if (!c || !p || !dst || !src) return FV3_ERR_ARG;
+  if (p->n == 0 || nk <= 0) return FV3_OK;
+#ifdef FV3_HOST_EMU
+  Real *d = (Real *)dst;
+  const Real *s = (const Real *)src;
+  for (int k = 0; k < nk; ++k)
+    for (int64_t e = 0; e < p->n; ++e) d[p->dst_off[e] + k * dks] = (Real)p->sign[e] * s[p->src_off[e] + k * sks];
+  (void)stream;
+  return FV3_OK;
+#else
+  dim3 grid((unsigned)((p->n + 255) / 256), (unsigned)nk, 1);
+  hipLaunchKernelGGL(fv3_gather_kernel, grid, dim3(256, 1, 1), 0, (hipStream_t)stream, p->n, p->dst_off, p->src_off, p->sign, (Real *)dst, dks,
+                     (const Real *)src, sks, nk);
+  return fv3_post(c, (fv3_stream_t)stream, "gather");
+#endif
+}
+
+}  // extern "C"

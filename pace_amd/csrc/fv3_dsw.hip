@@ -1,0 +1,561 @@
+// fv3_dsw.hip -- D-grid full step d_sw: fxadv flux preparation, transport of delp / w / q_con /
+// pt, corner kinetic energy (xtp_u / ytp_v), divergence damping, vorticity flux, damping heat.
+// CPU twin: oracle/fv3_oracle/d_sw.py.  [SURVEY A.3; reference operator
+// DGridShallowWaterLagrangianDynamics, REF tests/savepoint/thresholds/fv_dynamics.yaml:76-170]
+//
+// Per-level parameters (nord, damp, d_con of the sponge layers) come from device tables indexed
+// by k = blockIdx.z, so one launch serves all levels (the reference builds one stencil per
+// k-range through restrict_vertical).
+#include "fv3_ops.h"
+#include "fv3_ppm.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// fxadv: contravariant winds as pure functions of (uc, vc)
+// ---------------------------------------------------------------------------------------------
+struct FxAdv {
+  Geo g;
+  const Real *uc, *vc;  // level bases
+  long m2;
+  Real dt;
+  bool W, E, S, N;
+
+  FV3_HD Real UC(int i, int j) const { return uc[IX(i, j)]; }
+  FV3_HD Real VC(int i, int j) const { return vc[IX(i, j)]; }
+  FV3_HD Real ut_gen(int i, int j) const {
+    return (UC(i, j) - (Real)0.25 * g.cosa_u[m2 + IX(i, j)] * (VC(i - 1, j) + VC(i, j) + VC(i - 1, j + 1) + VC(i, j + 1))) * g.rsin_u[m2 + IX(i, j)];
+  }
+  FV3_HD Real vt_gen(int i, int j) const {
+    return (VC(i, j) - (Real)0.25 * g.cosa_v[m2 + IX(i, j)] * (UC(i, j - 1) + UC(i + 1, j - 1) + UC(i, j) + UC(i + 1, j))) * g.rsin_v[m2 + IX(i, j)];
+  }
+  FV3_HD bool edge_col(int i) const { return (W && i == 1) || (E && i == g.npx); }
+  FV3_HD bool edge_row(int j) const { return (S && j == 1) || (N && j == g.npy); }
+  FV3_HD bool ut_special_row(int j) const { return (S && (j == 0 || j == 1)) || (N && (j == g.npy - 1 || j == g.npy)); }
+  FV3_HD Real ut_edge(int i, int j) const {
+    const Real u_ = UC(i, j);
+    return u_ * dt > (Real)0 ? u_ / g.sin_sg3[m2 + IX(i - 1, j)] : u_ / g.sin_sg1[m2 + IX(i, j)];
+  }
+  FV3_HD Real vt_edge(int i, int j) const {
+    const Real v_ = VC(i, j);
+    return v_ * dt > (Real)0 ? v_ / g.sin_sg4[m2 + IX(i, j - 1)] : v_ / g.sin_sg2[m2 + IX(i, j)];
+  }
+  // stage-1 values (before the S/N row, W/E column and corner refinements)
+  FV3_HD Real ut1(int i, int j) const {
+    if (edge_col(i)) return ut_edge(i, j);
+    if (ut_special_row(j)) return (Real)0;  // not produced by the general formula
+    return ut_gen(i, j);
+  }
+  FV3_HD Real vt1(int i, int j) const {
+    if (edge_row(j)) return vt_edge(i, j);
+    return vt_gen(i, j);
+  }
+  // ranges of the edge-parallel refinements
+  FV3_HD bool in_i_rng(int i) const { return i >= (W ? 3 : 1) && i <= (E ? g.npx - 2 : g.nx + 1); }
+  FV3_HD bool in_j_rng(int j) const { return j >= (S ? 3 : 1) && j <= (N ? g.npy - 2 : g.ny + 1); }
+  FV3_HD bool vt_edge_col(int i) const { return (W && (i == 0 || i == 1)) || (E && (i == g.npx - 1 || i == g.npx)); }
+  // stage-2: all but the cube-corner solves
+  FV3_HD Real ut2(int i, int j) const {
+    if (edge_col(i)) return ut_edge(i, j);
+    if (ut_special_row(j)) {
+      if (in_i_rng(i))
+        return UC(i, j) - (Real)0.25 * g.cosa_u[m2 + IX(i, j)] * (vt1(i - 1, j) + vt1(i, j) + vt1(i - 1, j + 1) + vt1(i, j + 1));
+      return (Real)0;
+    }
+    return ut_gen(i, j);
+  }
+  FV3_HD Real vt2(int i, int j) const {
+    if (edge_row(j)) return vt_edge(i, j);
+    if (vt_edge_col(i) && in_j_rng(j))
+      return VC(i, j) - (Real)0.25 * g.cosa_v[m2 + IX(i, j)] * (ut1(i, j - 1) + ut1(i + 1, j - 1) + ut1(i, j) + ut1(i + 1, j));
+    return vt_gen(i, j);
+  }
+  // cube-corner coupled solves (oracle _corner_solve): the target's one unknown neighbour -- its
+  // partner across the corner -- is eliminated with the partner's own averaging formula.
+  FV3_HD bool ut_corner_target(int i, int j, bool &west, bool &south) const {
+    const int npx = g.npx, npy = g.npy;
+    if (W && i == 2) {
+      if (S && (j == 0 || j == 1)) { west = true; south = true; return true; }
+      if (N && (j == npy - 1 || j == npy)) { west = true; south = false; return true; }
+    }
+    if (E && i == npx - 1) {
+      if (S && (j == 0 || j == 1)) { west = false; south = true; return true; }
+      if (N && (j == npy - 1 || j == npy)) { west = false; south = false; return true; }
+    }
+    return false;
+  }
+  FV3_HD bool vt_corner_target(int i, int j, bool &west, bool &south) const {
+    const int npx = g.npx, npy = g.npy;
+    if (S && j == 2) {
+      if (W && (i == 0 || i == 1)) { west = true; south = true; return true; }
+      if (E && (i == npx - 1 || i == npx)) { west = false; south = true; return true; }
+    }
+    if (N && j == npy - 1) {
+      if (W && (i == 0 || i == 1)) { west = true; south = false; return true; }
+      if (E && (i == npx - 1 || i == npx)) { west = false; south = false; return true; }
+    }
+    return false;
+  }
+  FV3_HD Real ut_corner(int it, int j, bool west, bool south) const {
+    const int npx = g.npx, npy = g.npy;
+    const int pi = west ? 1 : npx - 1;
+    const int jedge = south ? 1 : npy;
+    const int nbi[4] = {it - 1, it, it - 1, it}, nbj[4] = {j, j, j + 1, j + 1};
+    const int pj = (j != jedge) ? j : j + 1;  // first neighbour row that is not the edge row
+    Real s_v = (Real)0;
+    for (int n = 0; n < 4; ++n)
+      if (!(nbi[n] == pi && nbj[n] == pj)) s_v = s_v + vt2(nbi[n], nbj[n]);
+    const int pbi[4] = {pi, pi + 1, pi, pi + 1}, pbj[4] = {pj - 1, pj - 1, pj, pj};
+    Real s_u = (Real)0;
+    for (int n = 0; n < 4; ++n)
+      if (!(pbi[n] == it && pbj[n] == j)) s_u = s_u + ut2(pbi[n], pbj[n]);
+    const Real cu = g.cosa_u[m2 + IX(it, j)], cv = g.cosa_v[m2 + IX(pi, pj)];
+    const Real damp = (Real)1 / ((Real)1 - (Real)0.0625 * cu * cv);
+    return (UC(it, j) - (Real)0.25 * cu * (s_v + VC(pi, pj) - (Real)0.25 * cv * s_u)) * damp;
+  }
+  FV3_HD Real vt_corner(int i, int jt, bool west, bool south) const {
+    const int npx = g.npx, npy = g.npy;
+    const int pj = south ? 1 : npy - 1;
+    const int iedge = west ? 1 : npx;
+    const int nbi[4] = {i, i + 1, i, i + 1}, nbj[4] = {jt - 1, jt - 1, jt, jt};
+    const int pi = (i != iedge) ? i : i + 1;
+    Real s_u = (Real)0;
+    for (int n = 0; n < 4; ++n)
+      if (!(nbi[n] == pi && nbj[n] == pj)) s_u = s_u + ut2(nbi[n], nbj[n]);
+    const int pbi[4] = {pi - 1, pi, pi - 1, pi}, pbj[4] = {pj, pj, pj + 1, pj + 1};
+    Real s_v = (Real)0;
+    for (int n = 0; n < 4; ++n)
+      if (!(pbi[n] == i && pbj[n] == jt)) s_v = s_v + vt2(pbi[n], pbj[n]);
+    const Real cv = g.cosa_v[m2 + IX(i, jt)], cu = g.cosa_u[m2 + IX(pi, pj)];
+    const Real damp = (Real)1 / ((Real)1 - (Real)0.0625 * cu * cv);
+    return (VC(i, jt) - (Real)0.25 * cv * (s_u + UC(pi, pj) - (Real)0.25 * cu * s_v)) * damp;
+  }
+  FV3_HD Real ut_final(int i, int j) const {
+    bool w_, s_;
+    if (ut_corner_target(i, j, w_, s_)) return ut_corner(i, j, w_, s_);
+    return ut2(i, j);
+  }
+  FV3_HD Real vt_final(int i, int j) const {
+    bool w_, s_;
+    if (vt_corner_target(i, j, w_, s_)) return vt_corner(i, j, w_, s_);
+    return vt2(i, j);
+  }
+};
+
+void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt) {
+  const Geo g = c->g;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    FxAdv f{g, uc + b, vc + b, m2, dt, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
+    const long p = IX(i, j);
+    if (i >= 0) {  // ut on is-1..ie+3, jsd..jed
+      const Real utv = f.ut_final(i, j);
+      ut[b + p] = utv;
+      if (i >= 1 && i <= g.nx + 1) {
+        const Real x = dt * utv;
+        if (x > (Real)0) {
+          crx[b + p] = x * g.rdxa[m2 + IX(i - 1, j)];
+          xfx[b + p] = g.dy[m2 + p] * x * g.sin_sg3[m2 + IX(i - 1, j)];
+        } else {
+          crx[b + p] = x * g.rdxa[m2 + p];
+          xfx[b + p] = g.dy[m2 + p] * x * g.sin_sg1[m2 + p];
+        }
+      }
+    }
+    if (j >= 0) {  // vt on isd..ied, js-1..je+3
+      const Real vtv = f.vt_final(i, j);
+      vt[b + p] = vtv;
+      if (j >= 1 && j <= g.ny + 1) {
+        const Real y = dt * vtv;
+        if (y > (Real)0) {
+          cry[b + p] = y * g.rdya[m2 + IX(i, j - 1)];
+          yfx[b + p] = g.dx[m2 + p] * y * g.sin_sg4[m2 + IX(i, j - 1)];
+        } else {
+          cry[b + p] = y * g.rdya[m2 + p];
+          yfx[b + p] = g.dx[m2 + p] * y * g.sin_sg2[m2 + p];
+        }
+      }
+    }
+  });
+}
+
+// fill_corners of the D-grid staggered pair (x = "vc" at (cell, iface), y = "uc" at (iface, cell))
+// used inside the divergence-damping iteration; returns the value a filled read would see.
+FV3_HD inline Real dg_x(const Real *x, const Real *y, const Geo &g, int fl, int i, int j, Real sign) {
+  // x lives at (x cell i, y interface j): corner block when i outside [1,nx] and j outside [1,npy]
+  const int npx = g.npx, npy = g.npy;
+  if ((i >= 1 && i <= g.nx) || (j >= 1 && j <= npy)) return x[IX(i, j)];
+  if (i < 1 && j < 1) {
+    if ((fl & (FV3_W | FV3_S)) != (FV3_W | FV3_S)) return x[IX(i, j)];
+    const int a = 1 - i, b = 1 - j;  // target (1-a, 1-b)
+    return sign * y[IX(1 - b, a)];
+  }
+  if (i < 1 && j > npy) {
+    if ((fl & (FV3_W | FV3_N)) != (FV3_W | FV3_N)) return x[IX(i, j)];
+    const int a = 1 - i, b = j - npy;
+    return y[IX(1 - b, npy - a)];
+  }
+  if (i > g.nx && j < 1) {
+    if ((fl & (FV3_E | FV3_S)) != (FV3_E | FV3_S)) return x[IX(i, j)];
+    const int a = i - (npx - 1), b = 1 - j;  // target (npx-1+a, 1-b)
+    return y[IX(npx + b, a)];
+  }
+  if ((fl & (FV3_E | FV3_N)) != (FV3_E | FV3_N)) return x[IX(i, j)];
+  const int a = i - (npx - 1), b = j - npy;
+  return sign * y[IX(npx + b, npy - a)];
+}
+FV3_HD inline Real dg_y(const Real *x, const Real *y, const Geo &g, int fl, int i, int j, Real sign) {
+  // y lives at (x interface i, y cell j): corner block when i outside [1,npx] and j outside [1,ny]
+  const int npx = g.npx, npy = g.npy;
+  if ((i >= 1 && i <= npx) || (j >= 1 && j <= g.ny)) return y[IX(i, j)];
+  if (i < 1 && j < 1) {
+    if ((fl & (FV3_W | FV3_S)) != (FV3_W | FV3_S)) return y[IX(i, j)];
+    const int b = 1 - i, a = 1 - j;  // target (1-b, 1-a)
+    return sign * x[IX(a, 1 - b)];
+  }
+  if (i < 1 && j > g.ny) {
+    if ((fl & (FV3_W | FV3_N)) != (FV3_W | FV3_N)) return y[IX(i, j)];
+    const int b = 1 - i, a = j - (npy - 1);  // target (1-b, npy-1+a)
+    return x[IX(a, npy + b)];
+  }
+  if (i > npx && j < 1) {
+    if ((fl & (FV3_E | FV3_S)) != (FV3_E | FV3_S)) return y[IX(i, j)];
+    const int b = i - npx, a = 1 - j;  // target (npx+b, 1-a)
+    return x[IX(npx - a, 1 - b)];
+  }
+  if ((fl & (FV3_E | FV3_N)) != (FV3_E | FV3_N)) return y[IX(i, j)];
+  const int b = i - npx, a = j - (npy - 1);
+  return sign * x[IX(npx - a, npy + b)];
+}
+
+}  // namespace
+
+extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_,
+                         const fv3_field *yfx_, const fv3_field *ut_, const fv3_field *vt_, double dt, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_) FV3_FIELD(crx, crx_) FV3_FIELD(cry, cry_) FV3_FIELD(xfx, xfx_) FV3_FIELD(yfx, yfx_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_)
+  fxadv(c, (fv3_stream_t)stream, uc, vc, crx, cry, xfx, yfx, ut, vt, (Real)dt);
+  return fv3_post(c, (fv3_stream_t)stream, "fxadv");
+}
+
+extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,
+                        const fv3_field *w_, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_,
+                        const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
+                        const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
+                        const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(delpc, delpc_) FV3_FIELD(delp, delp_) FV3_FIELD(pt, pt_) FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(w, w_) FV3_FIELD(uc, uc_)
+  FV3_FIELD(vc, vc_) FV3_FIELD(ua, ua_) FV3_FIELD(va, va_) FV3_FIELD(divgd, divgd_) FV3_FIELD(mfx, mfx_) FV3_FIELD(mfy, mfy_) FV3_FIELD(cx, cx_)
+  FV3_FIELD(cy, cy_) FV3_FIELD(crx, crx_) FV3_FIELD(cry, cry_) FV3_FIELD(xfx, xfx_) FV3_FIELD(yfx, yfx_) FV3_FIELD(q_con, q_con_)
+  FV3_FIELD(heat_source, heat_source_)
+  (void)zh_;
+  (void)diss_est_;  // accumulated only with do_skeb (unsupported); kept for signature parity
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt = (Real)dtd;
+  const fv3_acoustic_config cf = c->cfg;
+  const DampTables tab = c->tab;
+  const int nz1 = g.nz - 1;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  Real *ut = c->scratch[SC_A], *vt = c->scratch[SC_B], *fx = c->scratch[SC_C], *fy = c->scratch[SC_D], *gx = c->scratch[SC_E], *gy = c->scratch[SC_F];
+  Real *dw = c->scratch[SC_G], *heat_s = c->scratch[SC_H], *ke = c->scratch[SC_I], *wk = c->scratch[SC_J];
+  int nord_max_v = 0, nord_max_w = 0, nord_max_t = 0, nord_max = 0;
+  for (int k = 0; k < g.nz; ++k) {
+    nord_max_v = std::max(nord_max_v, c->nord_v_h[k]);
+    nord_max_w = std::max(nord_max_w, c->nord_w_h[k]);
+    nord_max_t = std::max(nord_max_t, c->nord_t_h[k]);
+    nord_max = std::max(nord_max, c->nord_h[k]);
+  }
+
+  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt);
+
+  // ---- air mass
+  Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
+  tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1);
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    if (i >= 1 && i <= g.nx + 1) cx[p] += crx[p];
+    if (j >= 1 && j <= g.ny + 1) cy[p] += cry[p];
+    if (i >= 1 && i <= g.nx + 1 && j >= 1 && j <= g.ny) mfx[p] += fx[p];
+    if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny + 1) mfy[p] += fy[p];
+  });
+
+  // ---- vertical velocity: del-n damping + heat, then transport with the mass fluxes
+  {
+    Deln dn_w{g.nord_w, tab.d6_w, g.damp_w, 0, (Real)0, false, (Real)1.0e-5, nord_max_w};
+    Real *fx2 = c->scratch[SC_DN_FX], *fy2 = c->scratch[SC_DN_FY];
+    del6_vt_flux(c, s, w, c->scratch[SC_DN_D2], fx2, fy2, dn_w, false, 0, nz1);
+    launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long b = t * g.st + k * g.sk;
+      const long p = IX(i, j);
+      Real hs = (Real)0, dwv = (Real)0;
+      if (g.damp_w[k] > (Real)1.0e-5) {
+        const Real dd8 = g.ke_bg[k] * fabs(dt);
+        dwv = (fx2[b + p] - fx2[b + IX(i + 1, j)] + fy2[b + p] - fy2[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+        hs = dd8 - dwv * (w[b + p] + (Real)0.5 * dwv);
+      }
+      dw[b + p] = dwv;
+      heat_s[b + p] = hs;
+    });
+  }
+  tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1);
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk;
+    const long p = IX(i, j);
+    w[b + p] = delp[b + p] * w[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+  });
+
+  // ---- condensate
+  {
+    Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
+    tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1);
+  }
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk;
+    const long p = IX(i, j);
+    q_con[b + p] = delp[b + p] * q_con[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+  });
+
+  // ---- potential temperature, then the delp update and the divisions
+  tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1);
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk;
+    const long p = IX(i, j);
+    const Real ra = g.rarea[t * g.st2 + p];
+    const Real ptn = pt[b + p] * delp[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * ra;
+    const Real dpn = delp[b + p] + (fx[b + p] - fx[b + IX(i + 1, j)] + fy[b + p] - fy[b + IX(i, j + 1)]) * ra;
+    delp[b + p] = dpn;
+    pt[b + p] = ptn / dpn;
+    Real wn = w[b + p] / dpn;
+    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + dw[b + p];
+    w[b + p] = wn;
+    q_con[b + p] = q_con[b + p] / dpn;
+  });
+
+  // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u) and cell-mean relative vorticity
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const long p = IX(i, j);
+    {
+      // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
+      const Real a = u[b + p] * g.dx[m2 + p], a1 = u[b + IX(i, j + 1)] * g.dx[m2 + IX(i, j + 1)];
+      const Real e = v[b + p] * g.dy[m2 + p], e1 = v[b + IX(i + 1, j)] * g.dy[m2 + IX(i + 1, j)];
+      wk[b + p] = g.rarea[m2 + p] * (a - a1 - e + e1);
+    }
+    if (i < 1 || i > g.nx + 1 || j < 1 || j > g.ny + 1) return;
+    const Real dt5 = (Real)0.5 * dt, dt4 = (Real)0.25 * dt;
+    const Real *utl = ut + b, *vtl = vt + b, *ucl = uc + b, *vcl = vc + b, *ul = u + b, *vl = v + b;
+    Real kev;
+    const bool cW = W && i == 1, cE = E && i == npx, cS = S && j == 1, cN = N && j == npy;
+    if ((cW || cE) && (cS || cN)) {
+      const Real dt6 = dt / (Real)6.0;
+      if (cW && cS)
+        kev = dt6 * ((utl[IX(1, 1)] + utl[IX(1, 0)]) * ul[IX(1, 1)] + (vtl[IX(1, 1)] + vtl[IX(0, 1)]) * vl[IX(1, 1)] +
+                     (utl[IX(1, 1)] + vtl[IX(1, 1)]) * ul[IX(0, 1)]);
+      else if (cE && cS)
+        kev = dt6 * ((utl[IX(i, 1)] + utl[IX(i, 0)]) * ul[IX(i - 1, 1)] + (vtl[IX(i, 1)] + vtl[IX(i - 1, 1)]) * vl[IX(i, 1)] +
+                     (utl[IX(i, 1)] - vtl[IX(i - 1, 1)]) * ul[IX(i, 1)]);
+      else if (cE && cN)
+        kev = dt6 * ((utl[IX(i, j)] + utl[IX(i, j - 1)]) * ul[IX(i - 1, j)] + (vtl[IX(i, j)] + vtl[IX(i - 1, j)]) * vl[IX(i, j - 1)] +
+                     (utl[IX(i, j - 1)] + vtl[IX(i - 1, j)]) * ul[IX(i, j)]);
+      else
+        kev = dt6 * ((utl[IX(1, j)] + utl[IX(1, j - 1)]) * ul[IX(1, j)] + (vtl[IX(1, j)] + vtl[IX(0, j)]) * vl[IX(1, j - 1)] +
+                     (utl[IX(1, j - 1)] - vtl[IX(1, j)]) * ul[IX(0, j)]);
+    } else {
+      Real vbv, ubv;
+      if (cS || cN)
+        vbv = dt5 * (vtl[IX(i - 1, j)] + vtl[p]);
+      else if (cW || cE)
+        vbv = dt4 * (-vtl[IX(i - 2, j)] + (Real)3.0 * (vtl[IX(i - 1, j)] + vtl[p]) - vtl[IX(i + 1, j)]);
+      else
+        vbv = dt5 * (vcl[IX(i - 1, j)] + vcl[p] - (ucl[IX(i, j - 1)] + ucl[p]) * g.cosa[m2 + p]) * g.rsina[m2 + p];
+      if (cW || cE)
+        ubv = dt5 * (utl[IX(i, j - 1)] + utl[p]);
+      else if (cS || cN)
+        ubv = dt4 * (-utl[IX(i, j - 2)] + (Real)3.0 * (utl[IX(i, j - 1)] + utl[p]) - utl[IX(i, j + 1)]);
+      else
+        ubv = dt5 * (ucl[IX(i, j - 1)] + ucl[p] - (vcl[IX(i - 1, j)] + vcl[p]) * g.cosa[m2 + p]) * g.rsina[m2 + p];
+      // ytp_v: advect v along y with vb ; xtp_u: advect u along x with ub
+      Real vflux, uflux;
+      {
+        auto Q = [&](int s_) { return vl[IX(i, s_)]; };
+        auto M = [&](int s_) { return g.dy[m2 + IX(i, s_)]; };
+        const bool zc = (W && i == 1) || (E && i == npx);  // tile corner columns of v
+        const bool zm = zc && ((S && (j - 1 == 0 || j - 1 == 1)) || (N && (j - 1 == npy - 1 || j - 1 == npy)));
+        const bool z0 = zc && ((S && (j == 0 || j == 1)) || (N && (j == npy - 1 || j == npy)));
+        vflux = ppm_flux(Q, M, vbv, j, S, N, npy, cf.hord_mt, zm, z0, g.rdy[m2 + IX(i, j - 1)], g.rdy[m2 + p]);
+      }
+      {
+        auto Q = [&](int s_) { return ul[IX(s_, j)]; };
+        auto M = [&](int s_) { return g.dx[m2 + IX(s_, j)]; };
+        const bool zr = (S && j == 1) || (N && j == npy);
+        const bool zm = zr && ((W && (i - 1 == 0 || i - 1 == 1)) || (E && (i - 1 == npx - 1 || i - 1 == npx)));
+        const bool z0 = zr && ((W && (i == 0 || i == 1)) || (E && (i == npx - 1 || i == npx)));
+        uflux = ppm_flux(Q, M, ubv, i, W, E, npx, cf.hord_mt, zm, z0, g.rdx[m2 + IX(i - 1, j)], g.rdx[m2 + p]);
+      }
+      kev = (Real)0.5 * (vbv * vflux + ubv * uflux);
+    }
+    ke[b + p] = kev;
+  });
+
+  // ---- divergence damping.  delpc: un-iterated divergence; divgd iterated in place; uc / vc are
+  //      the work arrays of the iteration exactly as in the reference (their C-grid values are dead).
+  Real *vdamp = c->scratch[SC_DN_D2];  // damping field "vort" on corners (free: del-n chains are done)
+  // nord == 0 levels: divergence of the D-grid wind on the fly; nord > 0 levels: delpc = divgd
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const long p = IX(i, j);
+    if (g.nord[k] != 0) {
+      delpc[b + p] = divgd[b + p];
+      return;
+    }
+    auto PTC = [&](int ii, int jj) -> Real {
+      const long q = IX(ii, jj), qm = IX(ii, jj - 1);
+      if ((S && jj == 1) || (N && jj == npy))
+        return vc[b + q] * dt > (Real)0 ? u[b + q] * g.dyc[m2 + q] * g.sin_sg4[m2 + qm] : u[b + q] * g.dyc[m2 + q] * g.sin_sg2[m2 + q];
+      return (u[b + q] - (Real)0.5 * (va[b + qm] + va[b + q]) * g.cosa_v[m2 + q]) * g.dyc[m2 + q] * g.sina_v[m2 + q];
+    };
+    auto VRT = [&](int ii, int jj) -> Real {
+      const long q = IX(ii, jj), qm = IX(ii - 1, jj);
+      if ((W && ii == 1) || (E && ii == npx))
+        return uc[b + q] * dt > (Real)0 ? v[b + q] * g.dxc[m2 + q] * g.sin_sg3[m2 + qm] : v[b + q] * g.dxc[m2 + q] * g.sin_sg1[m2 + q];
+      return (v[b + q] - (Real)0.5 * (ua[b + qm] + ua[b + q]) * g.cosa_u[m2 + q]) * g.dxc[m2 + q] * g.sina_u[m2 + q];
+    };
+    Real d = VRT(i, j - 1) - VRT(i, j) + PTC(i - 1, j) - PTC(i, j);
+    if (W && S && i == 1 && j == 1) d -= VRT(1, 0);
+    if (E && S && i == npx && j == 1) d -= VRT(npx, 0);
+    if (E && N && i == npx && j == npy) d += VRT(npx, npy);
+    if (W && N && i == 1 && j == npy) d += VRT(1, npy);
+    d = g.rarea_c[m2 + p] * d;
+    delpc[b + p] = d;
+    const Real damp = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * fabs(d * dt)));
+    const Real vd = damp * d;
+    vdamp[b + p] = vd;
+    ke[b + p] += vd;
+  });
+  for (int n = 1; n <= nord_max; ++n) {
+    const int ntm = nord_max - n;
+    // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
+    launch3(c, s, Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const int nord = g.nord[k];
+      if (n > nord) return;
+      const int nt = nord - n;
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const Real *dg = divgd + b;
+      const bool fill = nt != 0;
+      if (i >= 1 - 1 - nt && i <= g.nx + 1 + nt && j >= 1 - nt && j <= g.ny + 1 + nt) {
+        const Real a = fill ? dg[bc_index<1>(g, fl, i + 1, j)] : dg[IX(i + 1, j)];
+        const Real e = fill ? dg[bc_index<1>(g, fl, i, j)] : dg[IX(i, j)];
+        vc[b + IX(i, j)] = (a - e) * g.divg_u[m2 + IX(i, j)];
+      }
+      if (i >= 1 - nt && i <= g.nx + 1 + nt && j >= 1 - 1 - nt && j <= g.ny + 1 + nt) {
+        const Real a = fill ? dg[bc_index<2>(g, fl, i, j + 1)] : dg[IX(i, j + 1)];
+        const Real e = fill ? dg[bc_index<2>(g, fl, i, j)] : dg[IX(i, j)];
+        uc[b + IX(i, j)] = (a - e) * g.divg_v[m2 + IX(i, j)];
+      }
+    });
+    launch3(c, s, Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const int nord = g.nord[k];
+      if (n > nord) return;
+      const int nt = nord - n;
+      if (i < 1 - nt || i > g.nx + 1 + nt || j < 1 - nt || j > g.ny + 1 + nt) return;
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+      const int npx = g.npx, npy = g.npy;
+      const bool fill = nt != 0;
+      const Real *x = vc + b, *y = uc + b;
+      auto UCR = [&](int ii, int jj) { return fill ? dg_y(x, y, g, fl, ii, jj, (Real)-1) : y[IX(ii, jj)]; };
+      auto VCR = [&](int ii, int jj) { return fill ? dg_x(x, y, g, fl, ii, jj, (Real)-1) : x[IX(ii, jj)]; };
+      Real d = UCR(i, j - 1) - UCR(i, j) + VCR(i - 1, j) - VCR(i, j);
+      if (W && S && i == 1 && j == 1) d -= UCR(1, 0);
+      if (E && S && i == npx && j == 1) d -= UCR(npx, 0);
+      if (E && N && i == npx && j == npy) d += UCR(npx, npy);
+      if (W && N && i == 1 && j == npy) d += UCR(1, npy);
+      divgd[b + IX(i, j)] = d * g.rarea_c[m2 + IX(i, j)];
+    });
+  }
+  // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
+  Real *wkb = c->scratch[SC_DN_FX];
+  a2b_ord4(c, s, wk, wkb, 0, 0, g.nz, false);
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int nord = g.nord[k];
+    if (nord == 0) return;
+    const long b = t * g.st + k * g.sk;
+    const long p = IX(i, j);
+    const Real dpc = delpc[b + p];
+    Real vo = (Real)0;
+    if ((Real)cf.dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkb[b + p] * wkb[b + p]);
+    const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * vo));
+    const Real vd = damp2 * dpc + tab.dd8[k] * divgd[b + p];
+    vdamp[b + p] = vd;
+    ke[b + p] += vd;
+  });
+
+  // ---- vorticity transport: absolute vorticity, fluxes, wind update
+  Real *vabs = c->scratch[SC_DN_FY];
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = IX(i, j);
+    vabs[t * g.st + k * g.sk + p] = wk[t * g.st + k * g.sk + p] + g.f0[t * g.st2 + p];
+  });
+  tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1);
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long p = IX(i, j);
+    if (i <= g.nx) u[b + p] = u[b + p] * g.dx[m2 + p] + ke[b + p] - ke[b + IX(i + 1, j)] + fy[b + p];
+    if (j <= g.ny) v[b + p] = v[b + p] * g.dy[m2 + p] + ke[b + p] - ke[b + IX(i, j + 1)] - fx[b + p];
+  });
+
+  // ---- del-n damping of the relative vorticity, heat from the damped kinetic energy
+  Real *utd = c->scratch[SC_TP_FX2], *vtd = c->scratch[SC_TP_FY2];  // free: no transport call follows
+  {
+    Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
+    del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, nz1);
+  }
+  const bool heat_on = cf.d_con > 1.0e-5;
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long p = IX(i, j);
+    Real hs = heat_s[b + p];
+    const Real dcon = g.d_con[k];
+    if (dcon > (Real)1.0e-5) {
+      const bool dv = g.damp_vt[k] > (Real)1.0e-5;
+      // ub on (i, j), (i, j+1): (vort - vort[i+1] + vt) * rdx ; vb on (i, j), (i+1, j): (vort - vort[j+1] - ut) * rdy
+      auto UB = [&](int ii, int jj) {
+        const long q = IX(ii, jj);
+        const Real d0 = vdamp[b + q] - vdamp[b + IX(ii + 1, jj)];
+        return (d0 + (dv ? vtd[b + q] : u[b + q] * (Real)0)) * g.rdx[m2 + q];
+      };
+      auto VB = [&](int ii, int jj) {
+        const long q = IX(ii, jj);
+        const Real d0 = vdamp[b + q] - vdamp[b + IX(ii, jj + 1)];
+        return (d0 - (dv ? utd[b + q] : v[b + q] * (Real)0)) * g.rdy[m2 + q];
+      };
+      const Real ub0 = UB(i, j), ub1 = UB(i, j + 1), vb0 = VB(i, j), vb1 = VB(i + 1, j);
+      const Real fy0 = u[b + p] * g.rdx[m2 + p], fy1 = u[b + IX(i, j + 1)] * g.rdx[m2 + IX(i, j + 1)];
+      const Real fx0 = v[b + p] * g.rdy[m2 + p], fx1 = v[b + IX(i + 1, j)] * g.rdy[m2 + IX(i + 1, j)];
+      const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
+      const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
+      hs = delp[b + p] * (hs - (Real)0.25 * dcon * g.rsin2[m2 + p] *
+                                   ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) -
+                                    g.cosa_s[m2 + p] * (u2 * dv2 + v2 * du2 + du2 * dv2)));
+    }
+    if (heat_on) heat_source[b + p] += hs;
+  });
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    if (!(g.damp_vt[k] > (Real)1.0e-5)) return;
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    if (i <= g.nx) u[p] += vtd[p];
+    if (j <= g.ny) v[p] -= utd[p];
+  });
+  return fv3_post(c, s, "d_sw");
+}

@@ -1,0 +1,596 @@
+// fv3_nh.hip -- non-hydrostatic column / pressure-gradient operators: update_dz_c, update_dz_d,
+// Riem_Solver_c, Riem_Solver3 (SIM1), p_grad_c, nh_p_grad, pk3_halo, edge_pe, Ray_fast,
+// del2_cubed, apply_diffusive_heating.  CPU twin: oracle/fv3_oracle/nh.py.  [SURVEY A.5-A.12]
+//
+// Column kernels: one thread per (i, j) column walks k; because i is the fastest index every
+// per-level access of a wavefront is one coalesced row.  Per-level temporaries that do not fit
+// registers (tridiagonal gam / pp / w) live in context scratch fields with the same layout.
+#include "fv3_ops.h"
+
+#define K_(arr, k) (arr)[p + (long)(k)*g.sk]
+
+namespace {
+
+// SIM1_solver (MOIST_CAPPA form).  On entry: DZ = layer thickness (negative), W2 = w, PM = layer
+// mean pressure; delp / cappa / pt are the column inputs.  PP (nz+1), GAM, W2 are scratch.
+// On exit: W2 = new w, DZ = new dz, PE (nz+1) = non-hydrostatic pressure perturbation.
+struct Sim1 {
+  Geo g;
+  Real rgas, rgrav, p_fac, ptop;
+  FV3_HD void run(long p, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *w1, Real ws, Real *PM, Real *DZ, Real *W2, Real *PP,
+                  Real *GAM, Real *PE) const {
+    const int nz = g.nz;
+    const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
+    auto DM = [&](int k) { return K_(delp, k) * rgrav; };
+    auto GM = [&](int k) { return (Real)1.0 / ((Real)1.0 - K_(cappa, k)); };
+    auto PE1 = [&](int k) { return exp(GM(k) * log(-DM(k) / K_(DZ, k) * rgas * K_(pt, k))) - K_(PM, k); };
+    // ---- pressure perturbation: tridiagonal solve for pp
+    {
+      Real pe_k = PE1(0);
+      Real bet = (Real)0;
+      K_(PP, 0) = (Real)0;
+      for (int k = 0; k < nz; ++k) {
+        Real bb, dd;
+        Real pe_n = (Real)0;
+        if (k < nz - 1) {
+          const Real g_rat = DM(k) / DM(k + 1);
+          pe_n = PE1(k + 1);
+          bb = (Real)2.0 * ((Real)1.0 + g_rat);
+          dd = (Real)3.0 * (pe_k + g_rat * pe_n);
+        } else {
+          bb = (Real)2.0;
+          dd = (Real)3.0 * pe_k;
+        }
+        if (k == 0) {
+          bet = bb;
+          K_(PP, 1) = dd / bet;
+        } else {
+          const Real g_prev = DM(k - 1) / DM(k);
+          const Real gam = g_prev / bet;
+          K_(GAM, k) = gam;
+          bet = bb - gam;
+          K_(PP, k + 1) = (dd - K_(PP, k)) / bet;
+        }
+        pe_k = pe_n;
+      }
+      for (int k = nz - 1; k >= 1; --k) K_(PP, k) = K_(PP, k) - K_(GAM, k) * K_(PP, k + 1);
+    }
+    // ---- w solve
+    {
+      // pem[k] rolling prefix sum (same operation order as the setup pass)
+      Real pem_k = ptop;  // pem[0]
+      auto AA = [&](int k, Real pem_at_k) {
+        return t1g * (Real)0.5 * (GM(k - 1) + GM(k)) / (K_(DZ, k - 1) + K_(DZ, k)) * (pem_at_k + K_(PP, k));
+      };
+      Real pem1 = pem_k + K_(delp, 0);  // pem[1]
+      Real aa_k1 = AA(1, pem1);         // aa[1]
+      Real bet = DM(0) - aa_k1;
+      K_(W2, 0) = (DM(0) * K_(w1, 0) + dt * K_(PP, 1)) / bet;
+      Real pem_cur = pem1;  // pem[k] for k = 1
+      Real aa_k = aa_k1;
+      for (int k = 1; k < nz - 1; ++k) {
+        const Real pem_next = pem_cur + K_(delp, k);  // pem[k+1]
+        const Real aa_n = AA(k + 1, pem_next);
+        const Real gam = aa_k / bet;
+        K_(GAM, k) = gam;
+        bet = DM(k) - (aa_k + aa_n + aa_k * gam);
+        K_(W2, k) = (DM(k) * K_(w1, k) + dt * (K_(PP, k + 1) - K_(PP, k)) - aa_k * K_(W2, k - 1)) / bet;
+        aa_k = aa_n;
+        pem_cur = pem_next;
+      }
+      // pem_cur = pem[nz-1]; bottom
+      const Real pem_nz = pem_cur + K_(delp, nz - 1);
+      const Real p1 = t1g * GM(nz - 1) / K_(DZ, nz - 1) * (pem_nz + K_(PP, nz));
+      const Real gam = aa_k / bet;
+      K_(GAM, nz - 1) = gam;
+      bet = DM(nz - 1) - (aa_k + p1 + aa_k * gam);
+      K_(W2, nz - 1) = (DM(nz - 1) * K_(w1, nz - 1) + dt * (K_(PP, nz) - K_(PP, nz - 1)) - p1 * ws - aa_k * K_(W2, nz - 2)) / bet;
+      for (int k = nz - 2; k >= 0; --k) K_(W2, k) = K_(W2, k) - K_(GAM, k + 1) * K_(W2, k + 1);
+    }
+    // ---- new pressure perturbation and layer thickness
+    K_(PE, 0) = (Real)0;
+    for (int k = 0; k < nz; ++k) K_(PE, k + 1) = K_(PE, k) + DM(k) * (K_(W2, k) - K_(w1, k)) * rdt;
+    Real p1 = (K_(PE, nz - 1) + (Real)2.0 * K_(PE, nz)) * r3;
+    K_(DZ, nz - 1) = -DM(nz - 1) * rgas * K_(pt, nz - 1) *
+                     exp((K_(cappa, nz - 1) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, nz - 1), p1 + K_(PM, nz - 1))));
+    for (int k = nz - 2; k >= 0; --k) {
+      const Real g_rat = DM(k) / DM(k + 1);
+      const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
+      p1 = (K_(PE, k) + bb * K_(PE, k + 1) + g_rat * K_(PE, k + 2)) * r3 - g_rat * p1;
+      K_(DZ, k) = -DM(k) * rgas * K_(pt, k) * exp((K_(cappa, k) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, k), p1 + K_(PM, k))));
+    }
+  }
+};
+
+// interface interpolation weights of update_dz_c
+struct DzcW {
+  Real top_ratio, bot_ratio;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_update_dz_c(fv3_ctx *c, const fv3_field *zs_, const fv3_field *ut_, const fv3_field *vt_, const fv3_field *gz_, const fv3_field *ws_,
+                               double dtd, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD2D(zs, zs_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_) FV3_FIELD(gz, gz_) FV3_FIELD2D(ws, ws_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt = (Real)dtd;
+  const int nz = g.nz;
+  const Real dz_min = (Real)c->cst.dz_min;
+  const std::vector<double> &dp = c->dp_ref_h;
+  const Real top_ratio = (Real)(dp[0] / (dp[0] + dp[1]));
+  const Real bot_ratio = (Real)(dp[nz - 1] / (dp[nz - 2] + dp[nz - 1]));
+  Real *gzn = c->scratch[SC_A];
+  launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long bt = t * g.st, b = bt + k * g.sk, m2 = t * g.st2;
+    auto XI = [&](const Real *f, int ii, int jj) -> Real {
+      const long q = bt + IX(ii, jj);
+      if (k == 0) return f[q] + (f[q] - f[q + g.sk]) * top_ratio;
+      if (k == nz) return f[q + (nz - 1) * g.sk] + (f[q + (nz - 1) * g.sk] - f[q + (nz - 2) * g.sk]) * bot_ratio;
+      const Real int_ratio = (Real)1.0 / (g.dp_ref[k - 1] + g.dp_ref[k]);
+      return (g.dp_ref[k] * f[q + (k - 1) * g.sk] + g.dp_ref[k - 1] * f[q + k * g.sk]) * int_ratio;
+    };
+    const Real *gg = gz + b;
+    const Real x0 = XI(ut, i, j), x1 = XI(ut, i + 1, j), y0 = XI(vt, i, j), y1 = XI(vt, i, j + 1);
+    const Real fx0 = x0 * (x0 > (Real)0 ? gg[f4_index<1>(g, fl, i - 1, j)] : gg[f4_index<1>(g, fl, i, j)]);
+    const Real fx1 = x1 * (x1 > (Real)0 ? gg[f4_index<1>(g, fl, i, j)] : gg[f4_index<1>(g, fl, i + 1, j)]);
+    const Real fy0 = y0 * (y0 > (Real)0 ? gg[f4_index<2>(g, fl, i, j - 1)] : gg[f4_index<2>(g, fl, i, j)]);
+    const Real fy1 = y1 * (y1 > (Real)0 ? gg[f4_index<2>(g, fl, i, j)] : gg[f4_index<2>(g, fl, i, j + 1)]);
+    const long p = IX(i, j);
+    const Real ar = g.area[m2 + p];
+    gzn[b + p] = (gg[p] * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+  });
+  launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    Real below = gzn[p + (long)nz * g.sk];
+    gz[p + (long)nz * g.sk] = below;
+    ws[t * g.st2 + IX(i, j)] = (zs[t * g.st2 + IX(i, j)] - below) / dt;
+    for (int k = nz - 1; k >= 0; --k) {
+      const Real v = fv3_max(K_(gzn, k), below + dz_min);
+      K_(gz, k) = v;
+      below = v;
+    }
+  });
+  return fv3_post(c, s, "update_dz_c");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa_, double ptopd, const fv3_field *phis_, const fv3_field *ws_,
+                                 const fv3_field *ptc_, const fv3_field *q_con_, const fv3_field *delpc_, const fv3_field *gz_, const fv3_field *pef_,
+                                 const fv3_field *w3_, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(cappa, cappa_) FV3_FIELD2D(phis, phis_) FV3_FIELD2D(ws, ws_) FV3_FIELD(ptc, ptc_) FV3_FIELD(q_con, q_con_) FV3_FIELD(delpc, delpc_)
+  FV3_FIELD(gz, gz_) FV3_FIELD(pef, pef_) FV3_FIELD(w3, w3_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt2 = (Real)dt2d, ptop = (Real)ptopd, grav = (Real)c->cst.grav;
+  Sim1 sim{g, (Real)c->cst.rdgas, (Real)1.0 / (Real)c->cst.grav, (Real)c->cfg.p_fac, ptop};
+  Real *PM = c->scratch[SC_A], *DZ = c->scratch[SC_B], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
+  const int nz = g.nz;
+  launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    // setup: layer-mean pressure without condensate, thickness
+    Real peg = ptop;
+    for (int k = 0; k < nz; ++k) {
+      const Real dm = K_(delpc, k);
+      const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
+      K_(PM, k) = (peg_n - peg) / log(peg_n / peg);
+      K_(DZ, k) = K_(gz, k + 1) - K_(gz, k);
+      peg = peg_n;
+    }
+    sim.run(p, dt2, delpc, cappa, ptc, w3, ws[t * g.st2 + IX(i, j)], PM, DZ, W2, PP, GAM, pef);
+    // full interface pressure and geopotential
+    Real pem = ptop;
+    K_(pef, 0) = ptop;
+    for (int k = 0; k < nz; ++k) {
+      pem = pem + K_(delpc, k);
+      K_(pef, k + 1) = K_(pef, k + 1) + pem;
+    }
+    Real z = phis[t * g.st2 + IX(i, j)];
+    K_(gz, nz) = z;
+    for (int k = nz - 1; k >= 0; --k) {
+      z = z - K_(DZ, k) * grav;
+      K_(gz, k) = z;
+    }
+  });
+  return fv3_post(c, s, "riem_solver_c");
+}
+
+extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3_field *cappa_, double ptopd, const fv3_field *zs_, const fv3_field *wsd_,
+                                const fv3_field *delz_, const fv3_field *q_con_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *zh_,
+                                const fv3_field *pe_, const fv3_field *ppe_, const fv3_field *pk3_, const fv3_field *pk_, const fv3_field *peln_,
+                                const fv3_field *w_, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(cappa, cappa_) FV3_FIELD2D(zs, zs_) FV3_FIELD2D(wsd, wsd_) FV3_FIELD(delz, delz_) FV3_FIELD(q_con, q_con_) FV3_FIELD(delp, delp_)
+  FV3_FIELD(pt, pt_) FV3_FIELD(zh, zh_) FV3_FIELD(pe, pe_) FV3_FIELD(ppe, ppe_) FV3_FIELD(pk3, pk3_) FV3_FIELD(pk, pk_) FV3_FIELD(peln, peln_)
+  FV3_FIELD(w, w_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt = (Real)dtd, ptop = (Real)ptopd;
+  const Real akap = (Real)(c->cst.rdgas / c->cst.cp_air);
+  Sim1 sim{g, (Real)c->cst.rdgas, (Real)1.0 / (Real)c->cst.grav, (Real)c->cfg.p_fac, ptop};
+  Real *PM = c->scratch[SC_A], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
+  const int nz = g.nz;
+  const bool last = last_call != 0;
+  launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    Real pem = ptop, peg = ptop;
+    Real peln_k = log(pem), pelng_k = log(peg);
+    K_(pk3, 0) = exp(akap * peln_k);
+    if (last) {
+      K_(peln, 0) = peln_k;
+      K_(pk, 0) = K_(pk3, 0);
+      K_(pe, 0) = pem;
+    }
+    for (int k = 0; k < nz; ++k) {
+      const Real dm = K_(delp, k);
+      pem = pem + dm;
+      const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
+      const Real peln_n = log(pem), pelng_n = log(peg_n);
+      const Real pk3v = exp(akap * peln_n);
+      K_(pk3, k + 1) = pk3v;
+      if (last) {
+        K_(peln, k + 1) = peln_n;
+        K_(pk, k + 1) = pk3v;
+        K_(pe, k + 1) = pem;
+      }
+      K_(PM, k) = (peg_n - peg) / (pelng_n - pelng_k);
+      K_(delz, k) = K_(zh, k + 1) - K_(zh, k);  // dz2 lives in the output array
+      peg = peg_n;
+      pelng_k = pelng_n;
+    }
+    (void)peln_k;
+    sim.run(p, dt, delp, cappa, pt, w, wsd[t * g.st2 + IX(i, j)], PM, delz, W2, PP, GAM, ppe);
+    Real z = zs[t * g.st2 + IX(i, j)];
+    K_(zh, nz) = z;
+    for (int k = nz - 1; k >= 0; --k) {
+      K_(w, k) = K_(W2, k);
+      z = z - K_(delz, k);
+      K_(zh, k) = z;
+    }
+  });
+  return fv3_post(c, s, "riem_solver3");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_p_grad_c(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *delpc_, const fv3_field *pkc_, const fv3_field *gz_,
+                            double dt2d, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_) FV3_FIELD(delpc, delpc_) FV3_FIELD(pkc, pkc_) FV3_FIELD(gz, gz_)
+  const Geo g = c->g;
+  const Real dt2 = (Real)dt2d;
+  launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
+    const long p = IX(i, j);
+    if (j <= g.ny) {
+      const long pm = IX(i - 1, j);
+      uc[b + p] = uc[b + p] + dt2 * g.rdxc[m2 + p] / (delpc[b + pm] + delpc[b + p]) *
+                                  ((gz[b1 + pm] - gz[b + p]) * (pkc[b1 + p] - pkc[b + pm]) + (gz[b + pm] - gz[b1 + p]) * (pkc[b1 + pm] - pkc[b + p]));
+    }
+    if (i <= g.nx) {
+      const long pm = IX(i, j - 1);
+      vc[b + p] = vc[b + p] + dt2 * g.rdyc[m2 + p] / (delpc[b + pm] + delpc[b + p]) *
+                                  ((gz[b1 + pm] - gz[b + p]) * (pkc[b1 + p] - pkc[b + pm]) + (gz[b + pm] - gz[b1 + p]) * (pkc[b1 + pm] - pkc[b + p]));
+    }
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "p_grad_c");
+}
+
+extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, const fv3_field *pp_, const fv3_field *gz_, const fv3_field *pk3_,
+                             const fv3_field *delp_, double dtd, double ptop, double akap, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(pp, pp_) FV3_FIELD(gz, gz_) FV3_FIELD(pk3, pk3_) FV3_FIELD(delp, delp_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt = (Real)dtd;
+  const Real top = (Real)std::pow(ptop, akap);
+  const int nz = g.nz;
+  launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    pp[p] = (Real)0;
+    pk3[p] = top;
+  });
+  a2b_ord4(c, s, pp, pp, 1, 1, nz, true);
+  a2b_ord4(c, s, pk3, pk3, 1, 1, nz, true);
+  a2b_ord4(c, s, gz, gz, 0, 0, nz + 1, true);
+  Real *wk1 = c->scratch[SC_A];
+  a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
+    const long p = IX(i, j);
+    auto WK = [&](long q) { return pk3[b1 + q] - pk3[b + q]; };
+    if (i <= g.nx) {
+      const long pe_ = IX(i + 1, j);
+      const Real du = dt / (WK(p) + WK(pe_)) *
+                      ((gz[b1 + p] - gz[b + pe_]) * (pk3[b1 + pe_] - pk3[b + p]) + (gz[b + p] - gz[b1 + pe_]) * (pk3[b1 + p] - pk3[b + pe_]));
+      u[b + p] = (u[b + p] + du +
+                  dt / (wk1[b + p] + wk1[b + pe_]) *
+                      ((gz[b1 + p] - gz[b + pe_]) * (pp[b1 + pe_] - pp[b + p]) + (gz[b + p] - gz[b1 + pe_]) * (pp[b1 + p] - pp[b + pe_]))) *
+                 g.rdx[m2 + p];
+    }
+    if (j <= g.ny) {
+      const long pn = IX(i, j + 1);
+      const Real dv = dt / (WK(p) + WK(pn)) *
+                      ((gz[b1 + p] - gz[b + pn]) * (pk3[b1 + pn] - pk3[b + p]) + (gz[b + p] - gz[b1 + pn]) * (pk3[b1 + p] - pk3[b + pn]));
+      v[b + p] = (v[b + p] + dv +
+                  dt / (wk1[b + p] + wk1[b + pn]) *
+                      ((gz[b1 + p] - gz[b + pn]) * (pp[b1 + pn] - pp[b + p]) + (gz[b + p] - gz[b1 + pn]) * (pp[b1 + p] - pp[b + pn]))) *
+                 g.rdy[m2 + p];
+    }
+  });
+  return fv3_post(c, s, "nh_p_grad");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_pk3_halo(fv3_ctx *c, const fv3_field *pk3_, const fv3_field *delp_, double ptopd, double akapd, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(pk3, pk3_) FV3_FIELD(delp, delp_)
+  const Geo g = c->g;
+  const Real ptop = (Real)ptopd, akap = (Real)akapd;
+  launch2(c, (fv3_stream_t)stream, Box{-1, g.nx + 2, -1, g.ny + 2, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny) return;
+    const long p = t * g.st + IX(i, j);
+    Real pei = ptop;
+    for (int k = 0; k < g.nz; ++k) {
+      pei = pei + K_(delp, k);
+      K_(pk3, k + 1) = exp(akap * log(pei));
+    }
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "pk3_halo");
+}
+
+extern "C" int fv3_edge_pe(fv3_ctx *c, const fv3_field *pe_, const fv3_field *delp_, double ptopd, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(pe, pe_) FV3_FIELD(delp, delp_)
+  const Geo g = c->g;
+  const Real ptop = (Real)ptopd;
+  launch2(c, (fv3_stream_t)stream, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny) return;
+    const long p = t * g.st + IX(i, j);
+    Real pei = ptop;
+    K_(pe, 0) = pei;
+    for (int k = 0; k < g.nz; ++k) {
+      pei = pei + K_(delp, k);
+      K_(pe, k + 1) = pei;
+    }
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "edge_pe");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field *zh_, const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_,
+                               const fv3_field *yfx_, const fv3_field *wsd_, double dtd, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD2D(zs, zs_) FV3_FIELD(zh, zh_) FV3_FIELD(crx, crx_) FV3_FIELD(cry, cry_) FV3_FIELD(xfx, xfx_) FV3_FIELD(yfx, yfx_) FV3_FIELD2D(wsd, wsd_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real dt = (Real)dtd;
+  const int nz = g.nz;
+  const Real dz_min = (Real)c->cst.dz_min;
+  Real *crx_a = c->scratch[SC_A], *xfx_a = c->scratch[SC_B], *cry_a = c->scratch[SC_C], *yfx_a = c->scratch[SC_D];
+  Real *fx = c->scratch[SC_E], *fy = c->scratch[SC_F], *fx2 = c->scratch[SC_G], *fy2 = c->scratch[SC_H], *d2 = c->scratch[SC_I];
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  // cubic-spline-like layer -> interface interpolation (FV3 edge_profile, limiter 0)
+  launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    auto profile = [&](const Real *q, Real *qe) {
+      const Real *dp0 = g.dp_ref;
+      const Real g0 = dp0[1] / dp0[0];
+      Real xt1 = (Real)2.0 * g0 * (g0 + (Real)1.0);
+      Real bet = g0 * (g0 + (Real)0.5);
+      K_(qe, 0) = (xt1 * K_(q, 0) + K_(q, 1)) / bet;
+      Real gam_prev = ((Real)1.0 + g0 * (g0 + (Real)1.5)) / bet;
+      Real gk = g0;
+      // gam[k] is level-only: recomputed in the backward sweep from the same recurrence
+      for (int k = 1; k < nz; ++k) {
+        gk = dp0[k - 1] / dp0[k];
+        bet = (Real)2.0 + (Real)2.0 * gk - gam_prev;
+        K_(qe, k) = ((Real)3.0 * (K_(q, k - 1) + gk * K_(q, k)) - K_(qe, k - 1)) / bet;
+        gam_prev = gk / bet;
+      }
+      const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
+      xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
+      const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
+      K_(qe, nz) = (xt1 * K_(q, nz - 1) + K_(q, nz - 2) - a_bot * K_(qe, nz - 1)) / xt2;
+    };
+    const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
+    if (inx) {
+      profile(crx, crx_a);
+      profile(xfx, xfx_a);
+    }
+    if (iny) {
+      profile(cry, cry_a);
+      profile(yfx, yfx_a);
+    }
+  });
+  // backward sweep: gam[k] depends on dp_ref only (table built at context creation)
+  {
+    const Real *gamd = g.ep_gam;
+    launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+      const long p = t * g.st + IX(i, j);
+      const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
+      for (int k = nz - 1; k >= 0; --k) {
+        const Real gm = gamd[k];
+        if (inx) {
+          K_(crx_a, k) = K_(crx_a, k) - gm * K_(crx_a, k + 1);
+          K_(xfx_a, k) = K_(xfx_a, k) - gm * K_(xfx_a, k + 1);
+        }
+        if (iny) {
+          K_(cry_a, k) = K_(cry_a, k) - gm * K_(cry_a, k + 1);
+          K_(yfx_a, k) = K_(yfx_a, k) - gm * K_(yfx_a, k + 1);
+        }
+      }
+    });
+  }
+  // transport of every interface height + del-n damping
+  tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, fx, fy, nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz);
+  int nord_max = 0;
+  for (int k = 0; k <= nz; ++k) nord_max = std::max(nord_max, c->nord_v_h[k]);
+  Deln dn{g.nord_v, g.damp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
+  del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
+    const Real ar = g.area[m2 + p];
+    const Real ra_x = ar + xfx_a[b + p] - xfx_a[b + pe_];
+    const Real ra_y = ar + yfx_a[b + p] - yfx_a[b + pn];
+    Real z = (zh[b + p] * ar + fx[b + p] - fx[b + pe_] + fy[b + p] - fy[b + pn]) / (ra_x + ra_y - ar);
+    if (g.damp_vt[k] > (Real)1.0e-5) z = z + (fx2[b + p] - fx2[b + pe_] + fy2[b + p] - fy2[b + pn]) * g.rarea[m2 + p];
+    zh[b + p] = z;
+  });
+  launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    Real below = K_(zh, nz);
+    wsd[t * g.st2 + IX(i, j)] = (zs[t * g.st2 + IX(i, j)] - below) / dt;
+    for (int k = nz - 1; k >= 0; --k) {
+      const Real v = fv3_max(K_(zh, k), below + dz_min);
+      K_(zh, k) = v;
+      below = v;
+    }
+  });
+  return fv3_post(c, s, "update_dz_d");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, const fv3_field *w_, double dt, double ptop, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(w, w_)
+  const Geo g = c->g;
+  const int nz = g.nz;
+  const double rf_cutoff = c->cfg.rf_cutoff;
+  const double nudge = rf_cutoff + std::fmin(100.0, 10.0 * ptop);
+  const double tau0 = c->cfg.tau * c->cst.seconds_per_day;
+  // rf table for this (dt, ptop): host libm, cached in the context
+  if (!c->tab_rf || c->rf_dt != dt || c->rf_ptop != ptop) {
+    std::vector<Real> rf(nz, (Real)1);
+    int nd = 0, nn = 0;
+    double dm = 0.0;
+    for (int k = 0; k < nz; ++k) {
+      const double pf = c->pfull_h[k];
+      if (pf < rf_cutoff) {
+        const double sn = std::sin(0.5 * c->cst.pi * std::log(rf_cutoff / pf) / std::log(rf_cutoff / ptop));
+        rf[k] = (Real)(1.0 / (1.0 + dt / tau0 * (sn * sn)));
+        nd = k + 1;
+      }
+      if (pf < nudge) {
+        dm += c->dp_ref_h[k];
+        nn = k + 1;
+      }
+    }
+    if (!c->tab_rf) {
+      c->tab_rf = fv3_dev_alloc(c, nz * sizeof(Real));
+      if (!c->tab_rf) return fv3_fail(c, FV3_ERR_NOMEM, "rf table");
+    }
+    fv3_h2d(c->tab_rf, rf.data(), nz * sizeof(Real));
+    c->rf_dt = dt;
+    c->rf_ptop = ptop;
+    c->rf_nd = nd;
+    c->rf_nn = nn;
+    c->rf_dm = dm;
+  }
+  const int nd = c->rf_nd, nn = c->rf_nn;
+  if (nn == 0) return FV3_OK;
+  const Real dm = (Real)c->rf_dm;
+  const Real *rf = (const Real *)c->tab_rf;
+  launch2(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long p = t * g.st + IX(i, j);
+    auto wind = [&](Real *a) {
+      Real dmdir = (Real)0;
+      for (int k = 0; k < nd; ++k) {
+        dmdir = dmdir + ((Real)1.0 - rf[k]) * g.dp_ref[k] * K_(a, k);
+        K_(a, k) = K_(a, k) * rf[k];
+      }
+      const Real add = dmdir / dm;
+      for (int k = 0; k < nn; ++k) K_(a, k) = K_(a, k) + add;
+    };
+    if (i <= g.nx) wind(u);
+    if (j <= g.ny) wind(v);
+    if (i <= g.nx && j <= g.ny)
+      for (int k = 0; k < nd; ++k) K_(w, k) = K_(w, k) * rf[k];
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "ray_fast");
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int nmax, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(q, q_)
+  const Geo g = c->g;
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const Real cd = (Real)cdd;
+  const int ntimes = nmax < 3 ? nmax : 3;
+  const int nz1 = g.nz - 1;
+  Real *fx = c->scratch[SC_A], *fy = c->scratch[SC_B];
+  for (int n = 1; n <= ntimes; ++n) {
+    const int nt = ntimes - n;
+    launch3(c, s, Box{1, 1, 1, 1, 0, nz1}, [=] FV3_HD(int t, int k, int, int) {
+      const int fl = g.flags[t];
+      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+      Real *qq = q + t * g.st + k * g.sk;
+      const int npx = g.npx, npy = g.npy, ie = g.nx, je = g.ny;
+      const Real r3 = (Real)(1.0 / 3.0);
+      if (W && S) {
+        const Real a = (qq[IX(1, 1)] + qq[IX(0, 1)] + qq[IX(1, 0)]) * r3;
+        qq[IX(1, 1)] = a; qq[IX(0, 1)] = a; qq[IX(1, 0)] = a;
+      }
+      if (E && S) {
+        const Real a = (qq[IX(ie, 1)] + qq[IX(npx, 1)] + qq[IX(ie, 0)]) * r3;
+        qq[IX(ie, 1)] = a; qq[IX(npx, 1)] = a; qq[IX(ie, 0)] = a;
+      }
+      if (E && N) {
+        const Real a = (qq[IX(ie, je)] + qq[IX(npx, je)] + qq[IX(ie, npy)]) * r3;
+        qq[IX(ie, je)] = a; qq[IX(npx, je)] = a; qq[IX(ie, npy)] = a;
+      }
+      if (W && N) {
+        const Real a = (qq[IX(1, je)] + qq[IX(0, je)] + qq[IX(1, npy)]) * r3;
+        qq[IX(1, je)] = a; qq[IX(0, je)] = a; qq[IX(1, npy)] = a;
+      }
+    });
+    launch3(c, s, Box{1 - nt, g.nx + 1 + nt, 1 - nt, g.ny + 1 + nt, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const Real *qq = q + b;
+      const long p = IX(i, j);
+      if (j <= g.ny + nt) {
+        const Real a = nt > 0 ? cc<1>(qq, g, fl, i - 1, j) : qq[IX(i - 1, j)];
+        const Real e = nt > 0 ? cc<1>(qq, g, fl, i, j) : qq[p];
+        fx[b + p] = g.del6_v[m2 + p] * (a - e);
+      }
+      if (i <= g.nx + nt) {
+        const Real a = nt > 0 ? cc<2>(qq, g, fl, i, j - 1) : qq[IX(i, j - 1)];
+        const Real e = nt > 0 ? cc<2>(qq, g, fl, i, j) : qq[p];
+        fy[b + p] = g.del6_u[m2 + p] * (a - e);
+      }
+    });
+    launch3(c, s, Box{1 - nt, g.nx + nt, 1 - nt, g.ny + nt, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long b = t * g.st + k * g.sk;
+      const long p = IX(i, j);
+      q[b + p] = q[b + p] + cd * g.rarea[t * g.st2 + p] * (fx[b + p] - fx[b + IX(i + 1, j)] + fy[b + p] - fy[b + IX(i, j + 1)]);
+    });
+  }
+  return fv3_post(c, s, "del2_cubed");
+}
+
+extern "C" int fv3_apply_diffusive_heating(fv3_ctx *c, const fv3_field *delp_, const fv3_field *delz_, const fv3_field *cappa_, const fv3_field *hs_,
+                                           const fv3_field *pt_, double delt, void *stream) {
+  if (!c) return FV3_ERR_ARG;
+  FV3_FIELD(delp, delp_) FV3_FIELD(delz, delz_) FV3_FIELD(cappa, cappa_) FV3_FIELD(hs, hs_) FV3_FIELD(pt, pt_)
+  const Geo g = c->g;
+  const Real rdg = (Real)(-c->cst.rdgas / c->cst.grav), cv_air = (Real)(c->cst.cp_air - c->cst.rdgas), lim0 = (Real)delt;
+  launch3(c, (fv3_stream_t)stream, Box{1, g.nx, 1, g.ny, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    const Real cp = cappa[p];
+    const Real pkz = exp(cp / ((Real)1.0 - cp) * log(rdg * delp[p] / delz[p] * pt[p]));
+    const Real dtmp = hs[p] / (cv_air * delp[p]);
+    Real lim = lim0;
+    if (k == 0) lim = lim * (Real)0.1;
+    if (k == 1) lim = lim * (Real)0.5;
+    const Real mag = fv3_min(lim, fabs(dtmp));
+    const Real sg = dtmp > (Real)0 ? (Real)1 : (dtmp < (Real)0 ? (Real)-1 : (Real)0);
+    pt[p] = pt[p] + sg * mag / pkz;
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "apply_diffusive_heating");
+}

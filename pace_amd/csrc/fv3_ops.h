@@ -1,0 +1,52 @@
+// fv3_ops.h -- internal operator building blocks shared between translation units.
+#pragma once
+#include "fv3_common.h"
+
+// scratch slot map (indices into ctx->scratch); operators on one stream never overlap in time.
+enum {
+  SC_TP_FY2 = 0,  // fv_tp_2d inner y flux
+  SC_TP_FX2 = 1,  // fv_tp_2d inner x flux
+  SC_TP_QI = 2,
+  SC_TP_QJ = 3,
+  SC_DN_D2 = 4,   // del-n work array
+  SC_DN_FX = 5,   // del-n x flux
+  SC_DN_FY = 6,   // del-n y flux
+  SC_A = 7,       // operator-level temporaries (d_sw, c_sw, nh, a2b ...)
+  SC_B = 8,
+  SC_C = 9,
+  SC_D = 10,
+  SC_E = 11,
+  SC_F = 12,
+  SC_G = 13,
+  SC_H = 14,
+  SC_I = 15,
+  SC_J = 16,
+  SC_K = 17
+};
+
+// Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]
+// (or damp_u) and is active when on_k[k] > on_thr (or on_u).
+struct Deln {
+  const int *nord_k;
+  const Real *damp_k;
+  const Real *on_k;
+  int nord_u;
+  Real damp_u;
+  bool on_u;
+  Real on_thr;
+  int nord_max;  // host side: max order over the levels of the call
+};
+FV3_HD inline int deln_nord(const Deln &d, int k) { return d.nord_k ? d.nord_k[k] : d.nord_u; }
+FV3_HD inline Real deln_damp(const Deln &d, int k) { return d.damp_k ? d.damp_k[k] : d.damp_u; }
+FV3_HD inline bool deln_on(const Deln &d, int k) { return d.on_k ? d.on_k[k] > d.on_thr : d.on_u; }
+
+// fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).
+void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
+          const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1);
+
+// del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
+void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
+
+// a2b_ord4: qout levels kout0.. from qin levels kin0.. (nk levels); replace writes back into qin
+void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace);
+

@@ -1,0 +1,257 @@
+"""``AcousticDynamics`` -- the n_split acoustic loop of the FV3 dynamical core on MI355X.
+
+Drop-in for ``pyFV3.stencils.dyn_core.AcousticDynamics`` as reached from
+``Driver._critical_path_step_all -> DynamicalCore.step_dynamics`` [REF driver/pace/driver/driver.py:641];
+sequencing per SURVEY §3.3 (checkpoint names C_SW-In/Out, D_SW-In/Out
+[REF tests/savepoint/thresholds/fv_dynamics.yaml:2,39,76,125]).  The constructor takes the
+reference's objects (comm, grid_data, stencil_factory, quantity_factory, damping_coefficients,
+..., config, phis, state) where ``stencil_factory`` is this build's :class:`StencilFactory`.
+
+MI355X-first: all sub-domains of the process are one batched set of launches; halo updates of
+co-resident sub-domains are device gathers on the compute stream, cross-process ones are packed
+RCCL point-to-point messages (``pace_amd.halo``).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import stencils as st
+from .config import AcousticDynamicsConfig
+from .constants import X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM, Z_DIM, Z_INTERFACE_DIM
+from .context import StencilFactory
+from .halo import HaloExchanger, Layout
+from .quantity import Quantity
+
+_DIMS = {
+    "u": (X_DIM, Y_INTERFACE_DIM, Z_DIM),
+    "v": (X_INTERFACE_DIM, Y_DIM, Z_DIM),
+    "uc": (X_INTERFACE_DIM, Y_DIM, Z_DIM),
+    "vc": (X_DIM, Y_INTERFACE_DIM, Z_DIM),
+    "mfxd": (X_INTERFACE_DIM, Y_DIM, Z_DIM),
+    "mfyd": (X_DIM, Y_INTERFACE_DIM, Z_DIM),
+    "cxd": (X_INTERFACE_DIM, Y_DIM, Z_DIM),
+    "cyd": (X_DIM, Y_INTERFACE_DIM, Z_DIM),
+    "pe": (X_DIM, Y_DIM, Z_INTERFACE_DIM),
+    "pk": (X_DIM, Y_DIM, Z_INTERFACE_DIM),
+    "peln": (X_DIM, Y_DIM, Z_INTERFACE_DIM),
+}
+STATE_NAMES = "u v w ua va uc vc delp delz pt pe pk peln pkz q_con omga cappa mfxd mfyd cxd cyd diss_estd".split()
+
+
+class DycoreState:
+    """The fields of ``pyFV3.DycoreState`` the acoustic path touches
+    [REF tests/main/fv3core/test_init_from_geos.py:128-199; driver/pace/driver/state.py:131-139]."""
+
+    def __init__(self, quantity_factory):
+        self.quantity_factory = quantity_factory
+        for n in STATE_NAMES:
+            setattr(self, n, quantity_factory.zeros(_DIMS.get(n, (X_DIM, Y_DIM, Z_DIM))))
+        self.phis = quantity_factory.zeros((X_DIM, Y_DIM), "m^2 s^-2")
+
+    @classmethod
+    def init_zeros(cls, quantity_factory):
+        return cls(quantity_factory)
+
+    @classmethod
+    def from_arrays(cls, quantity_factory, per_rank: List[Dict[str, np.ndarray]]):
+        """``per_rank[r][name]`` are (i, j, k) host arrays (e.g. from ``pace_amd.init.synthetic_state``)."""
+        s = cls(quantity_factory)
+        for n in STATE_NAMES + ["phis"]:
+            q = getattr(s, n)
+            for r, d in enumerate(per_rank):
+                q.set_numpy(d[n], r)
+        return s
+
+    def to_arrays(self, names=None) -> List[Dict[str, np.ndarray]]:
+        names = names or (STATE_NAMES + ["phis"])
+        n_sub = self.u.n_sub
+        return [{n: getattr(self, n).numpy(r) for n in names} for r in range(n_sub)]
+
+
+class AcousticDynamics:
+    def __init__(
+        self,
+        comm,
+        grid_data,
+        stencil_factory: StencilFactory,
+        quantity_factory=None,
+        damping_coefficients=None,
+        grid_type: int = 0,
+        nested: bool = False,
+        stretched_grid: bool = False,
+        config: Optional[AcousticDynamicsConfig] = None,
+        phis: Optional[Quantity] = None,
+        wsd: Optional[Quantity] = None,
+        state: Optional[DycoreState] = None,
+        checkpointer=None,
+    ):
+        """``comm``: a :class:`pace_amd.halo.Layout` (which ranks live here) or None for "all ranks local"."""
+        self.sf = stencil_factory
+        self.qf = quantity_factory or stencil_factory.quantity_factory
+        self.config = (config or stencil_factory.config).validate()
+        self.checkpointer = checkpointer
+        self.grid_data = grid_data
+        c = stencil_factory.constants
+        self.c = c
+        g0 = stencil_factory.grids[0]
+        self._ptop = g0.ptop
+        self._akap = c.KAPPA
+        self._da_min = g0.da_min
+        self._dp_ref = g0.dp_ref
+        self._pfull = g0.pfull
+        qf = self.qf
+        cell = (X_DIM, Y_DIM, Z_DIM)
+        iface = (X_DIM, Y_DIM, Z_INTERFACE_DIM)
+        self._gz = qf.zeros(iface, "m^2 s^-2")
+        self._zh = qf.zeros(iface, "m")
+        self._pkc = qf.zeros(iface)
+        self._pk3 = qf.zeros(iface)
+        self._crx = qf.zeros(_DIMS["cxd"])
+        self._cry = qf.zeros(_DIMS["cyd"])
+        self._xfx = qf.zeros(_DIMS["cxd"])
+        self._yfx = qf.zeros(_DIMS["cyd"])
+        self._divgd = qf.zeros((X_INTERFACE_DIM, Y_INTERFACE_DIM, Z_DIM))
+        self._ut = qf.zeros(cell)
+        self._vt = qf.zeros(cell)
+        self._vt_scratch = qf.zeros(cell)
+        self._heat_source = qf.zeros(cell)
+        self._ws3 = qf.zeros((X_DIM, Y_DIM))
+        self._wsd = wsd if wsd is not None else qf.zeros((X_DIM, Y_DIM))
+        self._zs = qf.zeros((X_DIM, Y_DIM), "m")
+        self._phis = phis
+        # operators (same objects the reference builds in AcousticDynamics.__init__)
+        sf = stencil_factory
+        self.cgrid_shallow_water_lagrangian_dynamics = st.CGridShallowWaterDynamics(sf, qf, grid_data)
+        self.update_geopotential_height_on_c_grid = st.UpdateGeopotentialHeightOnCGrid(sf, qf, grid_data)
+        self.vertical_solver_cgrid = st.RiemannSolverC(sf, qf, grid_data)
+        self._p_grad_c = st.PGradC(sf, qf, grid_data)
+        self.dgrid_shallow_water_lagrangian_dynamics = st.DGridShallowWaterLagrangianDynamics(sf, qf, grid_data, damping_coefficients)
+        self.update_height_on_d_grid = st.UpdateHeightOnDGrid(sf, qf, grid_data)
+        self.vertical_solver = st.RiemannSolver3(sf, qf, grid_data)
+        self._pk3_halo = st.PK3Halo(sf, qf, grid_data)
+        self._edge_pe = st.EdgePE(sf, qf, grid_data)
+        self.nonhydrostatic_pressure_gradient = st.NonHydrostaticPressureGradient(sf, qf, grid_data)
+        self._rayleigh_damping = st.RayleighDamping(sf, qf, grid_data)
+        self._hyperdiffusion = st.HyperdiffusionDamping(sf, qf, damping_coefficients, nmax=min(3, self.config.nord + 1))
+        self._apply_diffusive_heating = st.ApplyDiffusiveHeating(sf, qf, grid_data)
+        # halo updaters
+        if comm is None:
+            from .topology import CubedSpherePartitioner
+
+            comm = Layout(CubedSpherePartitioner(self.config.npx - 1, tuple(self.config.layout)), 1, 0)
+        self.layout = comm
+        if len(comm.local_ranks) != sf.sizer.n_sub:
+            raise ValueError("stencil factory holds a different number of sub-domains than the layout assigns to this process")
+        self.halo = HaloExchanger(sf, comm, group=getattr(comm, "group", None))
+        self._updaters = None
+        if phis is not None and state is not None:
+            self._bind(state)
+
+    # ------------------------------------------------------------------------------------------
+    def _bind(self, state: DycoreState):
+        h = self.halo
+        self._updaters = {
+            "q_con__cappa": h.updater("cell", [(state.q_con,), (state.cappa,)]),
+            "delp__pt": h.updater("cell", [(state.delp,), (state.pt,)]),
+            "u__v": h.updater("dgrid", [(state.u, state.v)]),
+            "w": h.updater("cell", [(state.w,)]),
+            "gz": h.updater("cell", [(self._gz,)]),
+            "divgd": h.updater("corner", [(self._divgd,)]),
+            "uc__vc": h.updater("cgrid", [(state.uc, state.vc)]),
+            "delp__pt__q_con": h.updater("cell", [(state.delp,), (state.pt,), (state.q_con,)]),
+            "zh": h.updater("cell", [(self._zh,)]),
+            "pkc": h.updater("cell", [(self._pkc,)]),
+            "heat_source": h.updater("cell", [(self._heat_source,)]),
+            "interface_u__v": h.updater("sync_dgrid", [(state.u, state.v)], n_halo=0),
+            "zs": h.updater("cell", [(self._zs,)]),
+        }
+        self._state_id = id(state)
+        phis = self._phis if self._phis is not None else state.phis
+        self._phis = phis
+        self._zs.storage.copy_(phis.storage * self.c.RGRAV)
+        self._updaters["zs"].update()
+
+    def _checkpoint(self, name, **kw):
+        if self.checkpointer is not None:
+            self.checkpointer(name, **kw)
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, state: DycoreState, timestep: float, n_map: int = 1, update_temporaries: bool = True):
+        if self._updaters is None or self._state_id != id(state):
+            self._bind(state)
+        cfg, up, sf = self.config, self._updaters, self.sf
+        n_split = cfg.n_split
+        dt = timestep / n_split
+        dt2 = 0.5 * dt
+        end_step = n_map == cfg.k_split
+        up["q_con__cappa"].start()
+        up["delp__pt"].start()
+        up["u__v"].start()
+        up["q_con__cappa"].wait()
+        if update_temporaries:
+            if n_map == 1:
+                for q in (state.mfxd, state.mfyd, state.cxd, state.cyd):
+                    sf.call("zero", q.fref)
+            sf.call("zero", self._heat_source.fref)
+            sf.call("zero", state.diss_estd.fref)
+        for it in range(n_split):
+            remap_step = cfg.breed_vortex_inline or (it == n_split - 1)
+            up["w"].start()
+            if it == 0:
+                sf.call("set_gz", self._zs.fref, state.delz.fref, self._gz.fref)
+                up["gz"].start()
+                up["delp__pt"].wait()
+            up["u__v"].wait()
+            up["w"].wait()
+            self._checkpoint("C_SW-In", delpd=state.delp, ptd=state.pt, ud=state.u, vd=state.v, wd=state.w)
+            delpc, ptc = self.cgrid_shallow_water_lagrangian_dynamics(
+                state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt, self._divgd, state.omga, dt2
+            )
+            self._checkpoint("C_SW-Out", delpd=state.delp, ptd=state.pt, ucd=state.uc, vcd=state.vc, uad=state.ua, vad=state.va, utd=self._ut, vtd=self._vt, divgdd=self._divgd)
+            if cfg.nord > 0:
+                up["divgd"].start()
+            if it == 0:
+                up["gz"].wait()
+                sf.call("copy", self._gz.fref, self._zh.fref)
+            else:
+                sf.call("copy", self._zh.fref, self._gz.fref)
+            self.update_geopotential_height_on_c_grid(self._dp_ref, self._zs, self._ut, self._vt, self._gz, self._ws3, dt2)
+            self.vertical_solver_cgrid(dt2, state.cappa, self._ptop, self._phis, self._ws3, ptc, state.q_con, delpc, self._gz, self._pkc, state.omga)
+            self._p_grad_c(None, None, state.uc, state.vc, delpc, self._pkc, self._gz, dt2)
+            up["uc__vc"].start()
+            if cfg.nord > 0:
+                up["divgd"].wait()
+            up["uc__vc"].wait()
+            self._checkpoint("D_SW-In", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, zhd=self._zh, divgdd=self._divgd)
+            self.dgrid_shallow_water_lagrangian_dynamics(
+                self._vt_scratch, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
+                state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con, self._zh,
+                self._heat_source, state.diss_estd, dt,
+            )  # fmt: skip
+            self._checkpoint("D_SW-Out", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, divgdd=self._divgd, mfxd=state.mfxd, mfyd=state.mfyd, xfxd=self._xfx, yfxd=self._yfx)
+            up["delp__pt__q_con"].update()
+            self.update_height_on_d_grid(self._zs, self._zh, self._crx, self._cry, self._xfx, self._yfx, self._wsd, dt)
+            self.vertical_solver(remap_step, dt, state.cappa, self._ptop, self._zs, self._wsd, state.delz, state.q_con, state.delp, state.pt, self._zh, state.pe, self._pkc, self._pk3, state.pk, state.peln, state.w)
+            up["zh"].start()
+            up["pkc"].start()
+            if remap_step:
+                self._edge_pe(state.pe, state.delp, self._ptop)
+            self._pk3_halo(self._pk3, state.delp, self._ptop, self._akap)
+            up["zh"].wait()
+            sf.call("compute_geopotential", self._zh.fref, self._gz.fref)
+            up["pkc"].wait()
+            self.nonhydrostatic_pressure_gradient(state.u, state.v, self._pkc, self._gz, self._pk3, state.delp, dt, self._ptop, self._akap)
+            if cfg.rf_fast:
+                self._rayleigh_damping(state.u, state.v, state.w, self._dp_ref, self._pfull, dt, self._ptop)
+            if it != n_split - 1:
+                up["u__v"].start()
+            else:
+                up["interface_u__v"].update()
+        if cfg.d_con > 1.0e-5:
+            up["heat_source"].update()
+            cd = self.c.CNST_0P20 * self._da_min
+            self._hyperdiffusion(self._heat_source, cd)
+            self._apply_diffusive_heating(state.delp, state.delz, state.cappa, self._heat_source, state.pt, abs(dt * cfg.delt_max))

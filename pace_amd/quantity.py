@@ -1,0 +1,377 @@
+"""Quantity / QuantityFactory / GridIndexing -- the thin slice of NDSL's call surface the
+acoustic operators are constructed and called with.
+
+Reference evidence: ``Quantity`` attributes (``data``, ``view``, ``origin``, ``extent``,
+``dims``, ``units``, ``np``) [REF docs/util/state.rst:32-49; driver/pace/driver/safety_checks.py:82-86;
+diagnostics.py:57-62]; ``QuantityFactory.from_backend`` / ``SubtileGridSizer`` /
+``GridIndexing.from_sizer_and_communicator`` [REF driver/pace/driver/driver.py:744-765];
+``GridIndexing`` semantics [REF tests/main/fv3core/test_grid.py:56-804].
+
+MI355X-first difference: storage is *i-fastest* -- a torch tensor ``[n_sub][nk][nj][ni]`` --
+and one Quantity can carry several co-resident sub-domains (the reference's ranks) so that a
+single launch serves them all.  The logical index order the user sees stays ``(i, j, k)``:
+``q.data`` / ``q.view[:]`` are permuted views of the same memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .constants import N_HALO_DEFAULT, X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM, Z_DIM, Z_INTERFACE_DIM
+from .lib import FV3_F32, FV3_F64, fv3_field
+
+INT16_MAX = int(np.iinfo(np.int16).max)
+
+
+@dataclass
+class GridSizer:
+    """SubtileGridSizer [REF driver/pace/driver/driver.py:744-752]."""
+
+    nx: int
+    ny: int
+    nz: int
+    n_halo: int = N_HALO_DEFAULT
+    n_sub: int = 1
+
+    @classmethod
+    def from_tile_params(cls, nx_tile, ny_tile, nz, n_halo, layout, n_sub=1, **_):
+        return cls(nx_tile // layout[0], ny_tile // layout[1], nz, n_halo, n_sub)
+
+    @property
+    def storage_shape(self):
+        """(ni, nj, nk) allocation, padded to the interface shape like NDSL."""
+        return (self.nx + 2 * self.n_halo + 1, self.ny + 2 * self.n_halo + 1, self.nz + 1)
+
+    def get_extent(self, dims: Sequence[str]) -> Tuple[int, ...]:
+        ext = {
+            X_DIM: self.nx,
+            X_INTERFACE_DIM: self.nx + 1,
+            Y_DIM: self.ny,
+            Y_INTERFACE_DIM: self.ny + 1,
+            Z_DIM: self.nz,
+            Z_INTERFACE_DIM: self.nz + 1,
+        }
+        return tuple(ext[d] for d in dims)
+
+    def get_origin(self, dims: Sequence[str]) -> Tuple[int, ...]:
+        return tuple(self.n_halo if d in (X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM) else 0 for d in dims)
+
+
+class _View:
+    """``quantity.view[:]``: the compute domain [REF docs/util/state.rst:32-49]."""
+
+    def __init__(self, q: "Quantity"):
+        self._q = q
+
+    def _base(self):
+        q = self._q
+        sl = tuple(slice(o, o + e) for o, e in zip(q.origin, q.extent))
+        return q.data[sl] if q._squeeze else q.data[(slice(None),) + sl]
+
+    def __getitem__(self, idx):
+        return self._base()[idx]
+
+    def __setitem__(self, idx, value):
+        self._base()[idx] = value
+
+
+class Quantity:
+    """A field on one or more co-resident sub-domains.
+
+    ``storage`` is ``[n_sub, nk, nj, ni]`` (3-D) or ``[n_sub, nj, ni]`` (2-D);
+    ``data`` is the ``(i, j, k)`` view (with a leading sub-domain axis when n_sub > 1).
+    """
+
+    def __init__(self, storage: torch.Tensor, dims: Sequence[str], units: str = "", origin=None, extent=None, n_halo: int = N_HALO_DEFAULT):
+        if storage.dim() not in (3, 4):
+            raise ValueError("storage must be [n_sub, (nk,) nj, ni]")
+        if not storage.is_contiguous():
+            raise ValueError("storage must be contiguous (i fastest)")
+        self.storage = storage
+        self.dims = tuple(dims)
+        self.units = units
+        self.n_sub = storage.shape[0]
+        self.is_2d = storage.dim() == 3
+        self._squeeze = self.n_sub == 1
+        self.n_halo = n_halo
+        ni, nj = storage.shape[-1], storage.shape[-2]
+        nk = 1 if self.is_2d else storage.shape[1]
+        self._alloc = (ni, nj, nk)
+        if origin is None:
+            origin = tuple(n_halo if d in (X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM) else 0 for d in self.dims)
+        self.origin = tuple(origin)
+        if extent is None:
+            nx, ny = ni - 2 * n_halo - 1, nj - 2 * n_halo - 1
+            ex = {X_DIM: nx, X_INTERFACE_DIM: nx + 1, Y_DIM: ny, Y_INTERFACE_DIM: ny + 1, Z_DIM: nk - 1, Z_INTERFACE_DIM: nk}
+            extent = tuple(ex[d] for d in self.dims)
+        self.extent = tuple(extent)
+        self._field = None
+        self.view = _View(self)
+
+    # -- reference-style accessors -------------------------------------------------------------
+    @property
+    def data(self) -> torch.Tensor:
+        s = self.storage
+        v = s.permute(0, 2, 1) if self.is_2d else s.permute(0, 3, 2, 1)
+        return v[0] if self._squeeze else v
+
+    @property
+    def np(self):
+        return np
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def dtype(self):
+        return self.storage.dtype
+
+    @property
+    def device(self):
+        return self.storage.device
+
+    def sub(self, r: int) -> "Quantity":
+        """The r-th co-resident sub-domain as its own Quantity (shares memory)."""
+        return Quantity(self.storage[r : r + 1], self.dims, self.units, self.origin, self.extent, self.n_halo)
+
+    def numpy(self, r: Optional[int] = None) -> np.ndarray:
+        """Host copy in (i, j, k) order (of sub-domain r, or of the only one)."""
+        s = self.storage if r is None else self.storage[r : r + 1]
+        if s.shape[0] != 1:
+            raise ValueError("pick a sub-domain")
+        a = s[0].detach().cpu().numpy()
+        return np.ascontiguousarray(a.T)
+
+    def set_numpy(self, a: np.ndarray, r: int = 0):
+        """Fill sub-domain r from an (i, j[, k]) host array (trailing singleton k allowed for 2-D)."""
+        a = np.asarray(a)
+        if self.is_2d and a.ndim == 3:
+            a = a[:, :, 0]
+        t = torch.from_numpy(np.ascontiguousarray(a.T)).to(self.storage.dtype)
+        self.storage[r].copy_(t)
+
+    # -- C ABI -----------------------------------------------------------------------------------
+    @property
+    def field(self) -> fv3_field:
+        if self._field is None:
+            ni, nj, nk = self._alloc
+            f = fv3_field()
+            f.ptr = self.storage.data_ptr()
+            f.shape[0], f.shape[1], f.shape[2] = ni, nj, nk
+            f.stride[0], f.stride[1], f.stride[2] = 1, ni, ni * nj
+            f.sub_stride = ni * nj * nk
+            f.n_sub = self.n_sub
+            f.dtype = FV3_F64 if self.storage.dtype == torch.float64 else FV3_F32
+            self._field = f
+        return self._field
+
+    @property
+    def fref(self):
+        return C.byref(self.field)
+
+
+class QuantityFactory:
+    """``QuantityFactory.from_backend(sizer, backend)`` [REF driver/pace/driver/driver.py:183,758].
+    The backend string of this build is ``"hip:gfx950"``; ``"hostemu"`` keeps storage on the CPU
+    for the test-only host-emulation library."""
+
+    def __init__(self, sizer: GridSizer, device="cuda:0", dtype=torch.float64):
+        self.sizer = sizer
+        self.device = torch.device(device)
+        self.dtype = dtype
+
+    @classmethod
+    def from_backend(cls, sizer: GridSizer, backend: str = "hip:gfx950", dtype=torch.float64, device=None):
+        if backend == "hostemu":
+            return cls(sizer, "cpu", dtype)
+        if backend not in ("hip:gfx950", "hip"):
+            raise ValueError(f"backend {backend!r}: this build provides 'hip:gfx950' (product) and 'hostemu' (tests)")
+        return cls(sizer, device or "cuda:0", dtype)
+
+    def _alloc(self, dims, fill=None):
+        ni, nj, nk = self.sizer.storage_shape
+        two_d = not any(d in (Z_DIM, Z_INTERFACE_DIM) for d in dims)
+        shape = (self.sizer.n_sub, nj, ni) if two_d else (self.sizer.n_sub, nk, nj, ni)
+        if fill is None:
+            return torch.empty(shape, dtype=self.dtype, device=self.device)
+        return torch.full(shape, fill, dtype=self.dtype, device=self.device)
+
+    def zeros(self, dims: Sequence[str], units: str = "", dtype=None) -> Quantity:
+        return Quantity(self._alloc(dims, 0.0), dims, units, n_halo=self.sizer.n_halo)
+
+    def ones(self, dims, units="", dtype=None) -> Quantity:
+        return Quantity(self._alloc(dims, 1.0), dims, units, n_halo=self.sizer.n_halo)
+
+    def empty(self, dims, units="", dtype=None) -> Quantity:
+        return Quantity(self._alloc(dims), dims, units, n_halo=self.sizer.n_halo)
+
+    def from_array(self, arrays, dims, units="") -> Quantity:
+        """arrays: one (i, j[, k]) host array per sub-domain (or a single array for n_sub == 1)."""
+        if isinstance(arrays, np.ndarray):
+            arrays = [arrays]
+        q = self.zeros(dims, units)
+        for r, a in enumerate(arrays):
+            q.set_numpy(a, r)
+        return q
+
+
+# ----------------------------------------------------------------------------------------------
+# GridIndexing  [REF tests/main/fv3core/test_grid.py]
+# ----------------------------------------------------------------------------------------------
+class GridIndexing:
+    def __init__(self, domain, n_halo, south_edge, north_edge, west_edge, east_edge, origin=None, max_shape=None):
+        self.domain = tuple(domain)
+        self.n_halo = n_halo
+        self.south_edge = south_edge
+        self.north_edge = north_edge
+        self.west_edge = west_edge
+        self.east_edge = east_edge
+        self.origin = tuple(origin) if origin is not None else (n_halo, n_halo, 0)
+        self._max_shape = tuple(max_shape) if max_shape is not None else (self.domain[0] + 2 * n_halo + 1, self.domain[1] + 2 * n_halo + 1, self.domain[2] + 1)
+
+    @classmethod
+    def from_sizer_and_communicator(cls, sizer: GridSizer, comm=None, edges=None):
+        e = edges or {"south": True, "north": True, "west": True, "east": True}
+        if comm is not None and hasattr(comm, "edges"):
+            e = comm.edges
+        return cls((sizer.nx, sizer.ny, sizer.nz), sizer.n_halo, e["south"], e["north"], e["west"], e["east"])
+
+    @property
+    def max_shape(self):
+        return self._max_shape
+
+    # index properties of the compute domain
+    @property
+    def isc(self):
+        return self.origin[0]
+
+    @property
+    def iec(self):
+        return self.origin[0] + self.domain[0] - 1
+
+    @property
+    def jsc(self):
+        return self.origin[1]
+
+    @property
+    def jec(self):
+        return self.origin[1] + self.domain[1] - 1
+
+    @property
+    def isd(self):
+        return self.origin[0] - self.n_halo
+
+    @property
+    def ied(self):
+        return self.iec + self.n_halo
+
+    @property
+    def jsd(self):
+        return self.origin[1] - self.n_halo
+
+    @property
+    def jed(self):
+        return self.jec + self.n_halo
+
+    def origin_full(self, add=(0, 0, 0)):
+        return (self.isd + add[0], self.jsd + add[1], self.origin[2] + add[2])
+
+    def origin_compute(self, add=(0, 0, 0)):
+        return (self.isc + add[0], self.jsc + add[1], self.origin[2] + add[2])
+
+    def domain_full(self, add=(0, 0, 0)):
+        return (self.ied + 1 - self.isd + add[0], self.jed + 1 - self.jsd + add[1], self.domain[2] + add[2])
+
+    def domain_compute(self, add=(0, 0, 0)):
+        return (self.iec + 1 - self.isc + add[0], self.jec + 1 - self.jsc + add[1], self.domain[2] + add[2])
+
+    def axis_offsets(self, origin, domain):
+        """Edge-aware i_start..j_end externals: on a rank without the tile edge they are pushed
+        out of reach so edge clauses never fire [REF tests/main/fv3core/test_grid.py:56-101]."""
+        if self.west_edge:
+            i_start = self.isc - origin[0]
+        else:
+            i_start = -INT16_MAX
+        if self.east_edge:
+            i_end = self.iec - origin[0]
+        else:
+            i_end = INT16_MAX
+        if self.south_edge:
+            j_start = self.jsc - origin[1]
+        else:
+            j_start = -INT16_MAX
+        if self.north_edge:
+            j_end = self.jec - origin[1]
+        else:
+            j_end = INT16_MAX
+        return {
+            "i_start": i_start,
+            "local_is": self.isc - origin[0],
+            "i_end": i_end,
+            "local_ie": self.iec - origin[0],
+            "j_start": j_start,
+            "local_js": self.jsc - origin[1],
+            "j_end": j_end,
+            "local_je": self.jec - origin[1],
+        }
+
+    def _dim_extent(self, dim):
+        return {
+            X_DIM: self.domain[0],
+            X_INTERFACE_DIM: self.domain[0] + 1,
+            Y_DIM: self.domain[1],
+            Y_INTERFACE_DIM: self.domain[1] + 1,
+            Z_DIM: self.domain[2],
+            Z_INTERFACE_DIM: self.domain[2] + 1,
+        }[dim]
+
+    def get_origin_domain(self, dims: Sequence[str], halos: Sequence[int] = tuple()):
+        origin = self._origin_from_dims(dims)
+        domain = [self._dim_extent(d) for d in dims]
+        for i, n in enumerate(halos):
+            origin[i] -= n
+            domain[i] += 2 * n
+        return tuple(origin), tuple(domain)
+
+    def _origin_from_dims(self, dims):
+        out = []
+        for d in dims:
+            if d in (X_DIM, X_INTERFACE_DIM):
+                out.append(self.origin[0])
+            elif d in (Y_DIM, Y_INTERFACE_DIM):
+                out.append(self.origin[1])
+            elif d in (Z_DIM, Z_INTERFACE_DIM):
+                out.append(self.origin[2])
+        return out
+
+    def get_shape(self, dims: Sequence[str], halos: Sequence[int] = tuple()):
+        shape = []
+        for i, d in enumerate(dims):
+            n = self._dim_extent(d)
+            if d in (X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM):
+                n += self.n_halo
+            shape.append(n)
+        for i, n in enumerate(halos):
+            shape[i] += n
+        return tuple(shape)
+
+    def restrict_vertical(self, k_start=0, nk=None):
+        if nk is None:
+            nk = self.domain[2] - k_start
+        if k_start < 0 or k_start + nk > self.domain[2] or nk < 0:
+            raise ValueError("restrict_vertical outside the current vertical domain")
+        return GridIndexing(
+            (self.domain[0], self.domain[1], nk),
+            self.n_halo,
+            self.south_edge,
+            self.north_edge,
+            self.west_edge,
+            self.east_edge,
+            origin=(self.origin[0], self.origin[1], self.origin[2] + k_start),
+            max_shape=self._max_shape,
+        )

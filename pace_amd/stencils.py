@@ -1,0 +1,142 @@
+"""Operator classes of the acoustic path -- same names, constructor shape and ``__call__``
+argument order as the pyFV3 operators the reference constructs
+(ctor/call evidence [REF examples/notebooks/functions.py:877-891,935-951],
+class names [REF tests/main/fv3core/test_config.py:10-16]).  Each call is one C-ABI entry of
+``libfv3_mi355x`` enqueued on the factory's HIP stream; nothing is allocated or compiled at
+call time [REF tests/main/fv3core/test_dycore_call.py:193-211].
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from .constants import X_DIM, X_INTERFACE_DIM, Y_DIM, Y_INTERFACE_DIM, Z_DIM, Z_INTERFACE_DIM
+from .context import StencilFactory
+from .quantity import Quantity
+
+_CELL = (X_DIM, Y_DIM, Z_DIM)
+
+
+def _ref(q: Optional[Quantity]):
+    return None if q is None else q.fref
+
+
+class _Op:
+    def __init__(self, stencil_factory: StencilFactory, quantity_factory=None, grid_data=None, *_, **__):
+        self.sf = stencil_factory
+        self.qf = quantity_factory or stencil_factory.quantity_factory
+        self.grid_data = grid_data
+
+
+class CGridShallowWaterDynamics(_Op):
+    """``c_sw``; returns (delpc, ptc) like the reference."""
+
+    def __init__(self, stencil_factory, quantity_factory=None, grid_data=None, nested=False, grid_type=0, nord=None):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+        self.delpc = self.qf.zeros(_CELL, "Pa")
+        self.ptc = self.qf.zeros(_CELL, "K")
+
+    def __call__(self, delp, pt, u, v, w, uc, vc, ua, va, ut, vt, divgd, omga, dt2):
+        self.sf.call("c_sw", delp.fref, pt.fref, u.fref, v.fref, w.fref, uc.fref, vc.fref, ua.fref, va.fref, ut.fref, vt.fref, divgd.fref, omga.fref, self.delpc.fref, self.ptc.fref, float(dt2))
+        return self.delpc, self.ptc
+
+
+class UpdateGeopotentialHeightOnCGrid(_Op):
+    def __call__(self, dp_ref, zs, ut, vt, gz, ws, dt):
+        self.sf.call("update_dz_c", zs.fref, ut.fref, vt.fref, gz.fref, ws.fref, float(dt))
+
+
+class RiemannSolverC(_Op):
+    def __call__(self, dt2, cappa, ptop, phis, ws, ptc, q_con, delpc, gz, pef, w3):
+        self.sf.call("riem_solver_c", float(dt2), cappa.fref, float(ptop), phis.fref, ws.fref, ptc.fref, q_con.fref, delpc.fref, gz.fref, pef.fref, w3.fref)
+
+
+class PGradC(_Op):
+    """The ``p_grad_c`` stencil of dyn_core."""
+
+    def __call__(self, rdxc, rdyc, uc, vc, delpc, pkc, gz, dt2):
+        self.sf.call("p_grad_c", uc.fref, vc.fref, delpc.fref, pkc.fref, gz.fref, float(dt2))
+
+
+class FiniteVolumeFluxPrep(_Op):
+    def __init__(self, stencil_factory, grid_data=None, grid_type=0):
+        super().__init__(stencil_factory, None, grid_data)
+
+    def __call__(self, uc, vc, crx, cry, x_area_flux, y_area_flux, uc_contra, vc_contra, dt):
+        self.sf.call("fxadv", uc.fref, vc.fref, crx.fref, cry.fref, x_area_flux.fref, y_area_flux.fref, uc_contra.fref, vc_contra.fref, float(dt))
+
+
+class FiniteVolumeTransport(_Op):
+    """``fv_tp_2d``.  ``nord``/``damp_c`` enable the del-n damping fluxes (scalars here; the
+    per-level columns of d_sw are handled inside ``fv3_d_sw``)."""
+
+    def __init__(self, stencil_factory, quantity_factory=None, grid_data=None, damping_coefficients=None, grid_type=0, hord=6, nord=None, damp_c=None):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+        self.hord = int(hord)
+        self.nord = -1 if nord is None else int(nord)
+        self.damp_c = 0.0 if damp_c is None else float(damp_c)
+
+    def __call__(self, q, crx, cry, x_area_flux, y_area_flux, q_x_flux, q_y_flux, x_mass_flux=None, y_mass_flux=None, mass=None):
+        self.sf.call("fv_tp_2d", q.fref, crx.fref, cry.fref, x_area_flux.fref, y_area_flux.fref, q_x_flux.fref, q_y_flux.fref, _ref(x_mass_flux), _ref(y_mass_flux), _ref(mass), self.hord, self.nord, self.damp_c)
+
+
+class AGrid2BGridFourthOrder(_Op):
+    def __init__(self, stencil_factory, quantity_factory=None, grid_data=None, grid_type=0, z_dim=Z_DIM, replace=False):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+        self.replace = bool(replace)
+        self.nk = stencil_factory.sizer.nz + (1 if z_dim == Z_INTERFACE_DIM else 0)
+
+    def __call__(self, qin, qout, kstart=0, nk=None):
+        self.sf.call("a2b_ord4", qin.fref, qout.fref, int(kstart), int(self.nk if nk is None else nk), int(self.replace))
+
+
+class DGridShallowWaterLagrangianDynamics(_Op):
+    def __init__(self, stencil_factory, quantity_factory=None, grid_data=None, damping_coefficients=None, column_namelist=None, nested=False, stretched_grid=False, config=None):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+
+    def __call__(self, delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est, dt):
+        a = (delpc, delp, pt, u, v, w, uc, vc, ua, va, divgd, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, zh, heat_source, diss_est)
+        self.sf.call("d_sw", *[x.fref for x in a], float(dt))
+
+
+class UpdateHeightOnDGrid(_Op):
+    def __call__(self, surface_height, height, courant_number_x, courant_number_y, x_area_flux, y_area_flux, ws, dt):
+        self.sf.call("update_dz_d", surface_height.fref, height.fref, courant_number_x.fref, courant_number_y.fref, x_area_flux.fref, y_area_flux.fref, ws.fref, float(dt))
+
+
+class RiemannSolver3(_Op):
+    def __call__(self, last_call, dt, cappa, ptop, zs, wsd, delz, q_con, delp, pt, zh, pe, ppe, pk3, pk, peln, w):
+        self.sf.call("riem_solver3", int(bool(last_call)), float(dt), cappa.fref, float(ptop), zs.fref, wsd.fref, delz.fref, q_con.fref, delp.fref, pt.fref, zh.fref, pe.fref, ppe.fref, pk3.fref, pk.fref, peln.fref, w.fref)
+
+
+class PK3Halo(_Op):
+    def __call__(self, pk3, delp, ptop, akap):
+        self.sf.call("pk3_halo", pk3.fref, delp.fref, float(ptop), float(akap))
+
+
+class EdgePE(_Op):
+    def __call__(self, pe, delp, ptop):
+        self.sf.call("edge_pe", pe.fref, delp.fref, float(ptop))
+
+
+class NonHydrostaticPressureGradient(_Op):
+    def __call__(self, u, v, pp, gz, pk3, delp, dt, ptop, akap):
+        self.sf.call("nh_p_grad", u.fref, v.fref, pp.fref, gz.fref, pk3.fref, delp.fref, float(dt), float(ptop), float(akap))
+
+
+class RayleighDamping(_Op):
+    def __call__(self, u, v, w, dp, pfull, dt, ptop, ks=None):
+        self.sf.call("ray_fast", u.fref, v.fref, w.fref, float(dt), float(ptop))
+
+
+class HyperdiffusionDamping(_Op):
+    def __init__(self, stencil_factory, quantity_factory=None, damping_coefficients=None, rarea=None, nmax=3):
+        super().__init__(stencil_factory, quantity_factory, None)
+        self.nmax = int(nmax)
+
+    def __call__(self, qdel, cd):
+        self.sf.call("del2_cubed", qdel.fref, float(cd), self.nmax)
+
+
+class ApplyDiffusiveHeating(_Op):
+    def __call__(self, delp, delz, cappa, heat_source, pt, delt_time_factor):
+        self.sf.call("apply_diffusive_heating", delp.fref, delz.fref, cappa.fref, heat_source.fref, pt.fref, float(delt_time_factor))
