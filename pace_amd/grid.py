@@ -564,10 +564,19 @@ def global_area_minima(nx_tile: int, c: ConstantSet, nh: int = 3) -> Tuple[float
     recursion into make_grid's default)."""
     key = (nx_tile, c.name, nh)
     if key not in _AREA_MIN_CACHE:
-        part = CubedSpherePartitioner(nx_tile, (1, 1))
+        # cell areas of the equal-edge gnomonic grid shrink monotonically towards the cube
+        # corners, so a small corner patch holds both minima (checked against the full tile
+        # in tests/test_grid.py); avoids a 775^2 setup at C768.
+        div = 1
+        for d in range(nx_tile // 8, 0, -1):
+            if nx_tile % d == 0 and nx_tile // d >= 8:
+                div = d
+                break
+        part = CubedSpherePartitioner(nx_tile, (div, div))
+        n = part.nx
         g = make_grid(part, 0, nz=1, n_halo=nh, constants=c, ak=np.array([1.0, 0.0]), bk=np.array([0.0, 1.0]), da_min=1.0, da_min_c=1.0)
-        a = g.area[nh : nh + nx_tile, nh : nh + nx_tile]
-        ac = g.area_c[nh : nh + nx_tile + 1, nh : nh + nx_tile + 1]
+        a = g.area[nh : nh + n, nh : nh + n]
+        ac = g.area_c[nh : nh + n + 1, nh : nh + n + 1]
         _AREA_MIN_CACHE[key] = (float(a.min()), float(ac.min()))
     return _AREA_MIN_CACHE[key]
 

@@ -1,0 +1,107 @@
+"""Dycore-only harness: builds grid, synthetic state and the acoustic dynamics for the ranks
+one process owns and steps them -- the slice of ``Driver._critical_path_step_all`` that reaches
+the hot path with ``dycore_only: true, disable_step_physics: true``
+[REF driver/pace/driver/driver.py:627-662; .jenkins/driver_configs/baroclinic_c48_6ranks_dycore_only.yaml:1-2].
+One "step" = ``k_split`` calls of AcousticDynamics (no tracer advection / remapping / physics --
+out of scope), timed like the reference ("mainloop" timer, first step dropped
+[REF .jenkins/print_performance_number.py:13-14]).
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import AcousticDynamicsConfig
+from .constants import get_constants
+from .context import StencilFactory
+from .dyn_core import STATE_NAMES, AcousticDynamics, DycoreState
+from .grid import make_grid
+from .halo import Layout
+from .init import synthetic_state, synthetic_state_device
+from .topology import CubedSpherePartitioner
+
+# dt_atmos / k_split / n_split per configuration
+CONFIGS = {
+    "c12": dict(nx_tile=12, nz=79, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=1),
+    "c48": dict(nx_tile=48, nz=79, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=1),
+    "c192": dict(nx_tile=192, nz=79, layout=(1, 1), dt_atmos=200.0, k_split=7, n_split=8),
+    "c768": dict(nx_tile=768, nz=79, layout=(2, 2), dt_atmos=225.0, k_split=2, n_split=6),
+}
+
+
+class DycoreHarness:
+    def __init__(
+        self,
+        nx_tile: int,
+        nz: int = 79,
+        layout=(1, 1),
+        dt_atmos: float = 225.0,
+        k_split: int = 1,
+        n_split: int = 1,
+        world_size: int = 1,
+        proc: int = 0,
+        backend: str = "hip:gfx950",
+        device: Optional[str] = None,
+        dtype=torch.float64,
+        group=None,
+        seed: int = 20261002,
+        noise: float = 0.01,
+        verbose: bool = False,
+    ):
+        self.c = get_constants()
+        self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
+        self.cfg = AcousticDynamicsConfig(npx=nx_tile + 1, npy=nx_tile + 1, npz=nz, layout=tuple(layout), dt_atmos=dt_atmos, k_split=k_split, n_split=n_split)
+        self.layout = Layout(self.part, world_size, proc)
+        self.layout.group = group
+        t0 = time.time()
+        self.grids = [make_grid(self.part, r, nz=nz) for r in self.layout.local_ranks]
+        if verbose:
+            print(f"[harness] grid for ranks {self.layout.local_ranks} in {time.time() - t0:.1f}s", flush=True)
+        self.sf = StencilFactory(self.grids, self.cfg, self.c, backend=backend, device=device, dtype=dtype)
+        self.state = DycoreState(self.sf.quantity_factory)
+        t0 = time.time()
+        on_device = not self.sf.hostemu
+        for i, (g, r) in enumerate(zip(self.grids, self.layout.local_ranks)):
+            if on_device:
+                # evaluate the recipe with torch on the GPU (numpy needs ~1 min per 384^2 x 79 rank)
+                s = synthetic_state_device(g, self.sf.device, seed=seed, rank=r, noise=noise)
+                for n in STATE_NAMES + ["phis"]:
+                    q = getattr(self.state, n)
+                    src = s[n]
+                    q.storage[i].copy_((src.permute(1, 0) if src.dim() == 2 else src.permute(2, 1, 0)).to(q.storage.dtype))
+            else:
+                s = synthetic_state(g, seed=seed, rank=r, noise=noise)
+                for n in STATE_NAMES + ["phis"]:
+                    getattr(self.state, n).set_numpy(s[n], i)
+            del s
+        if verbose:
+            print(f"[harness] synthetic state in {time.time() - t0:.1f}s", flush=True)
+        self.dyn = AcousticDynamics(self.layout, self.grids, self.sf, config=self.cfg, phis=self.state.phis, state=self.state)
+        # shared D-grid interface winds must be single-valued across sub-domains (they are in any
+        # physical state; the per-rank white noise of the synthetic recipe breaks it)
+        self.dyn._updaters["interface_u__v"].update()
+        self.cells_local = self.part.nx * self.part.ny * nz * len(self.grids)
+        self.cells_global = nx_tile * nx_tile * 6 * nz
+
+    def step(self):
+        """One model step of the dycore-only driver: k_split acoustic-dynamics calls."""
+        dt = self.cfg.dt_atmos / self.cfg.k_split
+        for k in range(self.cfg.k_split):
+            self.dyn(self.state, dt, n_map=k + 1)
+
+    def synchronize(self):
+        if not self.sf.hostemu:
+            torch.cuda.synchronize(self.sf.device)
+
+    def sanity(self):
+        """SafetyChecker-style bounds [REF driver/pace/driver/driver.py:557-560] on the local state."""
+        out = {}
+        for n in ("delp", "pt", "u", "v", "w"):
+            q = getattr(self.state, n)
+            v = q.view[...]
+            v = v[..., : self.cfg.npz]
+            out[n] = (float(v.min()), float(v.max()), bool(torch.isfinite(v).all()))
+        return out

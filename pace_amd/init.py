@@ -143,3 +143,97 @@ def synthetic_state(
         phis[:, :, 0] = c.GRAV * mountain * np.maximum(0.0, modes[7](Pa)) ** 2
     st["phis"] = phis
     return st
+
+
+def synthetic_state_device(grid: GridData, device, seed: int = 20261002, constants: Optional[ConstantSet] = None, noise: float = 0.01, wind: float = 20.0, rank: int = 0):
+    """The same recipe as :func:`synthetic_state`, evaluated with torch on ``device`` (host numpy
+    takes ~1 min per 384^2 x 79 rank; the benchmark fills 24 of them).  Smooth parts agree with
+    the numpy version to round-off; the white noise comes from torch's generator instead of
+    numpy's.  Returns {name: tensor[i, j, k]} plus "phis" [i, j]."""
+    import torch
+
+    c = constants or get_constants()
+    nh, nx, ny, nz = grid.n_halo, grid.nx, grid.ny, grid.nz
+    shp2 = (nx + 2 * nh + 1, ny + 2 * nh + 1)
+    f64 = torch.float64
+    dev = torch.device(device)
+    T = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=f64, device=dev)  # noqa: E731
+    rng = np.random.default_rng(seed)
+    modes = [_Modes(rng) for _ in range(8)]
+    axis = T(_sph(np.array(0.3), np.array(1.1)))
+    wvec_modes = [_Modes(rng) for _ in range(3)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 1000 + rank)
+
+    def sph(lon, lat):
+        lon, lat = T(lon), T(lat)
+        return torch.stack([torch.cos(lat) * torch.cos(lon), torch.cos(lat) * torch.sin(lon), torch.sin(lat)], dim=-1)
+
+    def ev(m, p):
+        out = torch.zeros(p.shape[:-1], dtype=f64, device=dev)
+        for k, ph, a in zip(m.k, m.phase, m.amp):
+            out = out + float(a) * torch.sin(p @ T(k) + float(ph))
+        return out
+
+    Pc = sph(grid.lon, grid.lat)
+    Pa = sph(grid.lon_agrid, grid.lat_agrid)
+
+    def wind3(p):
+        w = torch.cross(axis.expand_as(p), p, dim=-1)
+        psi = torch.stack([ev(m, p) for m in wvec_modes], dim=-1)
+        return wind * (w + 0.5 * torch.cross(psi, p, dim=-1))
+
+    kk = torch.arange(nz, dtype=f64, device=dev)
+    vs = [torch.cos(2 * np.pi * (kk + 3.0 * i) / nz) for i in range(6)]
+
+    def field3(i, p):
+        base = ev(modes[i], p)
+        other = ev(modes[(i + 3) % len(modes)], p)
+        f = base[:, :, None] * (0.7 + 0.3 * vs[i % 6])[None, None, :] + 0.3 * other[:, :, None] * vs[(i + 1) % 6][None, None, :]
+        if noise > 0:
+            f = f + noise * torch.randn(f.shape, dtype=f64, device=dev, generator=gen)
+        return f
+
+    ak, bk = T(grid.ak), T(grid.bk)
+    ps = 1.0e5 * (1.0 + 0.01 * ev(modes[0], Pa))
+    pe = ak[None, None, :] + bk[None, None, :] * ps[:, :, None]
+    delp = (pe[:, :, 1:] - pe[:, :, :-1]) * (1.0 + 0.002 * field3(1, Pa))
+    q_con = 1.0e-4 * torch.abs(field3(6, Pa))
+    cappa = c.KAPPA * (1.0 - 0.2 * q_con)
+    top = torch.full(shp2 + (1,), float(grid.ak[0]), dtype=f64, device=dev)
+    pem = torch.cat([top, float(grid.ak[0]) + torch.cumsum(delp, dim=-1)], dim=-1)
+    peg = torch.cat([top, float(grid.ak[0]) + torch.cumsum(delp * (1.0 - q_con), dim=-1)], dim=-1)
+    pm = (peg[:, :, 1:] - peg[:, :, :-1]) / torch.log(peg[:, :, 1:] / peg[:, :, :-1])
+    temp = torch.clamp(288.0 * (pm / 1.0e5) ** 0.19, min=200.0) * (1.0 + 0.005 * field3(2, Pa))
+    pkz = torch.exp(cappa * torch.log(pm))
+    st = {n: torch.zeros(shp2 + (nz + 1,), dtype=f64, device=dev) for n in STATE_3D}
+
+    def edge_dir(a, b):
+        e = b - a
+        m = a + b
+        m = m / torch.linalg.norm(m, dim=-1, keepdim=True)
+        e = e - torch.sum(e * m, -1, keepdim=True) * m
+        return e / torch.linalg.norm(e, dim=-1, keepdim=True), m
+
+    ex, mx = edge_dir(Pc[:-1, :, :], Pc[1:, :, :])
+    ey, my = edge_dir(Pc[:, :-1, :], Pc[:, 1:, :])
+    prof = (0.6 + 0.4 * torch.cos(np.pi * (kk + 0.5) / nz))[None, None, :]
+    st["u"][:-1, :, :nz] = torch.sum(wind3(mx) * ex, -1)[:, :, None] * prof
+    st["v"][:, :-1, :nz] = torch.sum(wind3(my) * ey, -1)[:, :, None] * prof
+    if noise > 0:
+        st["u"][:, :, :nz] += wind * 0.2 * noise * torch.randn(st["u"][:, :, :nz].shape, dtype=f64, device=dev, generator=gen)
+        st["v"][:, :, :nz] += wind * 0.2 * noise * torch.randn(st["v"][:, :, :nz].shape, dtype=f64, device=dev, generator=gen)
+    st["w"][:, :, :nz] = 0.1 * field3(5, Pa)
+    st["delp"][:, :, :nz] = delp
+    st["pt"][:, :, :nz] = temp / pkz
+    st["delz"][:, :, :nz] = -c.RDGAS * temp * delp / (c.GRAV * pm)
+    st["q_con"][:, :, :nz] = q_con
+    st["cappa"][:, :, :nz] = cappa
+    st["pkz"][:, :, :nz] = pkz
+    st["pe"][:] = pem
+    st["peln"][:] = torch.log(pem)
+    st["pk"][:] = torch.exp(c.KAPPA * torch.log(pem))
+    for n in ("delp", "pt", "delz", "cappa"):
+        st[n][:, :, nz] = st[n][:, :, nz - 1]
+    st["phis"] = torch.zeros(shp2, dtype=f64, device=dev)
+    return st

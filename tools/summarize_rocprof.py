@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 --kernel-trace --stats CSV into a short table (for profiles/)."""
+import csv
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"fv3_k[23]<(.*?)::\{lambda.*?#(\d+)\}", name)
+    if m:
+        fn = re.sub(r"\(.*\)", "", m.group(1)).replace("(anonymous namespace)::", "")
+        return f"{fn}#{m.group(2)}"
+    return re.sub(r"\(.*", "", name)[:60]
+
+
+def main(path, top=45):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print(f"total kernel time {tot / 1e6:.1f} ms over {sum(int(r['Calls']) for r in rows)} launches, {len(rows)} distinct kernels\n")
+    print("| kernel (operator#launch) | calls | avg ms | total ms | % |")
+    print("|---|---:|---:|---:|---:|")
+    for r in rows[:top]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {float(r['TotalDurationNs']) / 1e6:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
+    agg = {}
+    for r in rows:
+        op = short(r["Name"]).split("#")[0]
+        agg[op] = agg.get(op, 0.0) + float(r["TotalDurationNs"])
+    print("\n| operator | total ms | % |\n|---|---:|---:|")
+    for op, v in sorted(agg.items(), key=lambda kv: -kv[1])[:20]:
+        print(f"| {op} | {v / 1e6:.1f} | {100 * v / tot:.1f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45)
