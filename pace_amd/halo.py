@@ -226,11 +226,11 @@ class HaloUpdater:
             ops = []
             self._recv_bufs = {}
             for peer, cnt in ph.recv_count.items():
-                buf = ex._buffer(("r", self.key, peer, len(self.groups)), cnt * self.nk * len(self.groups))
+                buf = ex._buffer(("r", id(self), peer), cnt * self.nk * len(self.groups))
                 self._recv_bufs[peer] = buf
                 ops.append(dist.P2POp(dist.irecv, buf, peer, group=ex.group))
             for peer, cnt in ph.send_count.items():
-                buf = ex._buffer(("s", self.key, peer, len(self.groups)), cnt * self.nk * len(self.groups))
+                buf = ex._buffer(("s", id(self), peer), cnt * self.nk * len(self.groups))
                 for gi, gp in enumerate(self.groups):
                     base = buf.data_ptr() + gi * cnt * self.nk * buf.element_size()
                     for comp, plan in ph.send[peer].items():

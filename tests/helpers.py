@@ -64,3 +64,67 @@ def assert_close(name, got, want, rtol=1e-13, atol_scale=1e-13):
     assert np.all(np.isfinite(got)), f"{name}: non-finite values"
     assert err <= atol_scale * scale + rtol * scale + 1e-300, f"{name}: max abs err {err:.3e} vs field scale {scale:.3e}"
     return err / scale if scale > 0 else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# whole-cube helpers
+# ---------------------------------------------------------------------------------------------
+STAG_X = ("v", "uc", "mfxd", "cxd")  # fields with an extra x interface
+STAG_Y = ("u", "vc", "mfyd", "cyd")
+IFACE_K = ("pe", "pk", "peln")
+
+
+def compute_slice(name, nx, ny, nz, nh=3):
+    ex = 1 if name in STAG_X else 0
+    ey = 1 if name in STAG_Y else 0
+    kk = nz + 1 if name in IFACE_K else nz
+    return (slice(nh, nh + nx + ex), slice(nh, nh + ny + ey), slice(0, kk))
+
+
+def oracle_cube(nx_tile, layout, nz, cfg_kw=None, seed=7, noise=0.01):
+    """(part, cfg, grids, states, OracleAcousticDynamics) with interface-consistent initial winds."""
+    from fv3_oracle.dyn_core import OracleAcousticDynamics
+
+    c = get_constants()
+    part = CubedSpherePartitioner(nx_tile, layout)
+    kw = dict(npx=nx_tile + 1, npy=nx_tile + 1, npz=nz, layout=layout)
+    kw.update(cfg_kw or {})
+    cfg = AcousticDynamicsConfig(**kw)
+    grids = [make_grid(part, r, nz=nz) for r in range(part.total_ranks)]
+    states = [synthetic_state(g, seed=seed, rank=r, noise=noise) for r, g in enumerate(grids)]
+    phis = [s["phis"] for s in states]
+    ost = [{k: v for k, v in s.items() if k != "phis"} for s in states]
+    dyn = OracleAcousticDynamics(part, grids, cfg, c, phis)
+    dyn.ex.synchronize_vector_interfaces([s["u"] for s in ost], [s["v"] for s in ost])
+    return part, cfg, grids, ost, phis, dyn
+
+
+def run_device_cube(backend, part, cfg, grids, ost_init, phis, timestep, n_calls=1, dtype=torch.float64):
+    """Run AcousticDynamics on every rank of the cube in one context; returns per-rank arrays."""
+    from pace_amd.dyn_core import AcousticDynamics, DycoreState
+    from pace_amd.halo import Layout
+
+    sf = StencilFactory(grids, cfg, get_constants(), backend=backend, dtype=dtype)
+    per_rank = [dict(s, phis=p) for s, p in zip(ost_init, phis)]
+    st = DycoreState.from_arrays(sf.quantity_factory, per_rank)
+    dyn = AcousticDynamics(Layout(part, 1, 0), grids, sf, config=cfg, phis=st.phis, state=st)
+    for n in range(n_calls):
+        dyn(st, timestep, n_map=n + 1)
+    if backend != "hostemu":
+        torch.cuda.synchronize()
+    return st.to_arrays(), dyn, st, sf
+
+
+def compare_cubes(got, want, part, nz, names, tol):
+    worst = {}
+    for r in range(part.total_ranks):
+        for name in names:
+            sl = compute_slice(name, part.nx, part.ny, nz)
+            a, b = got[r][name][sl], want[r][name][sl]
+            assert np.all(np.isfinite(a)), f"{name} rank {r}: non-finite"
+            sc = np.abs(b).max()
+            e = np.abs(a - b).max()
+            worst[name] = max(worst.get(name, 0.0), e / sc if sc > 0 else e)
+    bad = {k: v for k, v in worst.items() if v > tol.get(k, tol["default"])}
+    assert not bad, f"field-scale relative errors above tolerance: {bad} (all: {worst})"
+    return worst

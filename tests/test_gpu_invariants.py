@@ -1,0 +1,84 @@
+"""GPU-only checks at sizes the oracle cannot reach quickly: size-independent properties
+(global mass conservation, determinism / statelessness, no allocation at call time -- the
+reference's dycore-call invariants [REF tests/main/fv3core/test_dycore_call.py:149-211]) and
+the fp32 build against fp64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _harness(nx, layout=(1, 1), nz=79, dtype=torch.float64, **kw):
+    from pace_amd.harness import DycoreHarness
+
+    return DycoreHarness(nx, nz, layout, dt_atmos=225.0, k_split=kw.pop("k_split", 1), n_split=kw.pop("n_split", 2), backend="hip:gfx950", device="cuda:0", dtype=dtype, **kw)
+
+
+def _mass(h):
+    nx, nz = h.part.nx, h.cfg.npz
+    area = h.sf.grid_fields["area"].storage[:, 3 : 3 + nx, 3 : 3 + nx]
+    delp = h.state.delp.storage[:, :nz, 3 : 3 + nx, 3 : 3 + nx]
+    return float((delp * area[:, None]).sum(dtype=torch.float64))
+
+
+def test_c48_mass_conservation_finite_and_bounds(gpu_backend):
+    h = _harness(48)
+    m0 = _mass(h)
+    for _ in range(3):
+        h.step()
+    h.synchronize()
+    m1 = _mass(h)
+    assert abs(m1 - m0) / m0 < 1e-13
+    s = h.sanity()
+    assert all(v[2] for v in s.values()), s
+    assert -1 < s["delp"][0] and s["delp"][1] < 4000 and abs(s["u"][0]) < 200 and abs(s["u"][1]) < 200
+
+
+def test_c96_2x2_decomposition_identity_on_device(gpu_backend):
+    """24 sub-domains (layout 2x2) and 6 sub-domains (1x1) give the same fields."""
+    outs = []
+    for layout in ((1, 1), (2, 2)):
+        h = _harness(96, layout, nz=16, noise=0.0)
+        h.step()
+        h.synchronize()
+        nx = h.part.nx
+        G = torch.zeros((6, 96, 96, 16), dtype=torch.float64, device="cuda:0")
+        for i, r in enumerate(h.layout.local_ranks):
+            t = h.part.tile_index(r)
+            x0, y0 = h.part.origin(r)
+            G[t, x0 : x0 + nx, y0 : y0 + nx] = h.state.pt.sub(i).data[3 : 3 + nx, 3 : 3 + nx, :16]
+        outs.append(G)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_stateless_deterministic_and_no_allocation(gpu_backend):
+    h1, h2 = _harness(24, nz=20), _harness(24, nz=20)
+    h1.step()
+    h2.step()
+    h1.synchronize()
+    for n in ("delp", "pt", "u", "v", "w", "delz"):
+        assert torch.equal(getattr(h1.state, n).storage, getattr(h2.state, n).storage), n
+    # second call: no device allocation (scratch is owned by the context, buffers are cached)
+    before = torch.cuda.memory_allocated()
+    stats0 = torch.cuda.memory_stats()["allocation.all.allocated"]
+    h1.step()
+    h1.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] == stats0
+
+
+def test_fp32_build_tracks_fp64(gpu_backend):
+    """PACE_FLOAT_PRECISION=32 analogue: same step in fp32, stated tolerance 2e-4 field-relative
+    (pressure sums and exp/log chains run in fp32 -- SURVEY §7 hard part 9)."""
+    h64 = _harness(24, nz=20, noise=0.0)
+    h32 = _harness(24, nz=20, noise=0.0, dtype=torch.float32)
+    h64.step()
+    h32.step()
+    h64.synchronize()
+    for n, tol in (("delp", 2e-5), ("pt", 2e-5), ("u", 2e-4), ("v", 2e-4)):
+        a = getattr(h64.state, n).view[...][..., :20]
+        b = getattr(h32.state, n).view[...][..., :20].double()
+        assert torch.isfinite(b).all()
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err < tol, (n, err)

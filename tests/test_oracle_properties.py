@@ -1,0 +1,111 @@
+"""Oracle pinned by the properties the domain offers (the reference itself cannot run here):
+global mass conservation, bit-matching fluxes across every tile edge, decomposition identity,
+determinism, tracer constancy, and the committed golden vectors (regression pin of the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import compute_slice, oracle_cube
+from pace_amd.topology import STAGGER, build_interface_sync_map
+
+NAMES = ("delp", "pt", "u", "v", "w", "delz", "q_con")
+
+
+def _mass(states, grids, part, nz):
+    nx = part.nx
+    return sum((s["delp"][3 : 3 + nx, 3 : 3 + nx, :nz] * g.area[3 : 3 + nx, 3 : 3 + nx, None]).sum() for s, g in zip(states, grids))
+
+
+def test_mass_conservation_and_edge_flux_symmetry():
+    nz = 6
+    part, cfg, grids, st, phis, dyn = oracle_cube(12, (1, 1), nz, dict(n_split=2))
+    m0 = _mass(st, grids, part, nz)
+    dyn(st, 225.0, 1)
+    m1 = _mass(st, grids, part, nz)
+    assert abs(m1 - m0) / m0 < 2e-15
+    # the accumulated mass fluxes on shared tile edges agree between the two owners
+    ni = part.nx + 7
+    worst = 0.0
+    for r in range(6):
+        m = build_interface_sync_map(part, r, [STAGGER["cgrid_u"], STAGGER["cgrid_v"]], 3, ni)
+        comps = [[s["mfxd"] for s in st], [s["mfyd"] for s in st]]
+        di, dj, si, sj = m.dst_flat % ni, m.dst_flat // ni, m.src_flat % ni, m.src_flat // ni
+        for n in range(len(m)):
+            a = comps[m.dst_comp[n]][r][di[n], dj[n], :nz]
+            b = comps[m.src_comp[n]][m.src_rank[n]][si[n], sj[n], :nz] * m.sign[n]
+            worst = max(worst, np.abs(a - b).max() / np.abs(a).max())
+    assert worst < 1e-11, worst
+
+
+def test_decomposition_identity():
+    nz = 5
+    outs = []
+    for lay in (1, 2):
+        part, cfg, grids, st, phis, dyn = oracle_cube(12, (lay, lay), nz, dict(n_split=2), noise=0.0)
+        dyn(st, 225.0, 1)
+        glob = {}
+        for name in NAMES:
+            ex = 1 if name == "v" else 0
+            ey = 1 if name == "u" else 0
+            G = np.zeros((6, 13, 13, nz))
+            for r in range(part.total_ranks):
+                t = part.tile_index(r)
+                x0, y0 = part.origin(r)
+                G[t, x0 : x0 + part.nx + ex, y0 : y0 + part.ny + ey] = st[r][name][compute_slice(name, part.nx, part.ny, nz)]
+            glob[name] = G
+        outs.append(glob)
+    for name in NAMES:
+        assert np.array_equal(outs[0][name], outs[1][name]), name
+
+
+def test_determinism_and_statelessness():
+    """Two identical oracles agree and calling twice from the same input agrees
+    (the reference's dycore-call invariants [REF tests/main/fv3core/test_dycore_call.py:149-190])."""
+    nz = 4
+    res = []
+    for _ in range(2):
+        part, cfg, grids, st, phis, dyn = oracle_cube(12, (1, 1), nz)
+        dyn(st, 225.0, 1)
+        res.append(st)
+    for a, b in zip(*res):
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_tracer_constancy_through_fv_tp_2d():
+    from fv3_oracle import d_sw as od
+    from fv3_oracle import fvtp2d as of
+    from fv3_oracle.util import Dom
+    from pace_amd.constants import get_constants
+
+    nz = 3
+    part, cfg, grids, st, phis, dyn = oracle_cube(12, (1, 1), nz)
+    D = Dom(grids[0], get_constants())
+    s = st[0]
+    V = lambda a: a[:, :, :nz].copy()  # noqa: E731
+    uc, vc = V(s["v"]), V(s["u"])
+    z = lambda: np.zeros_like(uc)  # noqa: E731
+    crx, cry, xfx, yfx, ut, vt = z(), z(), z(), z(), z(), z()
+    ra_x, ra_y = od.fxadv(D, uc, vc, crx, cry, xfx, yfx, ut, vt, 20000.0)
+    q = np.ones_like(uc)
+    fx, fy = of.fv_tp_2d(D, q, crx, cry, xfx, yfx, ra_x, ra_y, 6)
+    R = D.sl(1, D.nx + 1, 1, D.ny)
+    assert np.allclose(fx[R], xfx[R], rtol=1e-14, atol=0)
+    R = D.sl(1, D.nx, 1, D.ny + 1)
+    assert np.allclose(fy[R], yfx[R], rtol=1e-14, atol=0)
+
+
+def test_golden_vectors():
+    """Regression pin: outputs of the oracle committed by tools/make_golden_oracle.py."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_c12_l6_step.npz")
+    gold = np.load(path)
+    nz = int(gold["nz"])
+    part, cfg, grids, st, phis, dyn = oracle_cube(12, (1, 1), nz, dict(n_split=2))
+    dyn(st, 225.0, 1)
+    for key in gold.files:
+        if key == "nz":
+            continue
+        name, r = key.rsplit("_r", 1)
+        got = st[int(r)][name][compute_slice(name, 12, 12, nz)]
+        assert np.allclose(got, gold[key], rtol=1e-12, atol=1e-12 * np.abs(gold[key]).max()), key
