@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-timing", action="store_true")
+    ap.add_argument("--k-split", type=int, default=None, help="override (profiling runs only; changes the workload)")
+    ap.add_argument("--n-split", type=int, default=None, help="override (profiling runs only; changes the workload)")
     a = ap.parse_args()
 
     from pace_amd.harness import CONFIGS, DycoreHarness
@@ -97,6 +99,10 @@ def main():
     kw = dict(CONFIGS[a.config])
     if a.nz:
         kw["nz"] = a.nz
+    if a.k_split:
+        kw["k_split"] = a.k_split
+    if a.n_split:
+        kw["n_split"] = a.n_split
     if (6 * kw["layout"][0] * kw["layout"][1]) % world:
         sys.exit(f"{a.config} has {6 * kw['layout'][0] * kw['layout'][1]} sub-domains: not divisible over {world} GPUs")
     dtype = torch.float64 if a.precision == 64 else torch.float32

@@ -49,6 +49,7 @@ struct Geo {
   int npx, npy;
   int ni, nj, nkA;  // allocation extents
   int o;            // nh - 1: Fortran-local index -> storage index offset
+  int sj32;         // j stride as 32-bit (in-plane offsets are computed in 32 bits: IX)
   long sj, sk, st;  // strides of 3-D fields: j, k, sub
   long st2;         // sub stride of 2-D fields
   unsigned char flags[FV3_MAX_SUB];
@@ -68,7 +69,7 @@ struct Geo {
 };
 
 // storage offset of Fortran-local (i, j) inside one k-plane
-#define IX(i, j) ((long)((j) + g.o) * g.sj + ((i) + g.o))
+#define IX(i, j) ((unsigned)(((j) + g.o) * g.sj32 + ((i) + g.o)))
 
 struct Box {
   int i0, i1, j0, j1, k0, k1;  // inclusive; i, j Fortran-local; k 0-based
@@ -190,13 +191,61 @@ inline void launch2(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// block-level launch for LDS-tiled kernels: f(blk, smem) runs once per workgroup with
+// blk.tid / blk.nthr / blk.bx,by,bz and a dynamic LDS buffer; phases are separated by blk.sync().
+// Work inside a phase is distributed as `for (w = blk.tid; w < n; w += blk.nthr)`, so the host
+// emulation (one "thread" per block, sync = no-op) executes exactly the same phases in order.
+// ---------------------------------------------------------------------------------------------
+struct Blk {
+  int tid, nthr, bx, by, bz;
+  FV3_HD inline void sync() const {
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+  }
+};
+
+#ifndef FV3_HOST_EMU
+template <class F>
+__global__ void __launch_bounds__(256, 2) fv3_kb(F f) {
+  extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
+  Blk b{(int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  f(b, fv3_smem);
+}
+#endif
+
+template <class F>
+inline void launch_blocks(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int gz, int nthr, size_t smem_bytes, F f) {
+  if (gx <= 0 || gy <= 0 || gz <= 0) return;
+#ifdef FV3_HOST_EMU
+  (void)c;
+  (void)s;
+  (void)nthr;
+#pragma omp parallel
+  {
+    std::vector<char> smem(smem_bytes + 16);
+#pragma omp for collapse(2) schedule(static)
+    for (int z = 0; z < gz; ++z)
+      for (int y = 0; y < gy; ++y)
+        for (int x = 0; x < gx; ++x) {
+          Blk b{0, 1, x, y, z};
+          f(b, smem.data());
+        }
+  }
+#else
+  (void)c;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kb<F>), dim3(gx, gy, gz), dim3(nthr, 1, 1), smem_bytes, s, f);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // cube-corner halo reads.  The reference fills the 3x3 corner block in place before every
 // directional sweep (copy_corners / fill_4corners / fill_corners); the fills are pure
 // functions of edge-halo cells, so here the *read* is redirected instead: no extra launch,
 // no in-place race.  DIR 1 = x sweep, 2 = y sweep.  [SURVEY A.13]
 // ---------------------------------------------------------------------------------------------
 template <int DIR>
-FV3_HD inline long cc_index(const Geo &g, int fl, int i, int j) {
+FV3_HD inline unsigned cc_index(const Geo &g, int fl, int i, int j) {
   // returns IX of the cell a copy_corners'ed read of cell (i, j) resolves to
   if ((i >= 1 && i <= g.nx) || (j >= 1 && j <= g.ny)) return IX(i, j);
   const int npx = g.npx, npy = g.npy;
@@ -223,7 +272,7 @@ FV3_HD inline Real cc(const Real *q, const Geo &g, int fl, int i, int j) {
 
 // fill_4corners read (c_sw, update_dz_c): only the two corner cells next to the edge exist
 template <int DIR>
-FV3_HD inline long f4_index(const Geo &g, int fl, int i, int j) {
+FV3_HD inline unsigned f4_index(const Geo &g, int fl, int i, int j) {
   if ((i >= 1 && i <= g.nx) || (j >= 1 && j <= g.ny)) return IX(i, j);
   const int npx = g.npx, npy = g.npy;
   if (i < 1 && j < 1 && (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S)) {
@@ -265,7 +314,7 @@ FV3_HD inline long f4_index(const Geo &g, int fl, int i, int j) {
 // fill_corners for a corner-staggered (B-grid) scalar: points (i, j) with both indices
 // strictly outside [1, npx] x [1, npy]
 template <int DIR>
-FV3_HD inline long bc_index(const Geo &g, int fl, int i, int j) {
+FV3_HD inline unsigned bc_index(const Geo &g, int fl, int i, int j) {
   const int npx = g.npx, npy = g.npy;
   if ((i >= 1 && i <= npx) || (j >= 1 && j <= npy)) return IX(i, j);
   if (i < 1 && j < 1) {

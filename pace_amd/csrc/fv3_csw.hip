@@ -86,9 +86,9 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
     const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
-    const long p = IX(i, j);
-    ua[b + p] = (ut_ - vt_ * g.cosa_s[m2 + p]) * g.rsin2[m2 + p];
-    va[b + p] = (vt_ - ut_ * g.cosa_s[m2 + p]) * g.rsin2[m2 + p];
+    const unsigned p = IX(i, j);
+    (ua + b)[p] = (ut_ - vt_ * (g.cosa_s + m2)[p]) * (g.rsin2 + m2)[p];
+    (va + b)[p] = (vt_ - ut_ * (g.cosa_s + m2)[p]) * (g.rsin2 + m2)[p];
   });
 
   // (B) C-grid winds + contravariant ut, vt (already scaled: dt2 * ut * dy * sin_sg)
@@ -130,7 +130,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       }
       return vaa[IX(ii, jj)];
     };
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     if (j <= g.ny + 1) {  // uc, ut on i = is-1..ie+2, j = js-1..je+1
       Real ucv = (Real)0, utv;
       bool edge = false;
@@ -148,15 +148,15 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
           ucv = CSW_C3 * d.utmp_x(npx, j) + CSW_C2 * d.utmp_x(npx + 1, j) + CSW_C1 * d.utmp_x(npx + 2, j);
       }
       if (edge && (i == 1 || i == npx)) {
-        utv = edge_interp4(UA(i - 2, j), UA(i - 1, j), UA(i, j), UA(i + 1, j), g.dxa[m2 + IX(i - 2, j)], g.dxa[m2 + IX(i - 1, j)], g.dxa[m2 + IX(i, j)],
-                           g.dxa[m2 + IX(i + 1, j)]);
-        ucv = utv > (Real)0 ? utv * g.sin_sg3[m2 + IX(i - 1, j)] : utv * g.sin_sg1[m2 + p];
+        utv = edge_interp4(UA(i - 2, j), UA(i - 1, j), UA(i, j), UA(i + 1, j), (g.dxa + m2)[IX(i - 2, j)], (g.dxa + m2)[IX(i - 1, j)], (g.dxa + m2)[IX(i, j)],
+                           (g.dxa + m2)[IX(i + 1, j)]);
+        ucv = utv > (Real)0 ? utv * (g.sin_sg3 + m2)[IX(i - 1, j)] : utv * (g.sin_sg1 + m2)[p];
       } else {
         if (!edge) ucv = CSW_A2 * (d.utmp_x(i - 2, j) + d.utmp_x(i + 1, j)) + CSW_A1 * (d.utmp_x(i - 1, j) + d.utmp_x(i, j));
-        utv = (ucv - v[b + p] * g.cosa_u[m2 + p]) * g.rsin_u[m2 + p];
+        utv = (ucv - (v + b)[p] * (g.cosa_u + m2)[p]) * (g.rsin_u + m2)[p];
       }
-      uc[b + p] = ucv;
-      ut[b + p] = utv > (Real)0 ? dt2 * utv * g.dy[m2 + p] * g.sin_sg3[m2 + IX(i - 1, j)] : dt2 * utv * g.dy[m2 + p] * g.sin_sg1[m2 + p];
+      (uc + b)[p] = ucv;
+      (ut + b)[p] = utv > (Real)0 ? dt2 * utv * (g.dy + m2)[p] * (g.sin_sg3 + m2)[IX(i - 1, j)] : dt2 * utv * (g.dy + m2)[p] * (g.sin_sg1 + m2)[p];
     }
     if (i <= g.nx + 1) {  // vc, vt on i = is-1..ie+1, j = js-1..je+2
       Real vcv = (Real)0, vtv;
@@ -175,15 +175,15 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
           vcv = CSW_C1 * d.vtmp_y(i, npy + 2) + CSW_C2 * d.vtmp_y(i, npy + 1) + CSW_C3 * d.vtmp_y(i, npy);
       }
       if (edge && (j == 1 || j == npy)) {
-        vtv = edge_interp4(VA(i, j - 2), VA(i, j - 1), VA(i, j), VA(i, j + 1), g.dya[m2 + IX(i, j - 2)], g.dya[m2 + IX(i, j - 1)], g.dya[m2 + IX(i, j)],
-                           g.dya[m2 + IX(i, j + 1)]);
-        vcv = vtv > (Real)0 ? vtv * g.sin_sg4[m2 + IX(i, j - 1)] : vtv * g.sin_sg2[m2 + p];
+        vtv = edge_interp4(VA(i, j - 2), VA(i, j - 1), VA(i, j), VA(i, j + 1), (g.dya + m2)[IX(i, j - 2)], (g.dya + m2)[IX(i, j - 1)], (g.dya + m2)[IX(i, j)],
+                           (g.dya + m2)[IX(i, j + 1)]);
+        vcv = vtv > (Real)0 ? vtv * (g.sin_sg4 + m2)[IX(i, j - 1)] : vtv * (g.sin_sg2 + m2)[p];
       } else {
         if (!edge) vcv = CSW_A2 * (d.vtmp_y(i, j - 2) + d.vtmp_y(i, j + 1)) + CSW_A1 * (d.vtmp_y(i, j - 1) + d.vtmp_y(i, j));
-        vtv = (vcv - u[b + p] * g.cosa_v[m2 + p]) * g.rsin_v[m2 + p];
+        vtv = (vcv - (u + b)[p] * (g.cosa_v + m2)[p]) * (g.rsin_v + m2)[p];
       }
-      vc[b + p] = vcv;
-      vt[b + p] = vtv > (Real)0 ? dt2 * vtv * g.dx[m2 + p] * g.sin_sg4[m2 + IX(i, j - 1)] : dt2 * vtv * g.dx[m2 + p] * g.sin_sg2[m2 + p];
+      (vc + b)[p] = vcv;
+      (vt + b)[p] = vtv > (Real)0 ? dt2 * vtv * (g.dx + m2)[p] * (g.sin_sg4 + m2)[IX(i, j - 1)] : dt2 * vtv * (g.dx + m2)[p] * (g.sin_sg2 + m2)[p];
     }
   });
 
@@ -222,23 +222,23 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
       const int npx = g.npx, npy = g.npy;
       auto UF = [&](int ii, int jj) -> Real {
-        const long q = IX(ii, jj), qm = IX(ii, jj - 1);
-        if ((S && jj == 1) || (N && jj == npy)) return u[b + q] * g.dyc[m2 + q] * (Real)0.5 * (g.sin_sg4[m2 + qm] + g.sin_sg2[m2 + q]);
-        return (u[b + q] - (Real)0.25 * (va[b + qm] + va[b + q]) * (g.cos_sg4[m2 + qm] + g.cos_sg2[m2 + q])) * g.dyc[m2 + q] * (Real)0.5 *
-               (g.sin_sg4[m2 + qm] + g.sin_sg2[m2 + q]);
+        const unsigned q = IX(ii, jj), qm = IX(ii, jj - 1);
+        if ((S && jj == 1) || (N && jj == npy)) return (u + b)[q] * (g.dyc + m2)[q] * (Real)0.5 * ((g.sin_sg4 + m2)[qm] + (g.sin_sg2 + m2)[q]);
+        return ((u + b)[q] - (Real)0.25 * ((va + b)[qm] + (va + b)[q]) * ((g.cos_sg4 + m2)[qm] + (g.cos_sg2 + m2)[q])) * (g.dyc + m2)[q] * (Real)0.5 *
+               ((g.sin_sg4 + m2)[qm] + (g.sin_sg2 + m2)[q]);
       };
       auto VF = [&](int ii, int jj) -> Real {
-        const long q = IX(ii, jj), qm = IX(ii - 1, jj);
-        if ((W && ii == 1) || (E && ii == npx)) return v[b + q] * g.dxc[m2 + q] * (Real)0.5 * (g.sin_sg3[m2 + qm] + g.sin_sg1[m2 + q]);
-        return (v[b + q] - (Real)0.25 * (ua[b + qm] + ua[b + q]) * (g.cos_sg3[m2 + qm] + g.cos_sg1[m2 + q])) * g.dxc[m2 + q] * (Real)0.5 *
-               (g.sin_sg3[m2 + qm] + g.sin_sg1[m2 + q]);
+        const unsigned q = IX(ii, jj), qm = IX(ii - 1, jj);
+        if ((W && ii == 1) || (E && ii == npx)) return (v + b)[q] * (g.dxc + m2)[q] * (Real)0.5 * ((g.sin_sg3 + m2)[qm] + (g.sin_sg1 + m2)[q]);
+        return ((v + b)[q] - (Real)0.25 * ((ua + b)[qm] + (ua + b)[q]) * ((g.cos_sg3 + m2)[qm] + (g.cos_sg1 + m2)[q])) * (g.dxc + m2)[q] * (Real)0.5 *
+               ((g.sin_sg3 + m2)[qm] + (g.sin_sg1 + m2)[q]);
       };
       Real dv = VF(i, j - 1) - VF(i, j) + UF(i - 1, j) - UF(i, j);
       if (W && S && i == 1 && j == 1) dv -= VF(1, 0);
       if (E && S && i == npx && j == 1) dv -= VF(npx, 0);
       if (E && N && i == npx && j == npy) dv += VF(npx, npy);
       if (W && N && i == 1 && j == npy) dv += VF(1, npy);
-      divgd[b + IX(i, j)] = g.rarea_c[m2 + IX(i, j)] * dv;
+      (divgd + b)[IX(i, j)] = (g.rarea_c + m2)[IX(i, j)] * dv;
     });
   }
 
@@ -248,57 +248,57 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     {
       // x fluxes at faces i and i+1 (fill_4corners x), y fluxes at j and j+1 (fill_4corners y)
       Real fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
       for (int a = 0; a < 2; ++a) {
         const int ii = i + a;
-        const Real utv = ut[b + IX(ii, j)];
+        const Real utv = (ut + b)[IX(ii, j)];
         const long src = utv > (Real)0 ? f4_index<1>(g, fl, ii - 1, j) : f4_index<1>(g, fl, ii, j);
-        fx1[a] = utv * delp[b + src];
-        fx[a] = fx1[a] * pt[b + src];
-        fx2[a] = fx1[a] * w[b + src];
+        fx1[a] = utv * (delp + b)[src];
+        fx[a] = fx1[a] * (pt + b)[src];
+        fx2[a] = fx1[a] * (w + b)[src];
         const int jj = j + a;
-        const Real vtv = vt[b + IX(i, jj)];
+        const Real vtv = (vt + b)[IX(i, jj)];
         const long srcy = vtv > (Real)0 ? f4_index<2>(g, fl, i, jj - 1) : f4_index<2>(g, fl, i, jj);
-        fy1[a] = vtv * delp[b + srcy];
-        fy[a] = fy1[a] * pt[b + srcy];
-        fy2[a] = fy1[a] * w[b + srcy];
+        fy1[a] = vtv * (delp + b)[srcy];
+        fy[a] = fy1[a] * (pt + b)[srcy];
+        fy2[a] = fy1[a] * (w + b)[srcy];
       }
-      const Real ra = g.rarea[m2 + p];
-      const Real dpc = delp[b + p] + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
-      delpc[b + p] = dpc;
-      ptc[b + p] = (pt[b + p] * delp[b + p] + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
-      omga[b + p] = (w[b + p] * delp[b + p] + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
+      const Real ra = (g.rarea + m2)[p];
+      const Real dpc = (delp + b)[p] + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
+      (delpc + b)[p] = dpc;
+      (ptc + b)[p] = ((pt + b)[p] * (delp + b)[p] + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
+      (omga + b)[p] = ((w + b)[p] * (delp + b)[p] + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
     }
     {
-      const Real uav = ua[b + p], vav = va[b + p];
-      Real kev = uav > (Real)0 ? uc[b + p] : uc[b + IX(i + 1, j)];
-      Real vov = vav > (Real)0 ? vc[b + p] : vc[b + IX(i, j + 1)];
+      const Real uav = (ua + b)[p], vav = (va + b)[p];
+      Real kev = uav > (Real)0 ? (uc + b)[p] : (uc + b)[IX(i + 1, j)];
+      Real vov = vav > (Real)0 ? (vc + b)[p] : (vc + b)[IX(i, j + 1)];
       if ((W && i == 1) || (E && i == npx)) {
-        if (uav > (Real)0) kev = uc[b + p] * g.sin_sg1[m2 + p] + v[b + p] * g.cos_sg1[m2 + p];
+        if (uav > (Real)0) kev = (uc + b)[p] * (g.sin_sg1 + m2)[p] + (v + b)[p] * (g.cos_sg1 + m2)[p];
       }
       if ((W && i == 0) || (E && i == npx - 1)) {
-        if (!(uav > (Real)0)) kev = uc[b + IX(i + 1, j)] * g.sin_sg3[m2 + p] + v[b + IX(i + 1, j)] * g.cos_sg3[m2 + p];
+        if (!(uav > (Real)0)) kev = (uc + b)[IX(i + 1, j)] * (g.sin_sg3 + m2)[p] + (v + b)[IX(i + 1, j)] * (g.cos_sg3 + m2)[p];
       }
       if ((S && j == 1) || (N && j == npy)) {
-        if (vav > (Real)0) vov = vc[b + p] * g.sin_sg2[m2 + p] + u[b + p] * g.cos_sg2[m2 + p];
+        if (vav > (Real)0) vov = (vc + b)[p] * (g.sin_sg2 + m2)[p] + (u + b)[p] * (g.cos_sg2 + m2)[p];
       }
       if ((S && j == 0) || (N && j == npy - 1)) {
-        if (!(vav > (Real)0)) vov = vc[b + IX(i, j + 1)] * g.sin_sg4[m2 + p] + u[b + IX(i, j + 1)] * g.cos_sg4[m2 + p];
+        if (!(vav > (Real)0)) vov = (vc + b)[IX(i, j + 1)] * (g.sin_sg4 + m2)[p] + (u + b)[IX(i, j + 1)] * (g.cos_sg4 + m2)[p];
       }
-      ke[b + p] = (Real)0.5 * dt2 * (uav * kev + vav * vov);
+      (ke + b)[p] = (Real)0.5 * dt2 * (uav * kev + vav * vov);
     }
     if (i >= 1 && j >= 1) {  // absolute vorticity on corners is..ie+1, js..je+1
-      auto FX = [&](int ii, int jj) { return uc[b + IX(ii, jj)] * g.dxc[m2 + IX(ii, jj)]; };
-      auto FY = [&](int ii, int jj) { return vc[b + IX(ii, jj)] * g.dyc[m2 + IX(ii, jj)]; };
+      auto FX = [&](int ii, int jj) { return (uc + b)[IX(ii, jj)] * (g.dxc + m2)[IX(ii, jj)]; };
+      auto FY = [&](int ii, int jj) { return (vc + b)[IX(ii, jj)] * (g.dyc + m2)[IX(ii, jj)]; };
       Real vo = FX(i, j - 1) - FX(i, j) - FY(i - 1, j) + FY(i, j);
       if (W && S && i == 1 && j == 1) vo += FY(0, 1);
       if (E && S && i == npx && j == 1) vo -= FY(npx, 1);
       if (E && N && i == npx && j == npy) vo -= FY(npx, npy);
       if (W && N && i == 1 && j == npy) vo += FY(0, npy);
-      vort[b + p] = g.fC[m2 + p] + g.rarea_c[m2 + p] * vo;
+      (vort + b)[p] = (g.fC + m2)[p] + (g.rarea_c + m2)[p] * vo;
     }
   });
 
@@ -308,18 +308,18 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     if (j <= g.ny) {
-      const Real ucv = uc[b + p];
-      Real fy1 = ((W && i == 1) || (E && i == npx)) ? dt2 * v[b + p] : dt2 * (v[b + p] - ucv * g.cosa_u[m2 + p]) / g.sina_u[m2 + p];
-      const Real fyv = fy1 > (Real)0 ? vort[b + p] : vort[b + IX(i, j + 1)];
-      uc[b + p] = ucv + fy1 * fyv + g.rdxc[m2 + p] * (ke[b + IX(i - 1, j)] - ke[b + p]);
+      const Real ucv = (uc + b)[p];
+      Real fy1 = ((W && i == 1) || (E && i == npx)) ? dt2 * (v + b)[p] : dt2 * ((v + b)[p] - ucv * (g.cosa_u + m2)[p]) / (g.sina_u + m2)[p];
+      const Real fyv = fy1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i, j + 1)];
+      (uc + b)[p] = ucv + fy1 * fyv + (g.rdxc + m2)[p] * ((ke + b)[IX(i - 1, j)] - (ke + b)[p]);
     }
     if (i <= g.nx) {
-      const Real vcv = vc[b + p];
-      Real fx1 = ((S && j == 1) || (N && j == npy)) ? dt2 * u[b + p] : dt2 * (u[b + p] - vcv * g.cosa_v[m2 + p]) / g.sina_v[m2 + p];
-      const Real fxv = fx1 > (Real)0 ? vort[b + p] : vort[b + IX(i + 1, j)];
-      vc[b + p] = vcv - fx1 * fxv + g.rdyc[m2 + p] * (ke[b + IX(i, j - 1)] - ke[b + p]);
+      const Real vcv = (vc + b)[p];
+      Real fx1 = ((S && j == 1) || (N && j == npy)) ? dt2 * (u + b)[p] : dt2 * ((u + b)[p] - vcv * (g.cosa_v + m2)[p]) / (g.sina_v + m2)[p];
+      const Real fxv = fx1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i + 1, j)];
+      (vc + b)[p] = vcv - fx1 * fxv + (g.rdyc + m2)[p] * ((ke + b)[IX(i, j - 1)] - (ke + b)[p]);
     }
   });
   return fv3_post(c, s, "c_sw");

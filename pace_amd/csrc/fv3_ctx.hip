@@ -183,6 +183,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   g.nkA = g.nz + 1;
   g.o = g.nh - 1;
   g.sj = g.ni;
+  g.sj32 = g.ni;
   g.sk = (long)g.ni * g.nj;
   g.st = g.sk * g.nkA;
   g.st2 = g.sk;
@@ -265,7 +266,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     g.corner_extrap = upload(c, ce);
   }
   // scratch: full-layout 3-D work fields shared by the operators (never allocated at call time)
-  const int n_scratch = 18;
+  const int n_scratch = 20;
   for (int s = 0; s < n_scratch; ++s) {
     Real *p = (Real *)fv3_dev_alloc(c, (size_t)g.st * g.nsub * sizeof(Real));
     if (!p) {

@@ -24,21 +24,21 @@ struct FxAdv {
   FV3_HD Real UC(int i, int j) const { return uc[IX(i, j)]; }
   FV3_HD Real VC(int i, int j) const { return vc[IX(i, j)]; }
   FV3_HD Real ut_gen(int i, int j) const {
-    return (UC(i, j) - (Real)0.25 * g.cosa_u[m2 + IX(i, j)] * (VC(i - 1, j) + VC(i, j) + VC(i - 1, j + 1) + VC(i, j + 1))) * g.rsin_u[m2 + IX(i, j)];
+    return (UC(i, j) - (Real)0.25 * (g.cosa_u + m2)[IX(i, j)] * (VC(i - 1, j) + VC(i, j) + VC(i - 1, j + 1) + VC(i, j + 1))) * (g.rsin_u + m2)[IX(i, j)];
   }
   FV3_HD Real vt_gen(int i, int j) const {
-    return (VC(i, j) - (Real)0.25 * g.cosa_v[m2 + IX(i, j)] * (UC(i, j - 1) + UC(i + 1, j - 1) + UC(i, j) + UC(i + 1, j))) * g.rsin_v[m2 + IX(i, j)];
+    return (VC(i, j) - (Real)0.25 * (g.cosa_v + m2)[IX(i, j)] * (UC(i, j - 1) + UC(i + 1, j - 1) + UC(i, j) + UC(i + 1, j))) * (g.rsin_v + m2)[IX(i, j)];
   }
   FV3_HD bool edge_col(int i) const { return (W && i == 1) || (E && i == g.npx); }
   FV3_HD bool edge_row(int j) const { return (S && j == 1) || (N && j == g.npy); }
   FV3_HD bool ut_special_row(int j) const { return (S && (j == 0 || j == 1)) || (N && (j == g.npy - 1 || j == g.npy)); }
   FV3_HD Real ut_edge(int i, int j) const {
     const Real u_ = UC(i, j);
-    return u_ * dt > (Real)0 ? u_ / g.sin_sg3[m2 + IX(i - 1, j)] : u_ / g.sin_sg1[m2 + IX(i, j)];
+    return u_ * dt > (Real)0 ? u_ / (g.sin_sg3 + m2)[IX(i - 1, j)] : u_ / (g.sin_sg1 + m2)[IX(i, j)];
   }
   FV3_HD Real vt_edge(int i, int j) const {
     const Real v_ = VC(i, j);
-    return v_ * dt > (Real)0 ? v_ / g.sin_sg4[m2 + IX(i, j - 1)] : v_ / g.sin_sg2[m2 + IX(i, j)];
+    return v_ * dt > (Real)0 ? v_ / (g.sin_sg4 + m2)[IX(i, j - 1)] : v_ / (g.sin_sg2 + m2)[IX(i, j)];
   }
   // stage-1 values (before the S/N row, W/E column and corner refinements)
   FV3_HD Real ut1(int i, int j) const {
@@ -59,7 +59,7 @@ struct FxAdv {
     if (edge_col(i)) return ut_edge(i, j);
     if (ut_special_row(j)) {
       if (in_i_rng(i))
-        return UC(i, j) - (Real)0.25 * g.cosa_u[m2 + IX(i, j)] * (vt1(i - 1, j) + vt1(i, j) + vt1(i - 1, j + 1) + vt1(i, j + 1));
+        return UC(i, j) - (Real)0.25 * (g.cosa_u + m2)[IX(i, j)] * (vt1(i - 1, j) + vt1(i, j) + vt1(i - 1, j + 1) + vt1(i, j + 1));
       return (Real)0;
     }
     return ut_gen(i, j);
@@ -67,7 +67,7 @@ struct FxAdv {
   FV3_HD Real vt2(int i, int j) const {
     if (edge_row(j)) return vt_edge(i, j);
     if (vt_edge_col(i) && in_j_rng(j))
-      return VC(i, j) - (Real)0.25 * g.cosa_v[m2 + IX(i, j)] * (ut1(i, j - 1) + ut1(i + 1, j - 1) + ut1(i, j) + ut1(i + 1, j));
+      return VC(i, j) - (Real)0.25 * (g.cosa_v + m2)[IX(i, j)] * (ut1(i, j - 1) + ut1(i + 1, j - 1) + ut1(i, j) + ut1(i + 1, j));
     return vt_gen(i, j);
   }
   // cube-corner coupled solves (oracle _corner_solve): the target's one unknown neighbour -- its
@@ -109,7 +109,7 @@ struct FxAdv {
     Real s_u = (Real)0;
     for (int n = 0; n < 4; ++n)
       if (!(pbi[n] == it && pbj[n] == j)) s_u = s_u + ut2(pbi[n], pbj[n]);
-    const Real cu = g.cosa_u[m2 + IX(it, j)], cv = g.cosa_v[m2 + IX(pi, pj)];
+    const Real cu = (g.cosa_u + m2)[IX(it, j)], cv = (g.cosa_v + m2)[IX(pi, pj)];
     const Real damp = (Real)1 / ((Real)1 - (Real)0.0625 * cu * cv);
     return (UC(it, j) - (Real)0.25 * cu * (s_v + VC(pi, pj) - (Real)0.25 * cv * s_u)) * damp;
   }
@@ -126,7 +126,7 @@ struct FxAdv {
     Real s_v = (Real)0;
     for (int n = 0; n < 4; ++n)
       if (!(pbi[n] == i && pbj[n] == jt)) s_v = s_v + vt2(pbi[n], pbj[n]);
-    const Real cv = g.cosa_v[m2 + IX(i, jt)], cu = g.cosa_u[m2 + IX(pi, pj)];
+    const Real cv = (g.cosa_v + m2)[IX(i, jt)], cu = (g.cosa_u + m2)[IX(pi, pj)];
     const Real damp = (Real)1 / ((Real)1 - (Real)0.0625 * cu * cv);
     return (VC(i, jt) - (Real)0.25 * cv * (s_u + UC(pi, pj) - (Real)0.25 * cu * s_v)) * damp;
   }
@@ -149,32 +149,32 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
     const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     FxAdv f{g, uc + b, vc + b, m2, dt, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     if (i >= 0) {  // ut on is-1..ie+3, jsd..jed
       const Real utv = f.ut_final(i, j);
-      ut[b + p] = utv;
+      (ut + b)[p] = utv;
       if (i >= 1 && i <= g.nx + 1) {
         const Real x = dt * utv;
         if (x > (Real)0) {
-          crx[b + p] = x * g.rdxa[m2 + IX(i - 1, j)];
-          xfx[b + p] = g.dy[m2 + p] * x * g.sin_sg3[m2 + IX(i - 1, j)];
+          (crx + b)[p] = x * (g.rdxa + m2)[IX(i - 1, j)];
+          (xfx + b)[p] = (g.dy + m2)[p] * x * (g.sin_sg3 + m2)[IX(i - 1, j)];
         } else {
-          crx[b + p] = x * g.rdxa[m2 + p];
-          xfx[b + p] = g.dy[m2 + p] * x * g.sin_sg1[m2 + p];
+          (crx + b)[p] = x * (g.rdxa + m2)[p];
+          (xfx + b)[p] = (g.dy + m2)[p] * x * (g.sin_sg1 + m2)[p];
         }
       }
     }
     if (j >= 0) {  // vt on isd..ied, js-1..je+3
       const Real vtv = f.vt_final(i, j);
-      vt[b + p] = vtv;
+      (vt + b)[p] = vtv;
       if (j >= 1 && j <= g.ny + 1) {
         const Real y = dt * vtv;
         if (y > (Real)0) {
-          cry[b + p] = y * g.rdya[m2 + IX(i, j - 1)];
-          yfx[b + p] = g.dx[m2 + p] * y * g.sin_sg4[m2 + IX(i, j - 1)];
+          (cry + b)[p] = y * (g.rdya + m2)[IX(i, j - 1)];
+          (yfx + b)[p] = (g.dx + m2)[p] * y * (g.sin_sg4 + m2)[IX(i, j - 1)];
         } else {
-          cry[b + p] = y * g.rdya[m2 + p];
-          yfx[b + p] = g.dx[m2 + p] * y * g.sin_sg2[m2 + p];
+          (cry + b)[p] = y * (g.rdya + m2)[p];
+          (yfx + b)[p] = (g.dx + m2)[p] * y * (g.sin_sg2 + m2)[p];
         }
       }
     }
@@ -289,22 +289,22 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     del6_vt_flux(c, s, w, c->scratch[SC_DN_D2], fx2, fy2, dn_w, false, 0, nz1);
     launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
-      const long p = IX(i, j);
+      const unsigned p = IX(i, j);
       Real hs = (Real)0, dwv = (Real)0;
       if (g.damp_w[k] > (Real)1.0e-5) {
         const Real dd8 = g.ke_bg[k] * fabs(dt);
-        dwv = (fx2[b + p] - fx2[b + IX(i + 1, j)] + fy2[b + p] - fy2[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-        hs = dd8 - dwv * (w[b + p] + (Real)0.5 * dwv);
+        dwv = ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+        hs = dd8 - dwv * ((w + b)[p] + (Real)0.5 * dwv);
       }
-      dw[b + p] = dwv;
-      heat_s[b + p] = hs;
+      (dw + b)[p] = dwv;
+      (heat_s + b)[p] = hs;
     });
   }
   tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1);
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk;
-    const long p = IX(i, j);
-    w[b + p] = delp[b + p] * w[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+    const unsigned p = IX(i, j);
+    (w + b)[p] = (delp + b)[p] * (w + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
   });
 
   // ---- condensate
@@ -314,24 +314,24 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk;
-    const long p = IX(i, j);
-    q_con[b + p] = delp[b + p] * q_con[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+    const unsigned p = IX(i, j);
+    (q_con + b)[p] = (delp + b)[p] * (q_con + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
   });
 
   // ---- potential temperature, then the delp update and the divisions
   tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1);
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     const Real ra = g.rarea[t * g.st2 + p];
-    const Real ptn = pt[b + p] * delp[b + p] + (gx[b + p] - gx[b + IX(i + 1, j)] + gy[b + p] - gy[b + IX(i, j + 1)]) * ra;
-    const Real dpn = delp[b + p] + (fx[b + p] - fx[b + IX(i + 1, j)] + fy[b + p] - fy[b + IX(i, j + 1)]) * ra;
-    delp[b + p] = dpn;
-    pt[b + p] = ptn / dpn;
-    Real wn = w[b + p] / dpn;
-    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + dw[b + p];
-    w[b + p] = wn;
-    q_con[b + p] = q_con[b + p] / dpn;
+    const Real ptn = (pt + b)[p] * (delp + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * ra;
+    const Real dpn = (delp + b)[p] + ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * ra;
+    (delp + b)[p] = dpn;
+    (pt + b)[p] = ptn / dpn;
+    Real wn = (w + b)[p] / dpn;
+    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + (dw + b)[p];
+    (w + b)[p] = wn;
+    (q_con + b)[p] = (q_con + b)[p] / dpn;
   });
 
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u) and cell-mean relative vorticity
@@ -340,12 +340,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     {
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
-      const Real a = u[b + p] * g.dx[m2 + p], a1 = u[b + IX(i, j + 1)] * g.dx[m2 + IX(i, j + 1)];
-      const Real e = v[b + p] * g.dy[m2 + p], e1 = v[b + IX(i + 1, j)] * g.dy[m2 + IX(i + 1, j)];
-      wk[b + p] = g.rarea[m2 + p] * (a - a1 - e + e1);
+      const Real a = (u + b)[p] * (g.dx + m2)[p], a1 = (u + b)[IX(i, j + 1)] * (g.dx + m2)[IX(i, j + 1)];
+      const Real e = (v + b)[p] * (g.dy + m2)[p], e1 = (v + b)[IX(i + 1, j)] * (g.dy + m2)[IX(i + 1, j)];
+      (wk + b)[p] = (g.rarea + m2)[p] * (a - a1 - e + e1);
     }
     if (i < 1 || i > g.nx + 1 || j < 1 || j > g.ny + 1) return;
     const Real dt5 = (Real)0.5 * dt, dt4 = (Real)0.25 * dt;
@@ -373,34 +373,34 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       else if (cW || cE)
         vbv = dt4 * (-vtl[IX(i - 2, j)] + (Real)3.0 * (vtl[IX(i - 1, j)] + vtl[p]) - vtl[IX(i + 1, j)]);
       else
-        vbv = dt5 * (vcl[IX(i - 1, j)] + vcl[p] - (ucl[IX(i, j - 1)] + ucl[p]) * g.cosa[m2 + p]) * g.rsina[m2 + p];
+        vbv = dt5 * (vcl[IX(i - 1, j)] + vcl[p] - (ucl[IX(i, j - 1)] + ucl[p]) * (g.cosa + m2)[p]) * (g.rsina + m2)[p];
       if (cW || cE)
         ubv = dt5 * (utl[IX(i, j - 1)] + utl[p]);
       else if (cS || cN)
         ubv = dt4 * (-utl[IX(i, j - 2)] + (Real)3.0 * (utl[IX(i, j - 1)] + utl[p]) - utl[IX(i, j + 1)]);
       else
-        ubv = dt5 * (ucl[IX(i, j - 1)] + ucl[p] - (vcl[IX(i - 1, j)] + vcl[p]) * g.cosa[m2 + p]) * g.rsina[m2 + p];
+        ubv = dt5 * (ucl[IX(i, j - 1)] + ucl[p] - (vcl[IX(i - 1, j)] + vcl[p]) * (g.cosa + m2)[p]) * (g.rsina + m2)[p];
       // ytp_v: advect v along y with vb ; xtp_u: advect u along x with ub
       Real vflux, uflux;
       {
         auto Q = [&](int s_) { return vl[IX(i, s_)]; };
-        auto M = [&](int s_) { return g.dy[m2 + IX(i, s_)]; };
+        auto M = [&](int s_) { return (g.dy + m2)[IX(i, s_)]; };
         const bool zc = (W && i == 1) || (E && i == npx);  // tile corner columns of v
         const bool zm = zc && ((S && (j - 1 == 0 || j - 1 == 1)) || (N && (j - 1 == npy - 1 || j - 1 == npy)));
         const bool z0 = zc && ((S && (j == 0 || j == 1)) || (N && (j == npy - 1 || j == npy)));
-        vflux = ppm_flux(Q, M, vbv, j, S, N, npy, cf.hord_mt, zm, z0, g.rdy[m2 + IX(i, j - 1)], g.rdy[m2 + p]);
+        vflux = ppm_flux(Q, M, vbv, j, S, N, npy, cf.hord_mt, zm, z0, (g.rdy + m2)[IX(i, j - 1)], (g.rdy + m2)[p]);
       }
       {
         auto Q = [&](int s_) { return ul[IX(s_, j)]; };
-        auto M = [&](int s_) { return g.dx[m2 + IX(s_, j)]; };
+        auto M = [&](int s_) { return (g.dx + m2)[IX(s_, j)]; };
         const bool zr = (S && j == 1) || (N && j == npy);
         const bool zm = zr && ((W && (i - 1 == 0 || i - 1 == 1)) || (E && (i - 1 == npx - 1 || i - 1 == npx)));
         const bool z0 = zr && ((W && (i == 0 || i == 1)) || (E && (i == npx - 1 || i == npx)));
-        uflux = ppm_flux(Q, M, ubv, i, W, E, npx, cf.hord_mt, zm, z0, g.rdx[m2 + IX(i - 1, j)], g.rdx[m2 + p]);
+        uflux = ppm_flux(Q, M, ubv, i, W, E, npx, cf.hord_mt, zm, z0, (g.rdx + m2)[IX(i - 1, j)], (g.rdx + m2)[p]);
       }
       kev = (Real)0.5 * (vbv * vflux + ubv * uflux);
     }
-    ke[b + p] = kev;
+    (ke + b)[p] = kev;
   });
 
   // ---- divergence damping.  delpc: un-iterated divergence; divgd iterated in place; uc / vc are
@@ -412,34 +412,34 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     if (g.nord[k] != 0) {
-      delpc[b + p] = divgd[b + p];
+      (delpc + b)[p] = (divgd + b)[p];
       return;
     }
     auto PTC = [&](int ii, int jj) -> Real {
-      const long q = IX(ii, jj), qm = IX(ii, jj - 1);
+      const unsigned q = IX(ii, jj), qm = IX(ii, jj - 1);
       if ((S && jj == 1) || (N && jj == npy))
-        return vc[b + q] * dt > (Real)0 ? u[b + q] * g.dyc[m2 + q] * g.sin_sg4[m2 + qm] : u[b + q] * g.dyc[m2 + q] * g.sin_sg2[m2 + q];
-      return (u[b + q] - (Real)0.5 * (va[b + qm] + va[b + q]) * g.cosa_v[m2 + q]) * g.dyc[m2 + q] * g.sina_v[m2 + q];
+        return (vc + b)[q] * dt > (Real)0 ? (u + b)[q] * (g.dyc + m2)[q] * (g.sin_sg4 + m2)[qm] : (u + b)[q] * (g.dyc + m2)[q] * (g.sin_sg2 + m2)[q];
+      return ((u + b)[q] - (Real)0.5 * ((va + b)[qm] + (va + b)[q]) * (g.cosa_v + m2)[q]) * (g.dyc + m2)[q] * (g.sina_v + m2)[q];
     };
     auto VRT = [&](int ii, int jj) -> Real {
-      const long q = IX(ii, jj), qm = IX(ii - 1, jj);
+      const unsigned q = IX(ii, jj), qm = IX(ii - 1, jj);
       if ((W && ii == 1) || (E && ii == npx))
-        return uc[b + q] * dt > (Real)0 ? v[b + q] * g.dxc[m2 + q] * g.sin_sg3[m2 + qm] : v[b + q] * g.dxc[m2 + q] * g.sin_sg1[m2 + q];
-      return (v[b + q] - (Real)0.5 * (ua[b + qm] + ua[b + q]) * g.cosa_u[m2 + q]) * g.dxc[m2 + q] * g.sina_u[m2 + q];
+        return (uc + b)[q] * dt > (Real)0 ? (v + b)[q] * (g.dxc + m2)[q] * (g.sin_sg3 + m2)[qm] : (v + b)[q] * (g.dxc + m2)[q] * (g.sin_sg1 + m2)[q];
+      return ((v + b)[q] - (Real)0.5 * ((ua + b)[qm] + (ua + b)[q]) * (g.cosa_u + m2)[q]) * (g.dxc + m2)[q] * (g.sina_u + m2)[q];
     };
     Real d = VRT(i, j - 1) - VRT(i, j) + PTC(i - 1, j) - PTC(i, j);
     if (W && S && i == 1 && j == 1) d -= VRT(1, 0);
     if (E && S && i == npx && j == 1) d -= VRT(npx, 0);
     if (E && N && i == npx && j == npy) d += VRT(npx, npy);
     if (W && N && i == 1 && j == npy) d += VRT(1, npy);
-    d = g.rarea_c[m2 + p] * d;
-    delpc[b + p] = d;
+    d = (g.rarea_c + m2)[p] * d;
+    (delpc + b)[p] = d;
     const Real damp = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * fabs(d * dt)));
     const Real vd = damp * d;
-    vdamp[b + p] = vd;
-    ke[b + p] += vd;
+    (vdamp + b)[p] = vd;
+    (ke + b)[p] += vd;
   });
   for (int n = 1; n <= nord_max; ++n) {
     const int ntm = nord_max - n;
@@ -455,12 +455,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       if (i >= 1 - 1 - nt && i <= g.nx + 1 + nt && j >= 1 - nt && j <= g.ny + 1 + nt) {
         const Real a = fill ? dg[bc_index<1>(g, fl, i + 1, j)] : dg[IX(i + 1, j)];
         const Real e = fill ? dg[bc_index<1>(g, fl, i, j)] : dg[IX(i, j)];
-        vc[b + IX(i, j)] = (a - e) * g.divg_u[m2 + IX(i, j)];
+        (vc + b)[IX(i, j)] = (a - e) * (g.divg_u + m2)[IX(i, j)];
       }
       if (i >= 1 - nt && i <= g.nx + 1 + nt && j >= 1 - 1 - nt && j <= g.ny + 1 + nt) {
         const Real a = fill ? dg[bc_index<2>(g, fl, i, j + 1)] : dg[IX(i, j + 1)];
         const Real e = fill ? dg[bc_index<2>(g, fl, i, j)] : dg[IX(i, j)];
-        uc[b + IX(i, j)] = (a - e) * g.divg_v[m2 + IX(i, j)];
+        (uc + b)[IX(i, j)] = (a - e) * (g.divg_v + m2)[IX(i, j)];
       }
     });
     launch3(c, s, Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -481,7 +481,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       if (E && S && i == npx && j == 1) d -= UCR(npx, 0);
       if (E && N && i == npx && j == npy) d += UCR(npx, npy);
       if (W && N && i == 1 && j == npy) d += UCR(1, npy);
-      divgd[b + IX(i, j)] = d * g.rarea_c[m2 + IX(i, j)];
+      (divgd + b)[IX(i, j)] = d * (g.rarea_c + m2)[IX(i, j)];
     });
   }
   // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
@@ -491,28 +491,28 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     const int nord = g.nord[k];
     if (nord == 0) return;
     const long b = t * g.st + k * g.sk;
-    const long p = IX(i, j);
-    const Real dpc = delpc[b + p];
+    const unsigned p = IX(i, j);
+    const Real dpc = (delpc + b)[p];
     Real vo = (Real)0;
-    if ((Real)cf.dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkb[b + p] * wkb[b + p]);
+    if ((Real)cf.dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + (wkb + b)[p] * (wkb + b)[p]);
     const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * vo));
-    const Real vd = damp2 * dpc + tab.dd8[k] * divgd[b + p];
-    vdamp[b + p] = vd;
-    ke[b + p] += vd;
+    const Real vd = damp2 * dpc + tab.dd8[k] * (divgd + b)[p];
+    (vdamp + b)[p] = vd;
+    (ke + b)[p] += vd;
   });
 
   // ---- vorticity transport: absolute vorticity, fluxes, wind update
   Real *vabs = c->scratch[SC_DN_FY];
   launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     vabs[t * g.st + k * g.sk + p] = wk[t * g.st + k * g.sk + p] + g.f0[t * g.st2 + p];
   });
   tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1);
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const long p = IX(i, j);
-    if (i <= g.nx) u[b + p] = u[b + p] * g.dx[m2 + p] + ke[b + p] - ke[b + IX(i + 1, j)] + fy[b + p];
-    if (j <= g.ny) v[b + p] = v[b + p] * g.dy[m2 + p] + ke[b + p] - ke[b + IX(i, j + 1)] - fx[b + p];
+    const unsigned p = IX(i, j);
+    if (i <= g.nx) (u + b)[p] = (u + b)[p] * (g.dx + m2)[p] + (ke + b)[p] - (ke + b)[IX(i + 1, j)] + (fy + b)[p];
+    if (j <= g.ny) (v + b)[p] = (v + b)[p] * (g.dy + m2)[p] + (ke + b)[p] - (ke + b)[IX(i, j + 1)] - (fx + b)[p];
   });
 
   // ---- del-n damping of the relative vorticity, heat from the damped kinetic energy
@@ -524,32 +524,32 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   const bool heat_on = cf.d_con > 1.0e-5;
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const long p = IX(i, j);
-    Real hs = heat_s[b + p];
+    const unsigned p = IX(i, j);
+    Real hs = (heat_s + b)[p];
     const Real dcon = g.d_con[k];
     if (dcon > (Real)1.0e-5) {
       const bool dv = g.damp_vt[k] > (Real)1.0e-5;
       // ub on (i, j), (i, j+1): (vort - vort[i+1] + vt) * rdx ; vb on (i, j), (i+1, j): (vort - vort[j+1] - ut) * rdy
       auto UB = [&](int ii, int jj) {
-        const long q = IX(ii, jj);
-        const Real d0 = vdamp[b + q] - vdamp[b + IX(ii + 1, jj)];
-        return (d0 + (dv ? vtd[b + q] : u[b + q] * (Real)0)) * g.rdx[m2 + q];
+        const unsigned q = IX(ii, jj);
+        const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii + 1, jj)];
+        return (d0 + (dv ? (vtd + b)[q] : (u + b)[q] * (Real)0)) * (g.rdx + m2)[q];
       };
       auto VB = [&](int ii, int jj) {
-        const long q = IX(ii, jj);
-        const Real d0 = vdamp[b + q] - vdamp[b + IX(ii, jj + 1)];
-        return (d0 - (dv ? utd[b + q] : v[b + q] * (Real)0)) * g.rdy[m2 + q];
+        const unsigned q = IX(ii, jj);
+        const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii, jj + 1)];
+        return (d0 - (dv ? (utd + b)[q] : (v + b)[q] * (Real)0)) * (g.rdy + m2)[q];
       };
       const Real ub0 = UB(i, j), ub1 = UB(i, j + 1), vb0 = VB(i, j), vb1 = VB(i + 1, j);
-      const Real fy0 = u[b + p] * g.rdx[m2 + p], fy1 = u[b + IX(i, j + 1)] * g.rdx[m2 + IX(i, j + 1)];
-      const Real fx0 = v[b + p] * g.rdy[m2 + p], fx1 = v[b + IX(i + 1, j)] * g.rdy[m2 + IX(i + 1, j)];
+      const Real fy0 = (u + b)[p] * (g.rdx + m2)[p], fy1 = (u + b)[IX(i, j + 1)] * (g.rdx + m2)[IX(i, j + 1)];
+      const Real fx0 = (v + b)[p] * (g.rdy + m2)[p], fx1 = (v + b)[IX(i + 1, j)] * (g.rdy + m2)[IX(i + 1, j)];
       const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
       const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
-      hs = delp[b + p] * (hs - (Real)0.25 * dcon * g.rsin2[m2 + p] *
+      hs = (delp + b)[p] * (hs - (Real)0.25 * dcon * (g.rsin2 + m2)[p] *
                                    ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) -
-                                    g.cosa_s[m2 + p] * (u2 * dv2 + v2 * du2 + du2 * dv2)));
+                                    (g.cosa_s + m2)[p] * (u2 * dv2 + v2 * du2 + du2 * dv2)));
     }
-    if (heat_on) heat_source[b + p] += hs;
+    if (heat_on) (heat_source + b)[p] += hs;
   });
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     if (!(g.damp_vt[k] > (Real)1.0e-5)) return;

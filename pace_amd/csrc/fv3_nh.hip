@@ -7,7 +7,8 @@
 // registers (tridiagonal gam / pp / w) live in context scratch fields with the same layout.
 #include "fv3_ops.h"
 
-#define K_(arr, k) (arr)[p + (long)(k)*g.sk]
+// column access: uniform (sub-domain, level) base + 32-bit in-plane offset
+#define K_(arr, k) ((arr) + tb + (long)(k)*g.sk)[pix]
 
 namespace {
 
@@ -17,7 +18,7 @@ namespace {
 struct Sim1 {
   Geo g;
   Real rgas, rgrav, p_fac, ptop;
-  FV3_HD void run(long p, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *w1, Real ws, Real *PM, Real *DZ, Real *W2, Real *PP,
+  FV3_HD void run(long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *w1, Real ws, Real *PM, Real *DZ, Real *W2, Real *PP,
                   Real *GAM, Real *PE) const {
     const int nz = g.nz;
     const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
@@ -126,12 +127,13 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
     const int fl = g.flags[t];
     const long bt = t * g.st, b = bt + k * g.sk, m2 = t * g.st2;
-    auto XI = [&](const Real *f, int ii, int jj) -> Real {
-      const long q = bt + IX(ii, jj);
-      if (k == 0) return f[q] + (f[q] - f[q + g.sk]) * top_ratio;
-      if (k == nz) return f[q + (nz - 1) * g.sk] + (f[q + (nz - 1) * g.sk] - f[q + (nz - 2) * g.sk]) * bot_ratio;
+    auto XI = [&](const Real *f0, int ii, int jj) -> Real {
+      const unsigned q = IX(ii, jj);
+      const Real *f = f0 + bt;
+      if (k == 0) return f[q] + (f[q] - (f + g.sk)[q]) * top_ratio;
+      if (k == nz) return (f + (nz - 1) * g.sk)[q] + ((f + (nz - 1) * g.sk)[q] - (f + (nz - 2) * g.sk)[q]) * bot_ratio;
       const Real int_ratio = (Real)1.0 / (g.dp_ref[k - 1] + g.dp_ref[k]);
-      return (g.dp_ref[k] * f[q + (k - 1) * g.sk] + g.dp_ref[k - 1] * f[q + k * g.sk]) * int_ratio;
+      return (g.dp_ref[k] * (f + (k - 1) * g.sk)[q] + g.dp_ref[k - 1] * (f + k * g.sk)[q]) * int_ratio;
     };
     const Real *gg = gz + b;
     const Real x0 = XI(ut, i, j), x1 = XI(ut, i + 1, j), y0 = XI(vt, i, j), y1 = XI(vt, i, j + 1);
@@ -139,12 +141,15 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, const fv3_field *zs_, const fv3_field
     const Real fx1 = x1 * (x1 > (Real)0 ? gg[f4_index<1>(g, fl, i, j)] : gg[f4_index<1>(g, fl, i + 1, j)]);
     const Real fy0 = y0 * (y0 > (Real)0 ? gg[f4_index<2>(g, fl, i, j - 1)] : gg[f4_index<2>(g, fl, i, j)]);
     const Real fy1 = y1 * (y1 > (Real)0 ? gg[f4_index<2>(g, fl, i, j)] : gg[f4_index<2>(g, fl, i, j + 1)]);
-    const long p = IX(i, j);
-    const Real ar = g.area[m2 + p];
-    gzn[b + p] = (gg[p] * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+    const unsigned p = IX(i, j);
+    const Real ar = (g.area + m2)[p];
+    (gzn + b)[p] = (gg[p] * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
   });
   launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     Real below = gzn[p + (long)nz * g.sk];
     gz[p + (long)nz * g.sk] = below;
     ws[t * g.st2 + IX(i, j)] = (zs[t * g.st2 + IX(i, j)] - below) / dt;
@@ -171,7 +176,10 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
   Real *PM = c->scratch[SC_A], *DZ = c->scratch[SC_B], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
   const int nz = g.nz;
   launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     // setup: layer-mean pressure without condensate, thickness
     Real peg = ptop;
     for (int k = 0; k < nz; ++k) {
@@ -181,7 +189,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
       K_(DZ, k) = K_(gz, k + 1) - K_(gz, k);
       peg = peg_n;
     }
-    sim.run(p, dt2, delpc, cappa, ptc, w3, ws[t * g.st2 + IX(i, j)], PM, DZ, W2, PP, GAM, pef);
+    sim.run(tb, pix, dt2, delpc, cappa, ptc, w3, ws[t * g.st2 + IX(i, j)], PM, DZ, W2, PP, GAM, pef);
     // full interface pressure and geopotential
     Real pem = ptop;
     K_(pef, 0) = ptop;
@@ -216,7 +224,10 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
   const int nz = g.nz;
   const bool last = last_call != 0;
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     Real pem = ptop, peg = ptop;
     Real peln_k = log(pem), pelng_k = log(peg);
     K_(pk3, 0) = exp(akap * peln_k);
@@ -243,7 +254,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
       pelng_k = pelng_n;
     }
     (void)peln_k;
-    sim.run(p, dt, delp, cappa, pt, w, wsd[t * g.st2 + IX(i, j)], PM, delz, W2, PP, GAM, ppe);
+    sim.run(tb, pix, dt, delp, cappa, pt, w, wsd[t * g.st2 + IX(i, j)], PM, delz, W2, PP, GAM, ppe);
     Real z = zs[t * g.st2 + IX(i, j)];
     K_(zh, nz) = z;
     for (int k = nz - 1; k >= 0; --k) {
@@ -264,16 +275,16 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, const fv3_field *uc_, const fv3_field *v
   const Real dt2 = (Real)dt2d;
   launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
-    const long p = IX(i, j);
+    const unsigned p = IX(i, j);
     if (j <= g.ny) {
-      const long pm = IX(i - 1, j);
-      uc[b + p] = uc[b + p] + dt2 * g.rdxc[m2 + p] / (delpc[b + pm] + delpc[b + p]) *
-                                  ((gz[b1 + pm] - gz[b + p]) * (pkc[b1 + p] - pkc[b + pm]) + (gz[b + pm] - gz[b1 + p]) * (pkc[b1 + pm] - pkc[b + p]));
+      const unsigned pm = IX(i - 1, j);
+      (uc + b)[p] = (uc + b)[p] + dt2 * (g.rdxc + m2)[p] / ((delpc + b)[pm] + (delpc + b)[p]) *
+                                  (((gz + b1)[pm] - (gz + b)[p]) * ((pkc + b1)[p] - (pkc + b)[pm]) + ((gz + b)[pm] - (gz + b1)[p]) * ((pkc + b1)[pm] - (pkc + b)[p]));
     }
     if (i <= g.nx) {
-      const long pm = IX(i, j - 1);
-      vc[b + p] = vc[b + p] + dt2 * g.rdyc[m2 + p] / (delpc[b + pm] + delpc[b + p]) *
-                                  ((gz[b1 + pm] - gz[b + p]) * (pkc[b1 + p] - pkc[b + pm]) + (gz[b + pm] - gz[b1 + p]) * (pkc[b1 + pm] - pkc[b + p]));
+      const unsigned pm = IX(i, j - 1);
+      (vc + b)[p] = (vc + b)[p] + dt2 * (g.rdyc + m2)[p] / ((delpc + b)[pm] + (delpc + b)[p]) *
+                                  (((gz + b1)[pm] - (gz + b)[p]) * ((pkc + b1)[p] - (pkc + b)[pm]) + ((gz + b)[pm] - (gz + b1)[p]) * ((pkc + b1)[pm] - (pkc + b)[p]));
     }
   });
   return fv3_post(c, (fv3_stream_t)stream, "p_grad_c");
@@ -289,7 +300,10 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v
   const Real top = (Real)std::pow(ptop, akap);
   const int nz = g.nz;
   launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     pp[p] = (Real)0;
     pk3[p] = top;
   });
@@ -300,25 +314,25 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v
   a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
-    const long p = IX(i, j);
-    auto WK = [&](long q) { return pk3[b1 + q] - pk3[b + q]; };
+    const unsigned p = IX(i, j);
+    auto WK = [&](unsigned q) { return (pk3 + b1)[q] - (pk3 + b)[q]; };
     if (i <= g.nx) {
-      const long pe_ = IX(i + 1, j);
+      const unsigned pe_ = IX(i + 1, j);
       const Real du = dt / (WK(p) + WK(pe_)) *
-                      ((gz[b1 + p] - gz[b + pe_]) * (pk3[b1 + pe_] - pk3[b + p]) + (gz[b + p] - gz[b1 + pe_]) * (pk3[b1 + p] - pk3[b + pe_]));
-      u[b + p] = (u[b + p] + du +
-                  dt / (wk1[b + p] + wk1[b + pe_]) *
-                      ((gz[b1 + p] - gz[b + pe_]) * (pp[b1 + pe_] - pp[b + p]) + (gz[b + p] - gz[b1 + pe_]) * (pp[b1 + p] - pp[b + pe_]))) *
-                 g.rdx[m2 + p];
+                      (((gz + b1)[p] - (gz + b)[pe_]) * ((pk3 + b1)[pe_] - (pk3 + b)[p]) + ((gz + b)[p] - (gz + b1)[pe_]) * ((pk3 + b1)[p] - (pk3 + b)[pe_]));
+      (u + b)[p] = ((u + b)[p] + du +
+                  dt / ((wk1 + b)[p] + (wk1 + b)[pe_]) *
+                      (((gz + b1)[p] - (gz + b)[pe_]) * ((pp + b1)[pe_] - (pp + b)[p]) + ((gz + b)[p] - (gz + b1)[pe_]) * ((pp + b1)[p] - (pp + b)[pe_]))) *
+                 (g.rdx + m2)[p];
     }
     if (j <= g.ny) {
-      const long pn = IX(i, j + 1);
+      const unsigned pn = IX(i, j + 1);
       const Real dv = dt / (WK(p) + WK(pn)) *
-                      ((gz[b1 + p] - gz[b + pn]) * (pk3[b1 + pn] - pk3[b + p]) + (gz[b + p] - gz[b1 + pn]) * (pk3[b1 + p] - pk3[b + pn]));
-      v[b + p] = (v[b + p] + dv +
-                  dt / (wk1[b + p] + wk1[b + pn]) *
-                      ((gz[b1 + p] - gz[b + pn]) * (pp[b1 + pn] - pp[b + p]) + (gz[b + p] - gz[b1 + pn]) * (pp[b1 + p] - pp[b + pn]))) *
-                 g.rdy[m2 + p];
+                      (((gz + b1)[p] - (gz + b)[pn]) * ((pk3 + b1)[pn] - (pk3 + b)[p]) + ((gz + b)[p] - (gz + b1)[pn]) * ((pk3 + b1)[p] - (pk3 + b)[pn]));
+      (v + b)[p] = ((v + b)[p] + dv +
+                  dt / ((wk1 + b)[p] + (wk1 + b)[pn]) *
+                      (((gz + b1)[p] - (gz + b)[pn]) * ((pp + b1)[pn] - (pp + b)[p]) + ((gz + b)[p] - (gz + b1)[pn]) * ((pp + b1)[p] - (pp + b)[pn]))) *
+                 (g.rdy + m2)[p];
     }
   });
   return fv3_post(c, s, "nh_p_grad");
@@ -332,7 +346,10 @@ extern "C" int fv3_pk3_halo(fv3_ctx *c, const fv3_field *pk3_, const fv3_field *
   const Real ptop = (Real)ptopd, akap = (Real)akapd;
   launch2(c, (fv3_stream_t)stream, Box{-1, g.nx + 2, -1, g.ny + 2, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny) return;
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     Real pei = ptop;
     for (int k = 0; k < g.nz; ++k) {
       pei = pei + K_(delp, k);
@@ -349,7 +366,10 @@ extern "C" int fv3_edge_pe(fv3_ctx *c, const fv3_field *pe_, const fv3_field *de
   const Real ptop = (Real)ptopd;
   launch2(c, (fv3_stream_t)stream, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny) return;
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     Real pei = ptop;
     K_(pe, 0) = pei;
     for (int k = 0; k < g.nz; ++k) {
@@ -375,7 +395,10 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   // cubic-spline-like layer -> interface interpolation (FV3 edge_profile, limiter 0)
   launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     auto profile = [&](const Real *q, Real *qe) {
       const Real *dp0 = g.dp_ref;
       const Real g0 = dp0[1] / dp0[0];
@@ -410,7 +433,10 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   {
     const Real *gamd = g.ep_gam;
     launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-      const long p = t * g.st + IX(i, j);
+      const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
       const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
       for (int k = nz - 1; k >= 0; --k) {
         const Real gm = gamd[k];
@@ -433,16 +459,19 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const long p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
-    const Real ar = g.area[m2 + p];
-    const Real ra_x = ar + xfx_a[b + p] - xfx_a[b + pe_];
-    const Real ra_y = ar + yfx_a[b + p] - yfx_a[b + pn];
-    Real z = (zh[b + p] * ar + fx[b + p] - fx[b + pe_] + fy[b + p] - fy[b + pn]) / (ra_x + ra_y - ar);
-    if (g.damp_vt[k] > (Real)1.0e-5) z = z + (fx2[b + p] - fx2[b + pe_] + fy2[b + p] - fy2[b + pn]) * g.rarea[m2 + p];
-    zh[b + p] = z;
+    const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
+    const Real ar = (g.area + m2)[p];
+    const Real ra_x = ar + (xfx_a + b)[p] - (xfx_a + b)[pe_];
+    const Real ra_y = ar + (yfx_a + b)[p] - (yfx_a + b)[pn];
+    Real z = ((zh + b)[p] * ar + (fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) / (ra_x + ra_y - ar);
+    if (g.damp_vt[k] > (Real)1.0e-5) z = z + ((fx2 + b)[p] - (fx2 + b)[pe_] + (fy2 + b)[p] - (fy2 + b)[pn]) * (g.rarea + m2)[p];
+    (zh + b)[p] = z;
   });
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     Real below = K_(zh, nz);
     wsd[t * g.st2 + IX(i, j)] = (zs[t * g.st2 + IX(i, j)] - below) / dt;
     for (int k = nz - 1; k >= 0; --k) {
@@ -496,7 +525,10 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_
   const Real dm = (Real)c->rf_dm;
   const Real *rf = (const Real *)c->tab_rf;
   launch2(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    const long p = tb + pix;
+    (void)p;
     auto wind = [&](Real *a) {
       Real dmdir = (Real)0;
       for (int k = 0; k < nd; ++k) {
@@ -553,22 +585,22 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
       const int fl = g.flags[t];
       const long b = t * g.st + k * g.sk, m2 = t * g.st2;
       const Real *qq = q + b;
-      const long p = IX(i, j);
+      const unsigned p = IX(i, j);
       if (j <= g.ny + nt) {
         const Real a = nt > 0 ? cc<1>(qq, g, fl, i - 1, j) : qq[IX(i - 1, j)];
         const Real e = nt > 0 ? cc<1>(qq, g, fl, i, j) : qq[p];
-        fx[b + p] = g.del6_v[m2 + p] * (a - e);
+        (fx + b)[p] = (g.del6_v + m2)[p] * (a - e);
       }
       if (i <= g.nx + nt) {
         const Real a = nt > 0 ? cc<2>(qq, g, fl, i, j - 1) : qq[IX(i, j - 1)];
         const Real e = nt > 0 ? cc<2>(qq, g, fl, i, j) : qq[p];
-        fy[b + p] = g.del6_u[m2 + p] * (a - e);
+        (fy + b)[p] = (g.del6_u + m2)[p] * (a - e);
       }
     });
     launch3(c, s, Box{1 - nt, g.nx + nt, 1 - nt, g.ny + nt, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
-      const long p = IX(i, j);
-      q[b + p] = q[b + p] + cd * g.rarea[t * g.st2 + p] * (fx[b + p] - fx[b + IX(i + 1, j)] + fy[b + p] - fy[b + IX(i, j + 1)]);
+      const unsigned p = IX(i, j);
+      (q + b)[p] = (q + b)[p] + cd * g.rarea[t * g.st2 + p] * ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]);
     });
   }
   return fv3_post(c, s, "del2_cubed");

@@ -21,7 +21,9 @@ enum {
   SC_H = 14,
   SC_I = 15,
   SC_J = 16,
-  SC_K = 17
+  SC_K = 17,
+  SC_L = 18,  // del-n corner windows (private fluxes)
+  SC_M = 19
 };
 
 // Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]

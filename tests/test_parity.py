@@ -200,6 +200,17 @@ def test_full_acoustic_call(backend, layout, n_split):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
+def test_full_acoustic_call_multi_tile(backend):
+    """C96: sub-domains span several LDS tiles (64 x 8 transport, 64 x 16 del-n), so interior,
+    tile-edge, cube-corner-window and partial tiles of the fused kernels are all exercised."""
+    nz = 4
+    part, cfg, grids, ost, phis, odyn = oracle_cube(96, (1, 1), nz, dict(n_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 60.0, 1)
+    got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    compare_cubes(got, ost, part, nz, STATE, TOL)
+
+
 def test_realistic_restart_values(backend):
     """Real FV3 C12 fields (L63 restart of the reference tree) regridded onto tile 1 of the cube:
     exercises limiter / upwind branches with genuine model data
