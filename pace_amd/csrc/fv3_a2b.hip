@@ -99,77 +99,135 @@ struct A2B {
 
 FV3_HD inline Real extrap(Real fac, Real q1, Real q2) { return q1 + fac * (q1 - q2); }
 
+// one output corner, any position: tile-edge formulas included
+FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j) {
+  const int fl = g.flags[t];
+  A2B a;
+  a.g = g;
+  a.q = qlev;
+  a.dxa = g.dxa + t * g.st2;
+  a.dya = g.dya + t * g.st2;
+  a.W = fl & FV3_W;
+  a.E = fl & FV3_E;
+  a.S = fl & FV3_S;
+  a.N = fl & FV3_N;
+  const int npx = g.npx, npy = g.npy;
+  const bool onW = a.W && i == 1, onE = a.E && i == npx, onS = a.S && j == 1, onN = a.N && j == npy;
+  const Real *ce = g.corner_extrap + t * 12;
+  Real r;
+  if ((!a.W || i >= 3) && (!a.E || i <= npx - 2) && (!a.S || j >= 3) && (!a.N || j <= npy - 2)) {
+    // interior: branch-free, the same expressions the general path reduces to
+    const Real *q = a.q;
+    Real qx[4], qy[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int jj = j - 2 + n, ii = i - 2 + n;
+      qx[n] = A2B_B2 * (q[IX(i - 2, jj)] + q[IX(i + 1, jj)]) + A2B_B1 * (q[IX(i - 1, jj)] + q[IX(i, jj)]);
+      qy[n] = A2B_B2 * (q[IX(ii, j - 2)] + q[IX(ii, j + 1)]) + A2B_B1 * (q[IX(ii, j - 1)] + q[IX(ii, j)]);
+    }
+    const Real qxx = A2B_A2 * (qx[0] + qx[3]) + A2B_A1 * (qx[1] + qx[2]);
+    const Real qyy = A2B_A2 * (qy[0] + qy[3]) + A2B_A1 * (qy[1] + qy[2]);
+    r = (Real)0.5 * (qxx + qyy);
+  } else if (onW && onS) {
+    r = (extrap(ce[0], a.Q(1, 1), a.Q(2, 2)) + extrap(ce[1], a.Q(0, 1), a.Q(-1, 2)) + extrap(ce[2], a.Q(1, 0), a.Q(2, -1))) * A2B_R3;
+  } else if (onE && onS) {
+    r = (extrap(ce[3], a.Q(npx - 1, 1), a.Q(npx - 2, 2)) + extrap(ce[4], a.Q(npx - 1, 0), a.Q(npx - 2, -1)) + extrap(ce[5], a.Q(npx, 1), a.Q(npx + 1, 2))) *
+        A2B_R3;
+  } else if (onE && onN) {
+    r = (extrap(ce[6], a.Q(npx - 1, npy - 1), a.Q(npx - 2, npy - 2)) + extrap(ce[7], a.Q(npx, npy - 1), a.Q(npx + 1, npy - 2)) +
+         extrap(ce[8], a.Q(npx - 1, npy), a.Q(npx - 2, npy + 1))) *
+        A2B_R3;
+  } else if (onW && onN) {
+    r = (extrap(ce[9], a.Q(1, npy - 1), a.Q(2, npy - 2)) + extrap(ce[10], a.Q(0, npy - 1), a.Q(-1, npy - 2)) + extrap(ce[11], a.Q(1, npy), a.Q(2, npy + 1))) *
+        A2B_R3;
+  } else if (onW) {
+    r = a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]);
+  } else if (onE) {
+    r = a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]);
+  } else if (onS) {
+    r = a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]);
+  } else if (onN) {
+    r = a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]);
+  } else {
+    Real qxx, qyy;
+    if (a.S && j == 2)
+      qxx = A2B_C1 * (a.qx(i, 1) + a.qx(i, 2)) + A2B_C2 * (a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]) + a.qxx_int(i, 3));
+    else if (a.N && j == npy - 1)
+      qxx = A2B_C1 * (a.qx(i, npy - 2) + a.qx(i, npy - 1)) + A2B_C2 * (a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]) + a.qxx_int(i, npy - 2));
+    else
+      qxx = a.qxx_int(i, j);
+    if (a.W && i == 2)
+      qyy = A2B_C1 * (a.qy(1, j) + a.qy(2, j)) + A2B_C2 * (a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]) + a.qyy_int(3, j));
+    else if (a.E && i == npx - 1)
+      qyy = A2B_C1 * (a.qy(npx - 2, j) + a.qy(npx - 1, j)) + A2B_C2 * (a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]) + a.qyy_int(npx - 2, j));
+    else
+      qyy = a.qyy_int(i, j);
+    r = (Real)0.5 * (qxx + qyy);
+  }
+  return r;
+}
+
+#define AB_TI 64
+#define AB_TJ 16
+#define AB_EW (AB_TI + 4)
+#define AB_EH (AB_TJ + 4)
+
 }  // namespace
 
+// Workgroup = one 64 x 16 tile of corners on one level.  Tiles that stay two corners away from
+// every cube-tile edge stage qin through LDS (the x- and y-interpolated intermediates are formed
+// once per point and shared); tiles touching an edge evaluate a2b_point per corner.
 void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace) {
   const Geo g = c->g;
   Real *out = replace ? c->scratch[SC_K] : qout;
   const int kshift = replace ? 0 : (kout0 - kin0);
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+  const int gx = (g.nx + 1 + AB_TI - 1) / AB_TI, gy = (g.ny + 1 + AB_TJ - 1) / AB_TJ;
+  const size_t smem = sizeof(Real) * (AB_EW * AB_EH + AB_TI * AB_EH + AB_EW * AB_TJ);
+  launch_blocks(c, s, gx, gy, g.nsub * nk, 256, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / nk, k = kin0 + (blk.bz - t * nk);
     const int fl = g.flags[t];
-    A2B a;
-    a.g = g;
-    a.q = qin + t * g.st + k * g.sk;
-    a.dxa = g.dxa + t * g.st2;
-    a.dya = g.dya + t * g.st2;
-    a.W = fl & FV3_W;
-    a.E = fl & FV3_E;
-    a.S = fl & FV3_S;
-    a.N = fl & FV3_N;
-    const int npx = g.npx, npy = g.npy;
-    const bool onW = a.W && i == 1, onE = a.E && i == npx, onS = a.S && j == 1, onN = a.N && j == npy;
-    const Real *ce = g.corner_extrap + t * 12;
-    Real r;
-    if ((!a.W || i >= 3) && (!a.E || i <= npx - 2) && (!a.S || j >= 3) && (!a.N || j <= npy - 2)) {
-      // interior fast path: branch-free, the same expressions the general path reduces to
-      const Real *q = a.q;
-      Real qx[4], qy[4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int jj = j - 2 + n, ii = i - 2 + n;
-        qx[n] = A2B_B2 * (q[IX(i - 2, jj)] + q[IX(i + 1, jj)]) + A2B_B1 * (q[IX(i - 1, jj)] + q[IX(i, jj)]);
-        qy[n] = A2B_B2 * (q[IX(ii, j - 2)] + q[IX(ii, j + 1)]) + A2B_B1 * (q[IX(ii, j - 1)] + q[IX(ii, j)]);
+    const Real *q = qin + t * g.st + k * g.sk;
+    Real *o = out + t * g.st + (k + kshift) * g.sk;
+    const int i0 = 1 + blk.bx * AB_TI, j0 = 1 + blk.by * AB_TJ;
+    const int i1 = i0 + AB_TI - 1 < g.nx + 1 ? i0 + AB_TI - 1 : g.nx + 1, j1 = j0 + AB_TJ - 1 < g.ny + 1 ? j0 + AB_TJ - 1 : g.ny + 1;
+    const bool interior = (!(fl & FV3_W) || i0 >= 3) && (!(fl & FV3_E) || i1 <= g.npx - 2) && (!(fl & FV3_S) || j0 >= 3) && (!(fl & FV3_N) || j1 <= g.npy - 2);
+    if (!interior) {
+      for (int w = blk.tid; w < AB_TI * AB_TJ; w += blk.nthr) {
+        const int i = i0 + w % AB_TI, j = j0 + w / AB_TI;
+        if (i <= i1 && j <= j1) o[IX(i, j)] = a2b_point(g, q, t, i, j);
       }
-      const Real qxx = A2B_A2 * (qx[0] + qx[3]) + A2B_A1 * (qx[1] + qx[2]);
-      const Real qyy = A2B_A2 * (qy[0] + qy[3]) + A2B_A1 * (qy[1] + qy[2]);
-      r = (Real)0.5 * (qxx + qyy);
-    } else if (onW && onS) {
-      r = (extrap(ce[0], a.Q(1, 1), a.Q(2, 2)) + extrap(ce[1], a.Q(0, 1), a.Q(-1, 2)) + extrap(ce[2], a.Q(1, 0), a.Q(2, -1))) * A2B_R3;
-    } else if (onE && onS) {
-      r = (extrap(ce[3], a.Q(npx - 1, 1), a.Q(npx - 2, 2)) + extrap(ce[4], a.Q(npx - 1, 0), a.Q(npx - 2, -1)) + extrap(ce[5], a.Q(npx, 1), a.Q(npx + 1, 2))) *
-          A2B_R3;
-    } else if (onE && onN) {
-      r = (extrap(ce[6], a.Q(npx - 1, npy - 1), a.Q(npx - 2, npy - 2)) + extrap(ce[7], a.Q(npx, npy - 1), a.Q(npx + 1, npy - 2)) +
-           extrap(ce[8], a.Q(npx - 1, npy), a.Q(npx - 2, npy + 1))) *
-          A2B_R3;
-    } else if (onW && onN) {
-      r = (extrap(ce[9], a.Q(1, npy - 1), a.Q(2, npy - 2)) + extrap(ce[10], a.Q(0, npy - 1), a.Q(-1, npy - 2)) + extrap(ce[11], a.Q(1, npy), a.Q(2, npy + 1))) *
-          A2B_R3;
-    } else if (onW) {
-      r = a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]);
-    } else if (onE) {
-      r = a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]);
-    } else if (onS) {
-      r = a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]);
-    } else if (onN) {
-      r = a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]);
-    } else {
-      Real qxx, qyy;
-      if (a.S && j == 2)
-        qxx = A2B_C1 * (a.qx(i, 1) + a.qx(i, 2)) + A2B_C2 * (a.edge_y(i, 1, g.edge_s[t * g.ni + i + g.o]) + a.qxx_int(i, 3));
-      else if (a.N && j == npy - 1)
-        qxx = A2B_C1 * (a.qx(i, npy - 2) + a.qx(i, npy - 1)) + A2B_C2 * (a.edge_y(i, npy, g.edge_n[t * g.ni + i + g.o]) + a.qxx_int(i, npy - 2));
-      else
-        qxx = a.qxx_int(i, j);
-      if (a.W && i == 2)
-        qyy = A2B_C1 * (a.qy(1, j) + a.qy(2, j)) + A2B_C2 * (a.edge_x(1, j, g.edge_w[t * g.nj + j + g.o]) + a.qyy_int(3, j));
-      else if (a.E && i == npx - 1)
-        qyy = A2B_C1 * (a.qy(npx - 2, j) + a.qy(npx - 1, j)) + A2B_C2 * (a.edge_x(npx, j, g.edge_e[t * g.nj + j + g.o]) + a.qyy_int(npx - 2, j));
-      else
-        qyy = a.qyy_int(i, j);
-      r = (Real)0.5 * (qxx + qyy);
+      return;
     }
-    out[t * g.st + (k + kshift) * g.sk + IX(i, j)] = r;
+    Real *sq = (Real *)smem_;        // [EH][EW]  qin,  origin (i0-2, j0-2)
+    Real *sx = sq + AB_EW * AB_EH;   // [EH][TI]  x-interpolated, origin (i0, j0-2)
+    Real *sy = sx + AB_TI * AB_EH;   // [TJ][EW]  y-interpolated, origin (i0-2, j0)
+    const int imax = g.nx + g.nh + 1, jmax = g.ny + g.nh + 1;
+    for (int w = blk.tid; w < AB_EW * AB_EH; w += blk.nthr) {
+      const int i = i0 - 2 + w % AB_EW, j = j0 - 2 + w / AB_EW;
+      sq[w] = (i <= imax && j <= jmax) ? q[IX(i, j)] : (Real)0;
+    }
+    blk.sync();
+    for (int w = blk.tid; w < AB_TI * AB_EH; w += blk.nthr) {
+      const int li = w % AB_TI, r = w / AB_TI;
+      const Real *p = sq + r * AB_EW + li;  // p[0] = q(i-2, jj)
+      sx[w] = A2B_B2 * (p[0] + p[3]) + A2B_B1 * (p[1] + p[2]);
+    }
+    for (int w = blk.tid; w < AB_EW * AB_TJ; w += blk.nthr) {
+      const int cc_ = w % AB_EW, lj = w / AB_EW;
+      const Real *p = sq + lj * AB_EW + cc_;  // p[0] = q(ii, j-2)
+      sy[w] = A2B_B2 * (p[0] + p[3 * AB_EW]) + A2B_B1 * (p[AB_EW] + p[2 * AB_EW]);
+    }
+    blk.sync();
+    for (int w = blk.tid; w < AB_TI * AB_TJ; w += blk.nthr) {
+      const int li = w % AB_TI, lj = w / AB_TI;
+      const int i = i0 + li, j = j0 + lj;
+      if (i > i1 || j > j1) continue;
+      const Real *px = sx + lj * AB_TI + li;
+      const Real *py = sy + lj * AB_EW + li;
+      const Real qxx = A2B_A2 * (px[0] + px[3 * AB_TI]) + A2B_A1 * (px[AB_TI] + px[2 * AB_TI]);
+      const Real qyy = A2B_A2 * (py[0] + py[3]) + A2B_A1 * (py[1] + py[2]);
+      o[IX(i, j)] = (Real)0.5 * (qxx + qyy);
+    }
   });
   if (replace) {
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {

@@ -86,6 +86,8 @@ struct DampTables {
 
 struct fv3_ctx {
   Geo g;
+  const Geo *g_dev = nullptr;  // device-resident copy of g: rarely taken kernel paths read geometry through it
+                               // instead of keeping dozens of kernel-argument scalars live in SGPRs
   DampTables tab;
   fv3_acoustic_config cfg;
   fv3_constants cst;
@@ -203,6 +205,17 @@ struct Blk {
     __syncthreads();
 #endif
   }
+  // ordering point for LDS exchanges inside ONE wavefront (wave kernels): a wave's LDS
+  // instructions execute in issue order, so only the compiler has to be kept from moving the
+  // reads above the writes -- no s_barrier, and outstanding global prefetches stay in flight
+  // (a full __syncthreads() would drain vmcnt to 0).
+  FV3_HD inline void wave_sync() const {
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  }
 };
 
 #ifndef FV3_HOST_EMU
@@ -235,6 +248,42 @@ inline void launch_blocks(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int 
 #else
   (void)c;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kb<F>), dim3(gx, gy, gz), dim3(nthr, 1, 1), smem_bytes, s, f);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave kernels: one 64-lane wavefront per workgroup; a lane owns one column and marches along j
+// keeping its sliding windows in registers, neighbours in i are exchanged through a few LDS row
+// lines private to the wave (sync = the wave's own LDS ordering, no cross-wave barrier).
+// Per-lane state is declared as arrays [FV3_LPT] and every phase is written as
+// FV3_LANES(blk, lane, l) { ... state[l] ... }: on the device FV3_LPT = 1 (state lives in
+// registers, the loop body runs once for lane = threadIdx.x); the host emulation runs the 64 lanes
+// of a phase one after the other with FV3_LPT = 64.
+// ---------------------------------------------------------------------------------------------
+#define FV3_WAVE 64
+#ifdef FV3_HOST_EMU
+#define FV3_LPT 64
+#define FV3_LANES(blk, lane, l) for (int lane = 0, l = 0; lane < FV3_WAVE; ++lane, ++l)
+#else
+#define FV3_LPT 1
+#define FV3_LANES(blk, lane, l) for (int lane = (blk).tid, l = 0; l < 1; ++l)
+// WPE = waves per SIMD the register allocation is sized for (512 / WPE VGPRs per lane)
+template <int WPE, class F>
+__global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) fv3_kw(F f) {
+  extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
+  Blk b{(int)threadIdx.x, FV3_WAVE, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  f(b, fv3_smem);
+}
+#endif
+
+template <int WPE = 3, class F>
+inline void launch_waves(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int gz, size_t smem_bytes, F f) {
+  if (gx <= 0 || gy <= 0 || gz <= 0) return;
+#ifdef FV3_HOST_EMU
+  launch_blocks(c, s, gx, gy, gz, FV3_WAVE, smem_bytes, f);
+#else
+  (void)c;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kw<WPE, F>), dim3(gx, gy, gz), dim3(FV3_WAVE, 1, 1), smem_bytes, s, f);
 #endif
 }
 

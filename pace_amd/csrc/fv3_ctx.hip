@@ -275,6 +275,15 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     }
     c->scratch.push_back(p);
   }
+  {
+    Geo *gd = (Geo *)fv3_dev_alloc(c, sizeof(Geo));
+    if (!gd) {
+      fv3_ctx_destroy(c);
+      return fv3_fail(nullptr, FV3_ERR_NOMEM, "device allocation of the geometry block failed");
+    }
+    fv3_h2d(gd, &c->g, sizeof(Geo));
+    c->g_dev = gd;
+  }
   *out = c;
   return FV3_OK;
 }

@@ -69,3 +69,59 @@ FV3_HD inline Real ppm_flux(Q q, M m, Real c, int s, bool lo, bool hi, int np_, 
   if (sm || s0) flux = flux + fx1;
   return flux;
 }
+
+// ---- streaming (marching) form: a lane walks the sweep axis and keeps what consecutive faces share
+// edge value at the low face of cell s from q(s-2), q(s-1), q(s), q(s+1) = a, b, c_, d (same
+// expressions as ppm_al; s is uniform over the wave so the edge tests are scalar branches)
+template <class M>
+FV3_HD inline Real ppm_al_win(Real a, Real b, Real c_, Real d, M m, int s, bool lo, bool hi, int np_) {
+  if (lo) {
+    if (s == 0) return PPM_C1 * a + PPM_C2 * b + PPM_C3 * c_;
+    if (s == 1) return ppm_edge_mean(a, b, c_, d, m(-1), m(0), m(1), m(2));
+    if (s == 2) return PPM_C3 * b + PPM_C2 * c_ + PPM_C1 * d;
+  }
+  if (hi) {
+    if (s == np_ - 1) return PPM_C1 * a + PPM_C2 * b + PPM_C3 * c_;
+    if (s == np_) return ppm_edge_mean(a, b, c_, d, m(np_ - 2), m(np_ - 1), m(np_), m(np_ + 1));
+    if (s == np_ + 1) return PPM_C3 * b + PPM_C2 * c_ + PPM_C1 * d;
+  }
+  return PPM_P1 * (b + c_) + PPM_P2 * (a + d);
+}
+
+struct PpmCell {
+  Real bl, br, q;
+  bool sm;
+};
+
+FV3_HD inline PpmCell ppm_cell(Real al_lo, Real al_hi, Real q, int mord) {
+  PpmCell c;
+  c.bl = al_lo - q;
+  c.br = al_hi - q;
+  c.q = q;
+  c.sm = ppm_smt5(c.bl, c.br, mord);
+  return c;
+}
+
+// flux-form value through the face between cell m (below) and cell o (above); = ppm_flux with unit cfl scales
+FV3_HD inline Real ppm_face(const PpmCell &m, const PpmCell &o, Real c) {
+  Real fx1, flux;
+  if (c > (Real)0) {
+    fx1 = ((Real)1 - c) * (m.br - c * (m.bl + m.br));
+    flux = m.q;
+  } else {
+    fx1 = ((Real)1 + c) * (o.bl + c * (o.bl + o.br));
+    flux = o.q;
+  }
+  if (m.sm || o.sm) flux = flux + fx1;
+  return flux;
+}
+
+// face value from the six cells q(s-3..s+2) = a..f when no tile-edge formula is within reach
+// (the expressions ppm_flux reduces to there)
+FV3_HD inline Real ppm_flux_int(Real a, Real b, Real c_, Real d, Real e, Real f, Real cr, int mord) {
+  const Real al_m = PPM_P1 * (b + c_) + PPM_P2 * (a + d);
+  const Real al_0 = PPM_P1 * (c_ + d) + PPM_P2 * (b + e);
+  const Real al_p = PPM_P1 * (d + e) + PPM_P2 * (c_ + f);
+  const PpmCell m = ppm_cell(al_m, al_0, c_, mord), o = ppm_cell(al_0, al_p, d, mord);
+  return ppm_face(m, o, cr);
+}

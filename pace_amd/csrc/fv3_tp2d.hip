@@ -8,6 +8,8 @@
 //   (3) outer fluxes, averaged with the inner ones and scaled by the area / mass flux
 // plus the del-n chain when damping is on.  HBM traffic per level is dominated by the four
 // intermediates (fy2, fx2, q_i, q_j); fusing them through LDS is the next step.
+#include <type_traits>
+
 #include "fv3_ops.h"
 #include "fv3_ppm.h"
 
@@ -717,17 +719,262 @@ static void tp2d_fused_level(fv3_ctx *c, fv3_stream_t s, const Real *q, const Re
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Marching form.  One wavefront = a strip of 64 columns (58 owned + 3 halo columns a side) of
+// one level; the lanes march together along j over a segment of rows.  Per row a lane loads its
+// q / crx / xfx / cry / yfx values once, the two y-sweeps (inner flux of q, outer flux of the
+// x-advected q_j) run entirely from 4-row register windows and share edge values / cell
+// reconstructions between consecutive faces, the two x-sweeps (inner flux of q on the new row,
+// outer flux of the y-advected q_i three rows behind) read their i-neighbours from two LDS row
+// lines.  Exactly four PPM face evaluations per cell and no intermediate field in memory.
+//   step r:  fy_in(r-2) -> q_i(r-3);   fx_in(r), fx_out(r-3) -> fx(r-3);   q_j(r) -> fy_out(r-2) -> fy(r-2)
+#define TS_OUT 58
+#define TS_SEG 64
+#define TS_LINE (FV3_WAVE + 6)
+#define TS_PF 2  // rows fetched ahead of their use
+
+static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
+                        const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
+  const Geo g = c->g;
+  Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
+  const bool damped = dn != nullptr;
+  Deln d;
+  memset(&d, 0, sizeof(d));
+  if (damped) {
+    d = *dn;
+    del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
+  }
+  const int nk = k1 - k0 + 1;
+  const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT, nseg = (g.ny + TS_SEG - 1) / TS_SEG;
+  const size_t smem = sizeof(Real) * (2 * TS_LINE + 2 * (FV3_WAVE + 1));
+  // The hot loop touches only these scalars; everything the rare paths need (cube-corner remaps,
+  // tile-edge metric terms) is read through gp inside those paths, so it does not occupy SGPRs
+  // (or spill lanes) across the march.
+  const Geo *gp = c->g_dev;
+  const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const Real *area = g.area;
+  launch_waves<2>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+    const int fl = gp->flags[t];
+    const long b = t * st + k * sk, m2 = t * st2;
+    const int i0 = 1 + blk.bx * TS_OUT;                            // first owned face / cell
+    const int ja = 1 + blk.by * TS_SEG;                            // first owned row / face
+    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + TS_SEG - 1;  // last owned face (rows stop at ny)
+    const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
+    Real *lq = (Real *)smem_;         // q on the row being loaded (x-sweep view); index = i - i0 + 6
+    Real *lqi = lq + TS_LINE;         // q_i three rows behind
+    Real *exp_ = lqi + TS_LINE;       // xfx * fx_in of the lane (read by lane - 1)
+    Real *exx = exp_ + FV3_WAVE + 1;  // xfx
+    const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
+    const Real *areab = area + m2;
+    const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
+    const bool S = fl & FV3_S, N = fl & FV3_N;
+    const bool halo_cols = i0 - 3 < 1 || i0 + FV3_WAVE - 4 > nx;
+    const bool on = damped && deln_on(d, k);
+    const Real damp = on ? deln_damp(d, k) : (Real)0;
+    const int r_end = jb + 3 < jed ? jb + 3 : jed;
+
+    // per-lane marching state
+    struct Row {  // the inputs of one step, fetched TS_PF steps ahead of their use
+      Real qy, cx, xv, ar, cy, yv, ar3;
+      Real mx, my, dx, dy, ma, mc;  // optional: mass fluxes, damping fluxes, mass(i-1, r-3), mass(i, r-2)
+    };
+    Real mb[FV3_LPT];  // mass(i, r-3) = mass(i, r-2) of the previous step
+    Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
+    Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
+    Real v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], v5[FV3_LPT], al_v[FV3_LPT];  // q_j likewise
+    PpmCell cq[FV3_LPT], cv[FV3_LPT];                                        // reconstructed cell r-3 of q / q_j
+    Real p_prev[FV3_LPT], y_prev[FV3_LPT];                                   // yfx * fy_in and yfx of face r-3
+    Real fi1[FV3_LPT], fi2[FV3_LPT], fi3[FV3_LPT];                           // fx_in of rows r-1, r-2, r-3
+    Real cx1[FV3_LPT], cx2[FV3_LPT], cx3[FV3_LPT], xv1[FV3_LPT], xv2[FV3_LPT], xv3[FV3_LPT];
+    Real fyin[FV3_LPT], px[FV3_LPT];
+    unsigned pcol[FV3_LPT];  // in-plane offset of (ic, 0)
+    bool own_x[FV3_LPT], own_y[FV3_LPT];
+
+    auto load_row = [&](int r, int l) -> Row {
+      const int rf = r - 2 < jsd ? jsd : r - 2;  // face / row of the y-sweeps (clamped while the windows fill)
+      const int r3 = r - 3 < jsd ? jsd : r - 3;  // row of q_i and of the outer x-sweep
+      const unsigned p0 = pcol[l] + (unsigned)(r * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
+      Row w;
+      w.qy = qq[p0];
+      w.cx = crxb[p0];
+      w.xv = xfxb[p0];
+      w.ar = areab[p0];
+      w.cy = cryb[pf];
+      w.yv = yfxb[pf];
+      const unsigned p3 = pcol[l] + (unsigned)(r3 * sj32);
+      w.ar3 = areab[p3];
+      w.mx = w.my = w.dx = w.dy = w.ma = w.mc = (Real)0;
+      if (mfx) {
+        w.mx = (mfx + b)[p3];
+        w.my = (mfy + b)[pf];
+      }
+      if (on) {
+        w.dx = (dfx + b)[p3];
+        w.dy = (dfy + b)[pf];
+        if (mass) {
+          w.ma = (mass + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
+          w.mc = (mass + b)[pf];
+        }
+      }
+      return w;
+    };
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own_x[l] = i >= i0 && i < i0 + TS_OUT && i <= nx + 1;
+      own_y[l] = i >= i0 && i < i0 + TS_OUT && i <= nx;
+      w2[l] = w3[l] = w4[l] = w5[l] = al_q[l] = v2[l] = v3[l] = v4[l] = v5[l] = al_v[l] = (Real)0;
+      cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+      mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
+      if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
+      if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
+      nxt[l] = load_row(ja - 3, l);
+      nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l);
+    }
+
+    // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
+    auto march = [&](auto xe_tag) {
+      constexpr bool XE = decltype(xe_tag)::value;
+      for (int r = ja - 3; r <= r_end; ++r) {
+        const int r3 = r - 3 < jsd ? jsd : r - 3;
+        const int rn = r + TS_PF < r_end ? r + TS_PF : r_end;
+        const int sy = r - 1;  // cell whose low edge value the y-windows complete at this step
+        const bool y_edge = (S && sy >= 0 && sy <= 2) || (N && sy >= npy - 1 && sy <= npy + 1);
+        const bool corner_row = halo_cols && (r < 1 || r > ny);
+        // ---- phase 1: prefetch row r+2; inner y-flux at face r-2, q_i at row r-3
+        FV3_LANES(blk, lane, l) {
+          cur[l] = nxt[l];
+          nxt[l] = nx2[l];
+          nx2[l] = load_row(rn, l);
+          Real qy = cur[l].qy, qx = qy;
+          if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
+            const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
+            qy = cc<2>(qq, *gp, fl, ic, r);
+            qx = cc<1>(qq, *gp, fl, ic, r);
+            cur[l].qy = qy;
+          }
+          w2[l] = w3[l];
+          w3[l] = w4[l];
+          w4[l] = w5[l];
+          w5[l] = qy;
+          Real al_new;
+          if (y_edge) {
+            const Real *dyab = gp->dya + m2;
+            auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
+            al_new = ppm_al_win(w2[l], w3[l], w4[l], w5[l], My, sy, S, N, npy);
+          } else {
+            al_new = PPM_P1 * (w3[l] + w4[l]) + PPM_P2 * (w2[l] + w5[l]);
+          }
+          const PpmCell co = ppm_cell(al_q[l], al_new, w3[l], hord);
+          al_q[l] = al_new;
+          fyin[l] = ppm_face(cq[l], co, cur[l].cy);
+          cq[l] = co;
+          const Real yv = cur[l].yv;
+          const Real pn = yv * fyin[l];
+          const Real ar3 = cur[l].ar3;
+          const Real qi = (w2[l] * ar3 + p_prev[l] - pn) / (ar3 + y_prev[l] - yv);
+          p_prev[l] = pn;
+          y_prev[l] = yv;
+          lq[3 + lane] = qx;
+          lqi[3 + lane] = qi;
+        }
+        blk.wave_sync();
+        // ---- phase 2: inner x-flux on row r, outer x-flux on row r-3, fx(row r-3)
+        const int jr = r - 3;
+        const bool fx_row = jr >= ja && jr <= jb && jr <= ny;
+        FV3_LANES(blk, lane, l) {
+          const Real cx = cur[l].cx, xv = cur[l].xv;
+          Real fxin, fxout;
+          if (XE) {
+            const int i = i0 - 3 + lane;
+            const Real *dxab = gp->dxa + m2;
+            auto Qx = [&](int s_) { return lq[s_ - i0 + 6]; };
+            auto Mx = [&](int s_) { return dxab[(unsigned)((r + go) * sj32 + s_ + go)]; };
+            fxin = ppm_flux(Qx, Mx, cx, i, W, E, npx, hord);
+            auto Qi = [&](int s_) { return lqi[s_ - i0 + 6]; };
+            auto Mx3 = [&](int s_) { return dxab[(unsigned)((r3 + go) * sj32 + s_ + go)]; };
+            fxout = ppm_flux(Qi, Mx3, cx3[l], i, W, E, npx, hord);
+          } else {
+            const Real *a = lq + lane, *bq = lqi + lane;
+            fxin = ppm_flux_int(a[0], a[1], a[2], a[3], a[4], a[5], cx, hord);
+            fxout = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord);
+          }
+          if (fx_row && own_x[l]) {
+            const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
+            Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx ? cur[l].mx : xv3[l]);
+            if (on) v = mass ? v + (Real)0.5 * damp * (cur[l].ma + mb[l]) * cur[l].dx : v + cur[l].dx;
+            (fx + b)[p] = v;
+          }
+          fi3[l] = fi2[l];
+          fi2[l] = fi1[l];
+          fi1[l] = fxin;
+          cx3[l] = cx2[l];
+          cx2[l] = cx1[l];
+          cx1[l] = cx;
+          xv3[l] = xv2[l];
+          xv2[l] = xv1[l];
+          xv1[l] = xv;
+          px[l] = xv * fxin;
+          exp_[lane] = px[l];
+          exx[lane] = xv;
+        }
+        blk.wave_sync();
+        // ---- phase 3: q_j on row r, outer y-flux at face r-2, fy(face r-2)
+        const int jf = r - 2;
+        const bool fy_row = jf >= ja && jf <= jb;
+        FV3_LANES(blk, lane, l) {
+          const Real p1 = exp_[lane + 1], x1 = exx[lane + 1];
+          const Real ar = cur[l].ar;
+          const Real qj = (cur[l].qy * ar + px[l] - p1) / (ar + cur[l].xv - x1);
+          v2[l] = v3[l];
+          v3[l] = v4[l];
+          v4[l] = v5[l];
+          v5[l] = qj;
+          Real al_new;
+          if (y_edge) {
+            const Real *dyab = gp->dya + m2;
+            auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
+            al_new = ppm_al_win(v2[l], v3[l], v4[l], v5[l], My, sy, S, N, npy);
+          } else {
+            al_new = PPM_P1 * (v3[l] + v4[l]) + PPM_P2 * (v2[l] + v5[l]);
+          }
+          const PpmCell co = ppm_cell(al_v[l], al_new, v3[l], hord);
+          al_v[l] = al_new;
+          const Real fyout = ppm_face(cv[l], co, cur[l].cy);
+          cv[l] = co;
+          if (fy_row && own_y[l]) {
+            const unsigned p = pcol[l] + (unsigned)(jf * sj32);
+            Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy ? cur[l].my : cur[l].yv);
+            if (on) v = mass ? v + (Real)0.5 * damp * (mb[l] + cur[l].mc) * cur[l].dy : v + cur[l].dy;
+            (fy + b)[p] = v;
+          }
+          mb[l] = cur[l].mc;
+        }
+        blk.wave_sync();
+      }
+    };
+    if (W || E)
+      march(std::true_type{});
+    else
+      march(std::false_type{});
+  });
+}
+
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
           const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
-  // FV3_TP2D_MODE = staged | kwalk | level (default): A/B switch for profiling
+  // FV3_TP2D_MODE = staged | kwalk | level | stream (default): A/B switch for profiling
   static const char *mode_env = getenv("FV3_TP2D_MODE");
-  static const int mode = !mode_env ? 2 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "kwalk") ? 1 : 2));
+  static const int mode = !mode_env ? 3 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "kwalk") ? 1 : (!strcmp(mode_env, "level") ? 2 : 3)));
   if (mode == 0)
     tp2d_staged(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
   else if (mode == 1)
     tp2d_fused_kwalk(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
-  else
+  else if (mode == 2)
     tp2d_fused_level(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
+  else
+    tp2d_stream(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
 }
 
 extern "C" int fv3_fv_tp_2d(fv3_ctx *c, const fv3_field *q_, const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_,

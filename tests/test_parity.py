@@ -43,10 +43,11 @@ def _winds_and_fluxes(D, s, nz, dt=30000.0):
     return dict(uc=uc, vc=vc, crx=crx, cry=cry, xfx=xfx, yfx=yfx, ut=ut, vt=vt, ra_x=ra_x, ra_y=ra_y)
 
 
-@pytest.mark.parametrize("layout, ranks", [((1, 1), (0, 1)), ((2, 2), (0, 3, 5, 6))])
-def test_fxadv_and_fv_tp_2d(backend, layout, ranks):
-    nz = 4
-    cs = Case(12, layout, ranks, nz=nz, backend=backend)
+# the C192 case has workgroup tiles away from every cube-tile edge (the LDS interior paths)
+@pytest.mark.parametrize("n, layout, ranks", [(12, (1, 1), (0, 1)), (12, (2, 2), (0, 3, 5, 6)), (192, (1, 1), (2,))])
+def test_fxadv_and_fv_tp_2d(backend, n, layout, ranks):
+    nz = 4 if n == 12 else 3
+    cs = Case(n, layout, ranks, nz=nz, backend=backend)
     w = [_winds_and_fluxes(D, s, nz) for D, s in zip(cs.doms, cs.states)]
     # fxadv
     Q = {k: cs.q([_pad(x[k]) for x in w]) for k in ("uc", "vc")}
@@ -78,10 +79,10 @@ def test_fxadv_and_fv_tp_2d(backend, layout, ranks):
             assert_close("fy", fy.numpy(r)[:, :, :nz][Ry], efy[Ry], 1e-13, 1e-13)
 
 
-@pytest.mark.parametrize("layout, ranks", [((1, 1), (0,)), ((2, 2), (1, 2, 4, 7))])
-def test_a2b_ord4(backend, layout, ranks):
+@pytest.mark.parametrize("n, layout, ranks", [(12, (1, 1), (0,)), (12, (2, 2), (1, 2, 4, 7)), (192, (1, 1), (4,))])
+def test_a2b_ord4(backend, n, layout, ranks):
     nz = 3
-    cs = Case(12, layout, ranks, nz=nz, backend=backend)
+    cs = Case(n, layout, ranks, nz=nz, backend=backend)
     qin = [s["pt"][:, :, :nz].copy() for s in cs.states]
     Q, O = cs.q([_pad(a) for a in qin]), cs.q()
     cs.sf.call("a2b_ord4", Q.fref, O.fref, 0, nz, 0)

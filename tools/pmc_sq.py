@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-kernel means of SQ counters from a rocprofv3 --pmc counter_collection.csv.
+
+    python tools/pmc_sq.py <counter_collection.csv> [filter-substring] [top]
+
+Prints, per kernel (averaged over its dispatches): duration, waves, VALU / SALU / LDS / VMEM
+instructions per wave, and the wave-cycle split (active / wait_any / wait_inst_any) when the
+counters were collected.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles
+(MI355X_MICROARCH.md, PMC slots).
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"fv3_k[23bw]<(.*?)::\{lambda.*?#(\d+)\}", name)
+    if m:
+        fn = re.sub(r"\(.*\)", "", m.group(1)).replace("(anonymous namespace)::", "")
+        return f"{fn}#{m.group(2)}"
+    m = re.search(r"fv3_k[23bw]<Z*L?\d*([A-Za-z_0-9]+)\(", name)
+    if m:
+        return m.group(1)
+    return re.sub(r"\(.*", "", name)[:50]
+
+
+def main(path, flt="", top=40):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    dur = defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        n = short(r["Kernel_Name"])
+        if flt and flt not in n:
+            continue
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[n][r["Counter_Name"]] += 1
+        dur[n] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    rows = []
+    for n, a in acc.items():
+        k = max(cnt[n].values())
+        ncounters = len(a)
+        m = {c: v / cnt[n][c] for c, v in a.items()}
+        ms = dur[n] / (k * ncounters) / 1e6 * 1.0
+        rows.append((dur[n] / ncounters, n, k, ms, m))
+    rows.sort(reverse=True)
+    for _, n, k, ms, m in rows[:top]:
+        w = m.get("SQ_WAVES", 0) or 1
+        out = [f"{n}: calls {k}, {ms:.3f} ms, waves {w:.0f}"]
+        for c, lab in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_SALU", "salu"), ("SQ_INSTS_LDS", "lds"), ("SQ_INSTS_VMEM_RD", "vmem_rd"), ("SQ_INSTS_VMEM_WR", "vmem_wr"),
+                       ("SQ_INSTS_SMEM", "smem"), ("SQ_INSTS_FLAT", "flat")):
+            if c in m:
+                out.append(f"{lab}/wave {m[c] / w:.0f}")
+        if "SQ_WAVE_CYCLES" in m:
+            wc = m["SQ_WAVE_CYCLES"]
+            out.append(f"wave_cycles/wave {4 * wc / w:.0f}")
+            for c, lab in (("SQ_ACTIVE_INST_ANY", "active"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst"), ("SQ_ACTIVE_INST_VALU", "act_valu"),
+                           ("SQ_ACTIVE_INST_LDS", "act_lds"), ("SQ_ACTIVE_INST_VMEM", "act_vmem"), ("SQ_WAIT_INST_LDS", "wait_lds")):
+                if c in m:
+                    out.append(f"{lab} {100 * m[c] / wc:.0f}%")
+        if "SQ_BUSY_CYCLES" in m:
+            out.append(f"busy_cycles {m['SQ_BUSY_CYCLES']:.3g}")
+        print(", ".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", int(sys.argv[3]) if len(sys.argv) > 3 else 40)

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [top]
+
+Counter units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): both counters
+are reported in KiB... no -- in units of 1 KB?  rocprofv3 documents FETCH_SIZE / WRITE_SIZE in
+kilobytes; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950.  8-B-per-lane f64
+accesses are "uncalibrated" there, so the table is calibrated on this library's own fv3_copy
+kernel (reads N*8 B, writes N*8 B): the script prints the raw per-launch values of fv3_copy next
+to its known byte count and applies that ratio (read_scale / write_scale) to every kernel.
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"fv3_k[23b]<(.*?)::\{lambda.*?#(\d+)\}", name)
+    if m:
+        fn = re.sub(r"\(.*\)", "", m.group(1)).replace("(anonymous namespace)::", "")
+        return f"{fn}#{m.group(2)}"
+    m = re.search(r"fv3_k[23b]<Z*L?\d*([A-Za-z_0-9]+)\(", name)
+    if m:
+        return m.group(1)
+    return re.sub(r"\(.*", "", name)[:60]
+
+
+def load(path, counter):
+    per = defaultdict(lambda: [0, 0.0, 0.0])  # calls, sum value, sum ns
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        e = per[short(r["Kernel_Name"])]
+        e[0] += 1
+        e[1] += float(r["Counter_Value"])
+        e[2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return per
+
+
+def main(fetch_csv, write_csv, top=40, copy_bytes=None):
+    rd = load(fetch_csv, "FETCH_SIZE")
+    wr = load(write_csv, "WRITE_SIZE")
+    names = sorted(set(rd) | set(wr), key=lambda n: -(rd.get(n, [0, 0, 0])[2]))
+    kb = 1024.0
+    rs = ws = 1.0
+    cp = [n for n in names if n.startswith("fv3_copy")]
+    if cp and copy_bytes:
+        c = cp[0]
+        raw_r = rd[c][1] / rd[c][0] * kb
+        raw_w = wr[c][1] / wr[c][0] * kb
+        rs, ws = copy_bytes / raw_r, copy_bytes / raw_w
+        print(f"calibration on {c}: known {copy_bytes / 1e6:.1f} MB each way per launch; raw FETCH_SIZE {raw_r / 1e6:.1f} MB (scale {rs:.3f}), raw WRITE_SIZE {raw_w / 1e6:.1f} MB (scale {ws:.3f})\n")
+    print("| kernel | calls | avg ms (pmc run) | read GB/launch | write GB/launch | GB/s |")
+    print("|---|---:|---:|---:|---:|---:|")
+    for n in names[:top]:
+        c = max(rd.get(n, [0])[0], wr.get(n, [0])[0])
+        if not c:
+            continue
+        r = rd.get(n, [1, 0, 0])
+        w = wr.get(n, [1, 0, 0])
+        rb = r[1] / max(r[0], 1) * kb * rs
+        wb = w[1] / max(w[0], 1) * kb * ws
+        ms = r[2] / max(r[0], 1) / 1e6
+        print(f"| {n} | {c} | {ms:.3f} | {rb / 1e9:.3f} | {wb / 1e9:.3f} | {(rb + wb) / max(ms, 1e-9) / 1e6:.0f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40, float(sys.argv[4]) if len(sys.argv) > 4 else None)
