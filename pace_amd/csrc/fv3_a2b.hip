@@ -167,67 +167,116 @@ FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j
   return r;
 }
 
-#define AB_TI 64
-#define AB_TJ 16
-#define AB_EW (AB_TI + 4)
-#define AB_EH (AB_TJ + 4)
-
 }  // namespace
 
-// Workgroup = one 64 x 16 tile of corners on one level.  Tiles that stay two corners away from
-// every cube-tile edge stage qin through LDS (the x- and y-interpolated intermediates are formed
-// once per point and shared); tiles touching an edge evaluate a2b_point per corner.
+#define AB_OUT 61  // corners owned by a wave (64 columns of qin, 2 + 1 of them halo)
+#define AB_PF 4    // rows of qin in flight ahead of the march
+
+// Marching form (see fv3_tp2d.hip): a wave owns a strip of 61 corner columns and walks j.  Per row
+// a lane loads one qin value (AB_PF rows ahead), forms the x-interpolated value of the new row and
+// the y-interpolated value of the corner row from its 4-row register window, exchanges both with
+// its i-neighbours through two LDS lines and stores one corner.  Corners within two points of a
+// cube-tile edge use other formulas: the marching kernel skips them and a thin frame launch
+// evaluates a2b_point there.
 void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace) {
   const Geo g = c->g;
   Real *out = replace ? c->scratch[SC_K] : qout;
   const int kshift = replace ? 0 : (kout0 - kin0);
-  const int gx = (g.nx + 1 + AB_TI - 1) / AB_TI, gy = (g.ny + 1 + AB_TJ - 1) / AB_TJ;
-  const size_t smem = sizeof(Real) * (AB_EW * AB_EH + AB_TI * AB_EH + AB_EW * AB_TJ);
-  launch_blocks(c, s, gx, gy, g.nsub * nk, 256, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+  const Geo *gp = c->g_dev;
+  const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk;
+  const int nstrip = (nx + 1 + AB_OUT - 1) / AB_OUT;
+  int nseg = (ny + 1 + 32) / 64;
+  if (nseg < 1) nseg = 1;
+  const int seglen = (ny + 1 + nseg - 1) / nseg;
+  const size_t smem = sizeof(Real) * 2 * (FV3_WAVE + 3);
+  launch_waves<8>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / nk, k = kin0 + (blk.bz - t * nk);
-    const int fl = g.flags[t];
-    const Real *q = qin + t * g.st + k * g.sk;
-    Real *o = out + t * g.st + (k + kshift) * g.sk;
-    const int i0 = 1 + blk.bx * AB_TI, j0 = 1 + blk.by * AB_TJ;
-    const int i1 = i0 + AB_TI - 1 < g.nx + 1 ? i0 + AB_TI - 1 : g.nx + 1, j1 = j0 + AB_TJ - 1 < g.ny + 1 ? j0 + AB_TJ - 1 : g.ny + 1;
-    const bool interior = (!(fl & FV3_W) || i0 >= 3) && (!(fl & FV3_E) || i1 <= g.npx - 2) && (!(fl & FV3_S) || j0 >= 3) && (!(fl & FV3_N) || j1 <= g.npy - 2);
-    if (!interior) {
-      for (int w = blk.tid; w < AB_TI * AB_TJ; w += blk.nthr) {
-        const int i = i0 + w % AB_TI, j = j0 + w / AB_TI;
-        if (i <= i1 && j <= j1) o[IX(i, j)] = a2b_point(g, q, t, i, j);
+    const int fl = gp->flags[t];
+    const Real *q = qin + t * st + k * sk;
+    Real *o = out + t * st + (k + kshift) * sk;
+    // corners of this sub-domain that take the interior formula
+    const int ia = (fl & FV3_W) ? 3 : 1, ib = (fl & FV3_E) ? npx - 2 : nx + 1;
+    const int ja = (fl & FV3_S) ? 3 : 1, jb = (fl & FV3_N) ? npy - 2 : ny + 1;
+    const int i0 = 1 + blk.bx * AB_OUT;
+    int j0 = 1 + blk.by * seglen, j1 = j0 + seglen - 1;
+    if (j0 < ja) j0 = ja;
+    if (j1 > jb) j1 = jb;
+    if (j0 > j1) return;
+    const int ilo = i0 > ia ? i0 : ia, ihi = i0 + AB_OUT - 1 < ib ? i0 + AB_OUT - 1 : ib;
+    if (ilo > ihi) return;
+    Real *lq = (Real *)smem_ + 2;        // qin of the new row;        lq[lane] <-> column i0 - 2 + lane
+    Real *ly = lq + FV3_WAVE + 3;        // y-interpolated corner row
+    const int ied = nx + nh;
+    Real qa[FV3_LPT], qb[FV3_LPT], qc[FV3_LPT], qd[FV3_LPT];  // qin rows r-3..r
+    Real x0[FV3_LPT], x1[FV3_LPT], x2[FV3_LPT], x3[FV3_LPT];  // x-interpolated rows r-3..r
+    Real pf[AB_PF][FV3_LPT];
+    unsigned pcol[FV3_LPT];
+    bool own[FV3_LPT];
+    const int r_beg = j0 - 2, r_end = j1 + 1;
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 2 + lane, ic = i < ied ? i : ied;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own[l] = i >= ilo && i <= ihi;
+      qa[l] = qb[l] = qc[l] = qd[l] = x0[l] = x1[l] = x2[l] = x3[l] = (Real)0;
+      if (lane < 2) lq[lane - 2] = ly[lane - 2] = (Real)0;
+      if (lane == 0) lq[FV3_WAVE] = ly[FV3_WAVE] = (Real)0;
+#pragma unroll
+      for (int n = 0; n < AB_PF; ++n) {
+        const int rr = r_beg + n < r_end ? r_beg + n : r_end;
+        pf[n][l] = q[pcol[l] + (unsigned)(rr * sj32)];
       }
-      return;
     }
-    Real *sq = (Real *)smem_;        // [EH][EW]  qin,  origin (i0-2, j0-2)
-    Real *sx = sq + AB_EW * AB_EH;   // [EH][TI]  x-interpolated, origin (i0, j0-2)
-    Real *sy = sx + AB_TI * AB_EH;   // [TJ][EW]  y-interpolated, origin (i0-2, j0)
-    const int imax = g.nx + g.nh + 1, jmax = g.ny + g.nh + 1;
-    for (int w = blk.tid; w < AB_EW * AB_EH; w += blk.nthr) {
-      const int i = i0 - 2 + w % AB_EW, j = j0 - 2 + w / AB_EW;
-      sq[w] = (i <= imax && j <= jmax) ? q[IX(i, j)] : (Real)0;
+    for (int r = r_beg; r <= r_end; ++r) {
+      const int rn = r + AB_PF < r_end ? r + AB_PF : r_end;
+      FV3_LANES(blk, lane, l) {
+        const Real qn = pf[0][l];
+#pragma unroll
+        for (int n = 0; n + 1 < AB_PF; ++n) pf[n][l] = pf[n + 1][l];
+        pf[AB_PF - 1][l] = q[pcol[l] + (unsigned)(rn * sj32)];
+        qa[l] = qb[l];
+        qb[l] = qc[l];
+        qc[l] = qd[l];
+        qd[l] = qn;
+        lq[lane] = qn;
+        ly[lane] = A2B_B2 * (qa[l] + qd[l]) + A2B_B1 * (qb[l] + qc[l]);  // corner row r-1
+      }
+      blk.wave_sync();
+      const int j = r - 1;
+      const bool row_ok = j >= j0 && j <= j1;
+      FV3_LANES(blk, lane, l) {
+        x0[l] = x1[l];
+        x1[l] = x2[l];
+        x2[l] = x3[l];
+        x3[l] = A2B_B2 * (lq[lane - 2] + lq[lane + 1]) + A2B_B1 * (lq[lane - 1] + lq[lane]);
+        const Real qxx = A2B_A2 * (x0[l] + x3[l]) + A2B_A1 * (x1[l] + x2[l]);
+        const Real qyy = A2B_A2 * (ly[lane - 2] + ly[lane + 1]) + A2B_A1 * (ly[lane - 1] + ly[lane]);
+        if (row_ok && own[l]) o[pcol[l] + (unsigned)(j * sj32)] = (Real)0.5 * (qxx + qyy);
+      }
+      blk.wave_sync();
     }
-    blk.sync();
-    for (int w = blk.tid; w < AB_TI * AB_EH; w += blk.nthr) {
-      const int li = w % AB_TI, r = w / AB_TI;
-      const Real *p = sq + r * AB_EW + li;  // p[0] = q(i-2, jj)
-      sx[w] = A2B_B2 * (p[0] + p[3]) + A2B_B1 * (p[1] + p[2]);
+  });
+  // frame: the two outermost corner rows / columns on each side, wherever the sub-domain has a cube-tile edge there
+  const int nfr = nx + 1 > ny + 1 ? nx + 1 : ny + 1;
+  launch3(c, s, Box{1, nfr, 1, 8, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int a, int side) {
+    const int fl = g.flags[t];
+    int i, j;
+    // side 1,2: columns 1,2 (W)   3,4: columns npx-1, npx (E)   5,6: rows 1,2 (S)   7,8: rows npy-1, npy (N)
+    if (side <= 4) {
+      if (a > g.ny + 1) return;
+      if (!(fl & (side <= 2 ? FV3_W : FV3_E))) return;
+      i = side <= 2 ? side : g.npx - 4 + side;
+      j = a;
+    } else {
+      if (a > g.nx + 1) return;
+      if (!(fl & (side <= 6 ? FV3_S : FV3_N))) return;
+      j = side <= 6 ? side - 4 : g.npy - 8 + side;
+      i = a;
+      // corners already covered by the column sides
+      if (((fl & FV3_W) && i <= 2) || ((fl & FV3_E) && i >= g.npx - 1)) return;
     }
-    for (int w = blk.tid; w < AB_EW * AB_TJ; w += blk.nthr) {
-      const int cc_ = w % AB_EW, lj = w / AB_EW;
-      const Real *p = sq + lj * AB_EW + cc_;  // p[0] = q(ii, j-2)
-      sy[w] = A2B_B2 * (p[0] + p[3 * AB_EW]) + A2B_B1 * (p[AB_EW] + p[2 * AB_EW]);
-    }
-    blk.sync();
-    for (int w = blk.tid; w < AB_TI * AB_TJ; w += blk.nthr) {
-      const int li = w % AB_TI, lj = w / AB_TI;
-      const int i = i0 + li, j = j0 + lj;
-      if (i > i1 || j > j1) continue;
-      const Real *px = sx + lj * AB_TI + li;
-      const Real *py = sy + lj * AB_EW + li;
-      const Real qxx = A2B_A2 * (px[0] + px[3 * AB_TI]) + A2B_A1 * (px[AB_TI] + px[2 * AB_TI]);
-      const Real qyy = A2B_A2 * (py[0] + py[3]) + A2B_A1 * (py[1] + py[2]);
-      o[IX(i, j)] = (Real)0.5 * (qxx + qyy);
-    }
+    const Real *q = qin + t * g.st + k * g.sk;
+    (out + t * g.st + (k + kshift) * g.sk)[IX(i, j)] = a2b_point(g, q, t, i, j);
   });
   if (replace) {
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {

@@ -105,10 +105,200 @@ FV3_HD static inline bool dl_corner_tile(const Geo &g, int fl, int i0, int j0) {
   return (W && S && lo_i && lo_j) || (E && S && hi_i && lo_j) || (E && N && hi_i && hi_j) || (W && N && lo_i && hi_j);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Marching del-n chain (orders 0..2 = del-2, del-4, del-6; fv_tp_2d / d_sw never ask for more:
+// get_column_namelist caps nord_v / nord_w / nord_t at 2).  A wave owns 58 face columns and
+// walks j; iteration s of the chain runs s rows behind the row being loaded, its d2 / fx2 / fy2
+// values live in registers, i-neighbours are exchanged through LDS lines.  q is read once,
+// the final fluxes are written once, no intermediate reaches memory.
+//   step r:  d2_0(r);  for s = 1..nord: d2_s(r-s) from the fluxes of iteration s-1;  fy_s(r-s) [own lane]
+//            -> exchange d2_s(i-1) -> fx_s(r-s) -> exchange fx_s(i+1) -> kept for d2_(s+1) at the next step
+// Faces whose dependency cone touches a cube corner (within nord+1 of it) come out wrong here
+// (the corner-halo remap is not a tile-local operation); an 8 x 8 patch per corner is
+// recomputed with the staged chain on a small window and overwrites them.
+#define D6_OUT 58
+#define D6_SEG 64
+#define D6_PF 2
+#define D6_NMAX 2
+#define D6_PATCH 8
+
+static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+  const Geo g = c->g;
+  int any = 0;
+  for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
+  Real *tfx = c->scratch[SC_L], *tfy = c->scratch[SC_M];
+  const Deln dd = dn;
+  auto patch = [&](int need, bool west, bool south) {
+    if ((any & need) != need) return;
+    const int P = D6_PATCH, M = 4;  // staged results are exact >= 4 points inside an artificial window boundary
+    Box w;
+    w.i0 = west ? -3 : g.nx + 1 - P - M;
+    w.i1 = west ? P + M : g.nx + 4;
+    w.j0 = south ? -3 : g.ny + 1 - P - M;
+    w.j1 = south ? P + M : g.ny + 4;
+    w.k0 = k0;
+    w.k1 = k1;
+    del6_vt_flux_staged(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, &w);
+    const int pi0 = west ? 1 : g.nx + 2 - P, pi1 = west ? P : g.nx + 1, pj0 = south ? 1 : g.ny + 2 - P, pj1 = south ? P : g.ny + 1;
+    launch3(c, s, Box{std::max(pi0, 1), pi1, std::max(pj0, 1), pj1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+      if (!deln_on(dd, k) || deln_nord(dd, k) == 0) return;
+      if ((g.flags[t] & need) != need) return;
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      if (j <= g.ny) fx2[p] = tfx[p];
+      if (i <= g.nx) fy2[p] = tfy[p];
+    });
+  };
+  patch(FV3_W | FV3_S, true, true);
+  patch(FV3_E | FV3_S, false, true);
+  patch(FV3_E | FV3_N, false, false);
+  patch(FV3_W | FV3_N, true, false);
+}
+
+static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+  const Geo g = c->g;
+  const Deln d = dn;
+  const int nk = k1 - k0 + 1;
+  const int nstrip = (g.nx + 1 + D6_OUT - 1) / D6_OUT, nseg = (g.ny + D6_SEG - 1) / D6_SEG;
+  const size_t smem = sizeof(Real) * 2 * (D6_NMAX + 1) * (FV3_WAVE + 2);
+  const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const Real *del6_u = g.del6_u, *del6_v = g.del6_v, *rarea = g.rarea;
+  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+    if (!deln_on(d, k)) return;
+    const int nord = deln_nord(d, k);
+    const Real damp = deln_damp(d, k);
+    const long b = t * st + k * sk, m2 = t * st2;
+    const int i0 = 1 + blk.bx * D6_OUT;
+    const int ja = 1 + blk.by * D6_SEG;
+    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + D6_SEG - 1;
+    const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
+    Real *ld = (Real *)smem_ + 1;                         // ld[s * LW + lane]: d2_s of the lane's cell (read by lane + 1)
+    Real *lf = ld + (D6_NMAX + 1) * (FV3_WAVE + 2);       // lf[s * LW + lane]: fx_s of the lane's west face (read by lane - 1)
+    const int LW = FV3_WAVE + 2;
+    const Real *qq = q + b, *dub = del6_u + m2, *dvb = del6_v + m2, *rab = rarea + m2;
+    struct Row {
+      Real q, du, dv, ra;
+    };
+    Row pf[D6_PF][FV3_LPT];
+    Real du[D6_NMAX + 1][FV3_LPT], dv[D6_NMAX + 1][FV3_LPT], ra[D6_NMAX + 1][FV3_LPT];  // metrics of row r - s
+    Real d2p[D6_NMAX + 1][FV3_LPT], fxp[D6_NMAX + 1][FV3_LPT], fxe[D6_NMAX + 1][FV3_LPT], fyp[D6_NMAX + 1][FV3_LPT];
+    Real d2c[D6_NMAX + 1][FV3_LPT], fxc[D6_NMAX + 1][FV3_LPT], fyc[D6_NMAX + 1][FV3_LPT];
+    unsigned pcol[FV3_LPT];
+    bool own_x[FV3_LPT], own_y[FV3_LPT];
+    int r_beg = ja - 1 - nord, r_end = jb + nord;
+    if (r_beg < jsd) r_beg = jsd;
+    if (r_end > jed) r_end = jed;
+    auto load_row = [&](int r, int l) -> Row {
+      const unsigned p0 = pcol[l] + (unsigned)(r * sj32);
+      Row w;
+      w.q = qq[p0];
+      w.du = dub[p0];
+      w.dv = dvb[p0];
+      w.ra = rab[p0];
+      return w;
+    };
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own_x[l] = i >= i0 && i < i0 + D6_OUT && i <= nx + 1;
+      own_y[l] = i >= i0 && i < i0 + D6_OUT && i <= nx;
+#pragma unroll
+      for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
+        du[s_][l] = dv[s_][l] = ra[s_][l] = d2p[s_][l] = fxp[s_][l] = fxe[s_][l] = fyp[s_][l] = (Real)0;
+        d2c[s_][l] = fxc[s_][l] = fyc[s_][l] = (Real)0;
+        if (lane == 0) {
+          ld[s_ * LW - 1] = (Real)0;
+          lf[s_ * LW + FV3_WAVE] = (Real)0;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < D6_PF; ++n) pf[n][l] = load_row(r_beg + n < r_end ? r_beg + n : r_end, l);
+    }
+    for (int r = r_beg; r <= r_end; ++r) {
+      const int rn = r + D6_PF < r_end ? r + D6_PF : r_end;
+      // ---- phase A: d2 of every iteration on its row, y-fluxes (own lane)
+      FV3_LANES(blk, lane, l) {
+        const Row cu = pf[0][l];
+#pragma unroll
+        for (int n = 0; n + 1 < D6_PF; ++n) pf[n][l] = pf[n + 1][l];
+        pf[D6_PF - 1][l] = load_row(rn, l);
+#pragma unroll
+        for (int s_ = D6_NMAX; s_ >= 1; --s_) {
+          du[s_][l] = du[s_ - 1][l];
+          dv[s_][l] = dv[s_ - 1][l];
+          ra[s_][l] = ra[s_ - 1][l];
+        }
+        du[0][l] = cu.du;
+        dv[0][l] = cu.dv;
+        ra[0][l] = cu.ra;
+        d2c[0][l] = q_raw ? cu.q : damp * cu.q;
+        fyc[0][l] = du[0][l] * (d2p[0][l] - d2c[0][l]);
+        ld[lane] = d2c[0][l];
+#pragma unroll
+        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+          if (s_ <= nord) {
+            d2c[s_][l] = (fxp[s_ - 1][l] - fxe[s_ - 1][l] + fyp[s_ - 1][l] - fyc[s_ - 1][l]) * ra[s_][l];
+            fyc[s_][l] = du[s_][l] * (d2c[s_][l] - d2p[s_][l]);
+            ld[s_ * LW + lane] = d2c[s_][l];
+          }
+        }
+      }
+      blk.wave_sync();
+      // ---- phase B: x-fluxes from the west neighbour's d2
+      FV3_LANES(blk, lane, l) {
+        fxc[0][l] = dv[0][l] * (ld[lane - 1] - d2c[0][l]);
+        lf[lane] = fxc[0][l];
+#pragma unroll
+        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+          if (s_ <= nord) {
+            fxc[s_][l] = dv[s_][l] * (d2c[s_][l] - ld[s_ * LW + lane - 1]);
+            lf[s_ * LW + lane] = fxc[s_][l];
+          }
+        }
+      }
+      blk.wave_sync();
+      // ---- phase C: east neighbour's x-flux for the next step; final fluxes of the last iteration
+      const int jo = r - nord;
+      const bool fx_row = jo >= ja && jo <= jb && jo <= ny, fy_row = jo >= ja && jo <= jb;
+      FV3_LANES(blk, lane, l) {
+#pragma unroll
+        for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
+          if (s_ <= nord) {
+            fxe[s_][l] = lf[s_ * LW + lane + 1];
+            fxp[s_][l] = fxc[s_][l];
+            fyp[s_][l] = fyc[s_][l];
+            d2p[s_][l] = d2c[s_][l];
+          }
+        }
+        const unsigned p = pcol[l] + (unsigned)(jo * sj32);
+        Real ox = fxc[0][l], oy = fyc[0][l];
+#pragma unroll
+        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+          if (s_ == nord) {
+            ox = fxc[s_][l];
+            oy = fyc[s_][l];
+          }
+        }
+        if (fx_row && own_x[l]) (fx2 + b)[p] = ox;
+        if (fy_row && own_y[l]) (fy2 + b)[p] = oy;
+      }
+      blk.wave_sync();
+    }
+  });
+  if (dn.nord_max > 0) del6_corner_patches(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
+}
+
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
-  static const bool staged = getenv("FV3_DEL6_STAGED") != nullptr;  // A/B switch for profiling
-  if (staged) {
+  // FV3_DEL6_MODE = staged | tile | stream (default): A/B switch for profiling
+  static const char *mode_env = getenv("FV3_DEL6_MODE");
+  static const int mode = !mode_env ? 2 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "tile") ? 1 : 2));
+  if (mode == 0) {
     del6_vt_flux_staged(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1, nullptr);
+    return;
+  }
+  if (mode == 2 && dn.nord_max <= D6_NMAX) {
+    del6_stream(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
     return;
   }
   const Geo g = c->g;
