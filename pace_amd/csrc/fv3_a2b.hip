@@ -19,8 +19,8 @@ namespace {
 struct A2B {
   Geo g;
   const Real *q;    // level base of qin for this (t, k)
-  const Real *dxa;  // metric planes for this t
-  const Real *dya;
+  MPtr dxa;  // metric planes for this t
+  MPtr dya;
   bool W, E, S, N;
 
   FV3_HD Real Q(int i, int j) const { return q[IX(i, j)]; }
@@ -279,7 +279,7 @@ void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int k
     (out + t * g.st + (k + kshift) * g.sk)[IX(i, j)] = a2b_point(g, q, t, i, j);
   });
   if (replace) {
-    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    launch3<4>(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       qin[p] = out[p];
     });

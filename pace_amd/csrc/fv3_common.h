@@ -44,6 +44,12 @@ typedef FV3_REAL Real;
 #define FV3_N 8
 
 // Geometry + metric terms, captured by value in every stage lambda.
+// 2-D metric terms (immutable after context creation).  Addressing them through the constant
+// address space (address_space(4)) lets the compiler hoist them out of the level loop of launch3,
+// but it then hoists ALL of them at once: the metric-heavy kernels (c_sw B/D, fxadv, the KE kernel)
+// went to 155-256 VGPRs and ran 1.5-4x slower on MI355X, so the plain generic pointer stays.
+typedef const Real *MPtr;
+
 struct Geo {
   int nx, ny, nz, nh, nsub;
   int npx, npy;
@@ -53,11 +59,11 @@ struct Geo {
   long sj, sk, st;  // strides of 3-D fields: j, k, sub
   long st2;         // sub stride of 2-D fields
   unsigned char flags[FV3_MAX_SUB];
-  const Real *dx, *dy, *dxa, *dya, *dxc, *dyc, *rdx, *rdy, *rdxa, *rdya, *rdxc, *rdyc;
-  const Real *area, *rarea, *area_c, *rarea_c;
-  const Real *cosa, *sina, *rsina, *cosa_u, *cosa_v, *cosa_s, *sina_u, *sina_v, *rsin_u, *rsin_v, *rsin2;
-  const Real *sin_sg1, *sin_sg2, *sin_sg3, *sin_sg4, *cos_sg1, *cos_sg2, *cos_sg3, *cos_sg4;
-  const Real *fC, *f0, *del6_u, *del6_v, *divg_u, *divg_v;
+  MPtr dx, dy, dxa, dya, dxc, dyc, rdx, rdy, rdxa, rdya, rdxc, rdyc;
+  MPtr area, rarea, area_c, rarea_c;
+  MPtr cosa, sina, rsina, cosa_u, cosa_v, cosa_s, sina_u, sina_v, rsin_u, rsin_v, rsin2;
+  MPtr sin_sg1, sin_sg2, sin_sg3, sin_sg4, cos_sg1, cos_sg2, cos_sg3, cos_sg4;
+  MPtr fC, f0, del6_u, del6_v, divg_u, divg_v;
   const Real *edge_w, *edge_e, *edge_s, *edge_n;
   const Real *corner_extrap;  // [nsub][4][3]
   const Real *dp_ref, *pfull; // [nz]
@@ -137,25 +143,69 @@ Real *fv3_chk(fv3_ctx *c, const fv3_field *f, const char *name, bool is2d = fals
 // launch: f(t, k, i, j) over a box for every sub-domain; f2(t, i, j) for column kernels
 // ---------------------------------------------------------------------------------------------
 #ifndef FV3_HOST_EMU
-template <class F>
-__global__ void __launch_bounds__(256) fv3_k3(Box b, int nk, F f) {
-  const int i = b.i0 + (int)(blockIdx.x * 64 + threadIdx.x);
-  const int j = b.j0 + (int)(blockIdx.y * 4 + threadIdx.y);
-  const int kz = (int)blockIdx.z;
-  const int t = kz / nk;
-  const int k = b.k0 + (kz - t * nk);
-  if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+// XCD-aware workgroup order.  The 8 XCDs of an MI355X take workgroups round-robin in linear
+// dispatch order, and each XCD has its own L2.  Kernels are launched on a grid
+// (8, tiles-per-plane, ceil(planes / 8)): blockIdx.x is then exactly the XCD a workgroup lands on,
+// every XCD walks the tiles of its OWN (sub-domain, level) plane in order, and the rows / columns
+// neighbouring tiles share are served by that XCD's L2 instead of being fetched once per XCD.
+struct GridMap {
+  int gx;       // tiles per plane along i
+  float rgx;    // 1 / gx  (tile index -> (bx, by) without an integer division)
+  int nplanes;  // sub-domains * levels
+};
+__device__ inline bool fv3_tile(const GridMap &m, int &bx, int &by, int &bz) {
+  bz = (int)(blockIdx.z * 8 + blockIdx.x);
+  if (bz >= m.nplanes) return false;
+  const int y = (int)blockIdx.y;
+  by = (int)(((float)y + 0.5f) * m.rgx);
+  bx = y - by * m.gx;
+  return true;
+}
+// KCH = levels walked by one thread.  1 for stencil kernels (a level loop makes the compiler hoist
+// every level-invariant index / metric expression at once: the big stencils went to 155-256 VGPRs
+// and ran up to 4x slower on MI355X); 4 for trivially pointwise kernels, where fewer, longer
+// workgroups stream ~25% faster.
+template <int KCH, class F>
+__global__ void __launch_bounds__(256) fv3_k3(Box b, int nkc, GridMap m, F f) {
+  int bx, by, kz;
+  if (!fv3_tile(m, bx, by, kz)) return;
+  const int i = b.i0 + (int)(bx * 64 + threadIdx.x);
+  const int j = b.j0 + (int)(by * 4 + threadIdx.y);
+  const int t = kz / nkc;
+  const int ka = b.k0 + (kz - t * nkc) * KCH;
+  if (i <= b.i1 && j <= b.j1) {
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+      const int k = ka + kk;
+      if (k > b.k1) break;
+      f(t, k, i, j);
+    }
+  }
 }
 template <class F>
-__global__ void __launch_bounds__(256) fv3_k2(Box b, F f) {
-  const int i = b.i0 + (int)(blockIdx.x * 64 + threadIdx.x);
-  const int j = b.j0 + (int)(blockIdx.y * 4 + threadIdx.y);
-  const int t = (int)blockIdx.z;
+__global__ void __launch_bounds__(256) fv3_k2(Box b, GridMap m, F f) {
+  int bx, by, t;
+  if (!fv3_tile(m, bx, by, t)) return;
+  const int i = b.i0 + (int)(bx * 64 + threadIdx.x);
+  const int j = b.j0 + (int)(by * 4 + threadIdx.y);
   if (i <= b.i1 && j <= b.j1) f(t, i, j);
+}
+// host side: grid + map for gx x gy tiles on nplanes planes (the float decode is checked once per shape)
+inline GridMap fv3_grid(int gx, int gy, int nplanes, dim3 *grid) {
+  GridMap m{gx, 1.0f / (float)gx, nplanes};
+  static thread_local int ok_gx = 0, ok_n = 0;
+  if (gx != ok_gx || gx * gy > ok_n) {
+    for (int y = 0; y < gx * gy; ++y)
+      if ((int)(((float)y + 0.5f) * m.rgx) != y / gx) abort();
+    ok_gx = gx;
+    ok_n = gx * gy;
+  }
+  *grid = dim3(8, gx * gy, (nplanes + 7) / 8);
+  return m;
 }
 #endif
 
-template <class F>
+template <int KCH = 1, class F>
 inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
   const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nk = b.k1 - b.k0 + 1;
   if (ni <= 0 || nj <= 0 || nk <= 0) return;
@@ -168,9 +218,10 @@ inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
       for (int j = b.j0; j <= b.j1; ++j)
         for (int i = b.i0; i <= b.i1; ++i) f(t, k, i, j);
 #else
-  dim3 block(64, 4, 1);
-  dim3 grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nk);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3<F>), grid, block, 0, s, b, nk, f);
+  dim3 block(64, 4, 1), grid;
+  const int nkc = (nk + KCH - 1) / KCH;
+  const GridMap m = fv3_grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nkc, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3<KCH, F>), grid, block, 0, s, b, nkc, m, f);
 #endif
 }
 
@@ -186,9 +237,9 @@ inline void launch2(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
     for (int j = b.j0; j <= b.j1; ++j)
       for (int i = b.i0; i <= b.i1; ++i) f(t, i, j);
 #else
-  dim3 block(64, 4, 1);
-  dim3 grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k2<F>), grid, block, 0, s, b, f);
+  dim3 block(64, 4, 1), grid;
+  const GridMap m = fv3_grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k2<F>), grid, block, 0, s, b, m, f);
 #endif
 }
 
@@ -220,9 +271,11 @@ struct Blk {
 
 #ifndef FV3_HOST_EMU
 template <class F>
-__global__ void __launch_bounds__(256, 2) fv3_kb(F f) {
+__global__ void __launch_bounds__(256, 2) fv3_kb(GridMap m, F f) {
   extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
-  Blk b{(int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  int bx, by, bz;
+  if (!fv3_tile(m, bx, by, bz)) return;
+  Blk b{(int)threadIdx.x, (int)blockDim.x, bx, by, bz};
   f(b, fv3_smem);
 }
 #endif
@@ -247,7 +300,9 @@ inline void launch_blocks(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int 
   }
 #else
   (void)c;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kb<F>), dim3(gx, gy, gz), dim3(nthr, 1, 1), smem_bytes, s, f);
+  dim3 grid;
+  const GridMap m = fv3_grid(gx, gy, gz, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kb<F>), grid, dim3(nthr, 1, 1), smem_bytes, s, m, f);
 #endif
 }
 
@@ -269,9 +324,11 @@ inline void launch_blocks(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int 
 #define FV3_LANES(blk, lane, l) for (int lane = (blk).tid, l = 0; l < 1; ++l)
 // WPE = waves per SIMD the register allocation is sized for (512 / WPE VGPRs per lane)
 template <int WPE, class F>
-__global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) fv3_kw(F f) {
+__global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) fv3_kw(GridMap m, F f) {
   extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
-  Blk b{(int)threadIdx.x, FV3_WAVE, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  int bx, by, bz;
+  if (!fv3_tile(m, bx, by, bz)) return;
+  Blk b{(int)threadIdx.x, FV3_WAVE, bx, by, bz};
   f(b, fv3_smem);
 }
 #endif
@@ -283,7 +340,9 @@ inline void launch_waves(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int g
   launch_blocks(c, s, gx, gy, gz, FV3_WAVE, smem_bytes, f);
 #else
   (void)c;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kw<WPE, F>), dim3(gx, gy, gz), dim3(FV3_WAVE, 1, 1), smem_bytes, s, f);
+  dim3 grid;
+  const GridMap m = fv3_grid(gx, gy, gz, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kw<WPE, F>), grid, dim3(FV3_WAVE, 1, 1), smem_bytes, s, m, f);
 #endif
 }
 

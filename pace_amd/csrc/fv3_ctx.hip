@@ -189,7 +189,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   g.st2 = g.sk;
   for (int t = 0; t < g.nsub; ++t) g.flags[t] = (unsigned char)(spec->edge_flags[t] & 15);
 #define CP(n)                                                              \
-  g.n = (const Real *)grid->n;                                             \
+  g.n = (decltype(g.n))grid->n;                                            \
   if (!g.n) {                                                              \
     delete c;                                                              \
     return fv3_fail(nullptr, FV3_ERR_ARG, "griddata." #n " is null");      \
@@ -309,7 +309,7 @@ int fv3_ctx_set_device_sync(fv3_ctx *c, int on) {
 int fv3_copy(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, void *stream) {
   FV3_FIELD(a, src) FV3_FIELD(b, dst)
   const Geo g = c->g;
-  launch3(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+  launch3<4>(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
     const long p = t * g.st + k * g.sk + IX(i, j);
     b[p] = a[p];
   });
@@ -319,7 +319,7 @@ int fv3_copy(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, void *strea
 int fv3_zero(fv3_ctx *c, const fv3_field *dst, void *stream) {
   FV3_FIELD(b, dst)
   const Geo g = c->g;
-  launch3(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+  launch3<4>(c, (fv3_stream_t)stream, Box{-g.o, g.ni - 1 - g.o, -g.o, g.nj - 1 - g.o, 0, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
     b[t * g.st + k * g.sk + IX(i, j)] = (Real)0;
   });
   return fv3_post(c, (fv3_stream_t)stream, "zero");

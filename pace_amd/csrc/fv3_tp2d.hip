@@ -162,7 +162,7 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
   const size_t smem = sizeof(Real) * 2 * (D6_NMAX + 1) * (FV3_WAVE + 2);
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
-  const Real *del6_u = g.del6_u, *del6_v = g.del6_v, *rarea = g.rarea;
+  const MPtr del6_u = g.del6_u, del6_v = g.del6_v, rarea = g.rarea;
   launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
     if (!deln_on(d, k)) return;
@@ -176,7 +176,8 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
     Real *ld = (Real *)smem_ + 1;                         // ld[s * LW + lane]: d2_s of the lane's cell (read by lane + 1)
     Real *lf = ld + (D6_NMAX + 1) * (FV3_WAVE + 2);       // lf[s * LW + lane]: fx_s of the lane's west face (read by lane - 1)
     const int LW = FV3_WAVE + 2;
-    const Real *qq = q + b, *dub = del6_u + m2, *dvb = del6_v + m2, *rab = rarea + m2;
+    const Real *qq = q + b;
+    const MPtr dub = del6_u + m2, dvb = del6_v + m2, rab = rarea + m2;
     struct Row {
       Real q, du, dv, ra;
     };
@@ -812,7 +813,7 @@ static void tp2d_fused_level(fv3_ctx *c, fv3_stream_t s, const Real *q, const Re
     Real *sqi = sfx2 + (TP_TI + 1) * TP_EH;   // [TJ][EW]
     Real *sqj = sqi + TP_EW * TP_TJ;          // [EH][TI]
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
-    const Real *areab = g.area + m2, *dxab = g.dxa + m2, *dyab = g.dya + m2;
+    const MPtr areab = g.area + m2, dxab = g.dxa + m2, dyab = g.dya + m2;
     // tile-level edge flags: the one-sided PPM formulas only exist within 3 faces of a tile edge,
     // so most workgroups take the branch-free interior form
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TP_TI + 1 >= g.npx - 1;
@@ -943,7 +944,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   const Geo *gp = c->g_dev;
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
-  const Real *area = g.area;
+  const MPtr area = g.area;
   launch_waves<2>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
     const int fl = gp->flags[t];
@@ -957,7 +958,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     Real *exp_ = lqi + TS_LINE;       // xfx * fx_in of the lane (read by lane - 1)
     Real *exx = exp_ + FV3_WAVE + 1;  // xfx
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
-    const Real *areab = area + m2;
+    const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
     const bool S = fl & FV3_S, N = fl & FV3_N;
     const bool halo_cols = i0 - 3 < 1 || i0 + FV3_WAVE - 4 > nx;
@@ -1051,7 +1052,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           w5[l] = qy;
           Real al_new;
           if (y_edge) {
-            const Real *dyab = gp->dya + m2;
+            const MPtr dyab = gp->dya + m2;
             auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
             al_new = ppm_al_win(w2[l], w3[l], w4[l], w5[l], My, sy, S, N, npy);
           } else {
@@ -1079,7 +1080,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           Real fxin, fxout;
           if (XE) {
             const int i = i0 - 3 + lane;
-            const Real *dxab = gp->dxa + m2;
+            const MPtr dxab = gp->dxa + m2;
             auto Qx = [&](int s_) { return lq[s_ - i0 + 6]; };
             auto Mx = [&](int s_) { return dxab[(unsigned)((r + go) * sj32 + s_ + go)]; };
             fxin = ppm_flux(Qx, Mx, cx, i, W, E, npx, hord);
@@ -1124,7 +1125,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           v5[l] = qj;
           Real al_new;
           if (y_edge) {
-            const Real *dyab = gp->dya + m2;
+            const MPtr dyab = gp->dya + m2;
             auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
             al_new = ppm_al_win(v2[l], v3[l], v4[l], v5[l], My, sy, S, N, npy);
           } else {

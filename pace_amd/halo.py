@@ -117,6 +117,14 @@ class HaloExchanger:
         self._phases: Dict[Tuple[str, int], _Phase] = {}
         self._buffers: Dict[Tuple, torch.Tensor] = {}
         self.comm_stream = comm_stream
+        # gloo cannot move device memory: with a gloo group and device-resident fields the packed
+        # messages are staged through pinned host buffers (used to exercise the multi-process
+        # path on a single-GPU box; RCCL takes the device buffers directly)
+        self.host_staged = False
+        if layout.world_size > 1 and torch.device(sf.device).type == "cuda":
+            import torch.distributed as dist
+
+            self.host_staged = dist.get_backend(group) == "gloo"
 
     # ------------------------------------------------------------------------------------------
     def _maps(self, key, rank) -> GatherMap:
@@ -183,10 +191,13 @@ class HaloExchanger:
         self._phases[pkey] = ph
         return ph
 
-    def _buffer(self, tag, n):
-        k = (tag, n)
+    def _buffer(self, tag, n, host=False):
+        k = (tag, n, host)
         if k not in self._buffers:
-            self._buffers[k] = torch.empty(n, dtype=self.sf.dtype, device=self.sf.device)
+            if host:
+                self._buffers[k] = torch.empty(n, dtype=self.sf.dtype, pin_memory=True)
+            else:
+                self._buffers[k] = torch.empty(n, dtype=self.sf.dtype, device=self.sf.device)
         return self._buffers[k]
 
     # ------------------------------------------------------------------------------------------
@@ -228,14 +239,19 @@ class HaloUpdater:
             for peer, cnt in ph.recv_count.items():
                 buf = ex._buffer(("r", id(self), peer), cnt * self.nk * len(self.groups))
                 self._recv_bufs[peer] = buf
-                ops.append(dist.P2POp(dist.irecv, buf, peer, group=ex.group))
+                wire = ex._buffer(("r", id(self), peer), buf.numel(), host=True) if ex.host_staged else buf
+                ops.append(dist.P2POp(dist.irecv, wire, peer, group=ex.group))
             for peer, cnt in ph.send_count.items():
                 buf = ex._buffer(("s", id(self), peer), cnt * self.nk * len(self.groups))
                 for gi, gp in enumerate(self.groups):
                     base = buf.data_ptr() + gi * cnt * self.nk * buf.element_size()
                     for comp, plan in ph.send[peer].items():
                         plan.run(base, cnt, gp[comp].storage.data_ptr(), ex.sk, self.nk, stream)
-                ops.append(dist.P2POp(dist.isend, buf, peer, group=ex.group))
+                wire = buf
+                if ex.host_staged:
+                    wire = ex._buffer(("s", id(self), peer), buf.numel(), host=True)
+                    wire.copy_(buf)  # synchronous device -> host copy, ordered after the pack kernels
+                ops.append(dist.P2POp(dist.isend, wire, peer, group=ex.group))
             if ops:
                 # NCCL/RCCL p2p ops order themselves after the work already enqueued on the
                 # current stream (the pack kernels above) and wait() orders the unpack after them.
@@ -255,6 +271,8 @@ class HaloUpdater:
         stream = self._stream()
         for peer, cnt in ph.recv_count.items():
             buf = self._recv_bufs[peer]
+            if ex.host_staged:
+                buf.copy_(ex._buffer(("r", id(self), peer), buf.numel(), host=True))
             for gi, gp in enumerate(self.groups):
                 base = buf.data_ptr() + gi * cnt * self.nk * buf.element_size()
                 for comp, plan in ph.recv[peer].items():

@@ -2,6 +2,8 @@
 (global mass conservation, determinism / statelessness, no allocation at call time -- the
 reference's dycore-call invariants [REF tests/main/fv3core/test_dycore_call.py:149-211]) and
 the fp32 build against fp64."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -84,3 +86,24 @@ def test_fp32_build_tracks_fp64(gpu_backend):
         assert torch.isfinite(b).all()
         err = float((a - b).abs().max() / a.abs().max())
         assert err < tol, (n, err)
+
+
+@pytest.mark.gpu
+def test_two_process_decomposition_is_bitwise_identical(tmp_path):
+    """The same C48 cube stepped by one process and by two processes (6 sub-domains split 3 + 3,
+    messages over gloo staged through pinned host memory because the box has one GPU; the 8-GPU
+    bench uses RCCL with the identical pack / unpack plans) must give bitwise equal fields."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "multi_gpu_check.py")
+    env = dict(os.environ, FV3_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    w1, w2 = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
+    subprocess.run([sys.executable, tool, "--out", w1], check=True, env=env, timeout=600)
+    subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533", tool,
+         "--backend", "gloo", "--out", w2],
+        check=True, env=env, timeout=600,
+    )
+    subprocess.run([sys.executable, tool, "--compare", w1, w2], check=True, timeout=60)

@@ -17,11 +17,11 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"fv3_k[23b]<(.*?)::\{lambda.*?#(\d+)\}", name)
+    m = re.search(r"fv3_k[23bw]<(?:\d+, )?(.*?)::\{lambda.*?#(\d+)\}", name)
     if m:
-        fn = re.sub(r"\(.*\)", "", m.group(1)).replace("(anonymous namespace)::", "")
+        fn = re.sub(r"\(.*\)", "", m.group(1).replace("(anonymous namespace)::", ""))
         return f"{fn}#{m.group(2)}"
-    m = re.search(r"fv3_k[23b]<Z*L?\d*([A-Za-z_0-9]+)\(", name)
+    m = re.search(r"fv3_k[23bw]<(?:\d+, )?Z*L?\d*([A-Za-z_0-9]+)\(", name)
     if m:
         return m.group(1)
     return re.sub(r"\(.*", "", name)[:60]
@@ -39,7 +39,20 @@ def load(path, counter):
     return per
 
 
-def main(fetch_csv, write_csv, top=40, copy_bytes=None):
+def window(path, counter, first, last):
+    """Sum of the counter over the dispatches from the first launch of kernel `first` to the last
+    launch of kernel `last` (one operator call, e.g. fxadv .. fv3_d_sw#14 = one fv3_d_sw)."""
+    rows = [(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort()
+    a = next((d for d, n, _ in rows if n.startswith(first)), None)
+    z = max((d for d, n, _ in rows if n.startswith(last)), default=None)
+    if a is None or z is None:
+        return None, 0
+    sel = [v for d, n, v in rows if a <= d <= z]
+    return sum(sel), len(sel)
+
+
+def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, json_out=None):
     rd = load(fetch_csv, "FETCH_SIZE")
     wr = load(write_csv, "WRITE_SIZE")
     names = sorted(set(rd) | set(wr), key=lambda n: -(rd.get(n, [0, 0, 0])[2]))
@@ -52,6 +65,18 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None):
         raw_w = wr[c][1] / wr[c][0] * kb
         rs, ws = copy_bytes / raw_r, copy_bytes / raw_w
         print(f"calibration on {c}: known {copy_bytes / 1e6:.1f} MB each way per launch; raw FETCH_SIZE {raw_r / 1e6:.1f} MB (scale {rs:.3f}), raw WRITE_SIZE {raw_w / 1e6:.1f} MB (scale {ws:.3f})\n")
+    if first and last:
+        r, n1 = window(fetch_csv, "FETCH_SIZE", first, last)
+        w, n2 = window(write_csv, "WRITE_SIZE", first, last)
+        if r is not None and w is not None:
+            print(f"operator window {first} .. {last}: {n1} launches, read {r * kb * rs / 1e9:.2f} GB, write {w * kb * ws / 1e9:.2f} GB, "
+                  f"total {(r * kb * rs + w * kb * ws) / 1e9:.2f} GB (corrected)\n")
+            if json_out:
+                import json
+
+                json.dump({"window": [first, last], "launches": n1, "read_bytes": r * kb * rs, "write_bytes": w * kb * ws, "bytes": r * kb * rs + w * kb * ws,
+                           "read_scale": rs, "write_scale": ws, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"},
+                          open(json_out, "w"))
     print("| kernel | calls | avg ms (pmc run) | read GB/launch | write GB/launch | GB/s |")
     print("|---|---:|---:|---:|---:|---:|")
     for n in names[:top]:
@@ -67,4 +92,5 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40, float(sys.argv[4]) if len(sys.argv) > 4 else None)
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40, float(sys.argv[4]) if len(sys.argv) > 4 else None,
+         sys.argv[5] if len(sys.argv) > 5 else None, sys.argv[6] if len(sys.argv) > 6 else None, sys.argv[7] if len(sys.argv) > 7 else None)
