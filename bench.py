@@ -15,7 +15,7 @@ Extra objects on the JSON line:
                local cells / mean HIP-event duration of the call, vs 8 TB/s HBM peak
   cpu_baseline the numpy oracle on one host core on a bounded sample (a C48 L79 cube, a few acoustic
                sub-steps), scaled per cell to the C768 step -- baseline only
-  operators    per-operator mean milliseconds per acoustic sub-step (HIP events)
+  operators    per-operator mean milliseconds per acoustic sub-step (HIP events recorded by fv3_acoustic_step)
 """
 import argparse
 import json
@@ -108,37 +108,10 @@ def main():
     dtype = torch.float64 if a.precision == 64 else torch.float32
     h = DycoreHarness(world_size=world, proc=rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), **kw)
 
-    # ---- per-operator HIP-event timing (events on the stream the kernels are launched on)
-    op_events = {}
+    # ---- per-operator HIP-event timing: fv3_acoustic_step brackets every operator with an event
+    #      pair on the stream it launches on (fv3_ctx_set_profiling / fv3_profile_read)
     if not a.no_op_timing:
-        ops = {
-            "c_sw": "cgrid_shallow_water_lagrangian_dynamics",
-            "update_dz_c": "update_geopotential_height_on_c_grid",
-            "riem_solver_c": "vertical_solver_cgrid",
-            "p_grad_c": "_p_grad_c",
-            "d_sw": "dgrid_shallow_water_lagrangian_dynamics",
-            "update_dz_d": "update_height_on_d_grid",
-            "riem_solver3": "vertical_solver",
-            "nh_p_grad": "nonhydrostatic_pressure_gradient",
-            "ray_fast": "_rayleigh_damping",
-        }
-
-        def wrap(name, fn):
-            ev = op_events.setdefault(name, [])
-
-            def inner(*args, **kwargs):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = fn(*args, **kwargs)
-                e1.record()
-                ev.append((e0, e1))
-                return out
-
-            return inner
-
-        for name, attr in ops.items():
-            setattr(h.dyn, attr, wrap(name, getattr(h.dyn, attr)))
+        h.sf.set_profiling(True)
 
     def barrier():
         if world > 1:
@@ -150,8 +123,8 @@ def main():
     for _ in range(a.warmup):
         h.step()
     barrier()
-    for ev in op_events.values():
-        ev.clear()
+    if not a.no_op_timing:
+        h.sf.profile(reset=True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         h.step()
@@ -171,9 +144,12 @@ def main():
         n_sub_steps = cfg.k_split * cfg.n_split
         sdpd = cfg.dt_atmos / s_per_step
         op_ms = {}
-        for name, ev in op_events.items():
-            if ev:
-                op_ms[name] = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        if not a.no_op_timing:
+            for name, (ms, calls) in h.sf.profile(reset=True).items():
+                if name in ("glue", "halo", "diffusive_heating", "pk3_halo_edge_pe"):
+                    op_ms[name] = ms / (a.steps * n_sub_steps)  # several launches per sub-step: quote the sum per sub-step
+                else:
+                    op_ms[name] = ms / calls
         line = {
             "metric": "simulated-days/day + acoustic-step ms, C768 L79 fp64, 1/2/4/8 MI355X",
             "value": sdpd,

@@ -230,6 +230,65 @@ int fv3_gather_plan_destroy(fv3_gather_plan *);
 int fv3_gather_run(fv3_ctx *, const fv3_gather_plan *, void *dst, int64_t dst_kstride, const void *src,
                    int64_t src_kstride, int nk, void *stream);
 
+/* ---- whole acoustic call [REF AcousticDynamics.__call__; SURVEY §3.3] ----------------------------
+ * Temporaries AcousticDynamics owns (allocated by the host's QuantityFactory, borrowed here). */
+typedef struct {
+  fv3_field gz, zh, pkc, pk3;             /* interface fields (nz+1) */
+  fv3_field crx, cry, xfx, yfx;           /* Courant numbers / area fluxes of d_sw */
+  fv3_field divgd, ut, vt;                /* corner divergence, contravariant C-grid winds */
+  fv3_field delpc, ptc;                   /* c_sw outputs */
+  fv3_field dsw_delpc;                    /* d_sw work field (its "delpc" argument) */
+  fv3_field heat_source;
+  fv3_field ws3, wsd, zs;                 /* 2-D */
+} fv3_workspace;
+
+/* The 11 halo updaters of AcousticDynamics + the D-grid interface synchronisation. */
+enum fv3_halo_update {
+  FV3_HALO_Q_CON__CAPPA = 0,
+  FV3_HALO_DELP__PT,
+  FV3_HALO_U__V,
+  FV3_HALO_W,
+  FV3_HALO_GZ,
+  FV3_HALO_DIVGD,
+  FV3_HALO_UC__VC,
+  FV3_HALO_DELP__PT__Q_CON,
+  FV3_HALO_ZH,
+  FV3_HALO_PKC,
+  FV3_HALO_HEAT_SOURCE,
+  FV3_HALO_INTERFACE_U__V,
+  FV3_HALO_COUNT
+};
+/* Host-provided transport: phase 0 = start (pack + post), 1 = wait (complete + unpack), both
+ * enqueued on `stream`.  Returns 0 on success.  The library never moves halos on its own. */
+typedef int (*fv3_halo_fn)(void *user, int update /* fv3_halo_update */, int phase, void *stream);
+
+/* n_split acoustic sub-steps (+ the once-per-call diffusive heating when d_con > 1e-5);
+ * timestep = dt_atmos / k_split, n_map = 1..k_split. */
+int fv3_acoustic_step(fv3_ctx *, const fv3_state *state, const fv3_workspace *work, double timestep, int n_map,
+                      fv3_halo_fn halo, void *halo_user, void *stream);
+
+/* ---- per-operator timing (HIP events on the operators' stream) --------------------------------- */
+enum fv3_op {
+  FV3_OP_C_SW = 0,
+  FV3_OP_UPDATE_DZ_C,
+  FV3_OP_RIEM_SOLVER_C,
+  FV3_OP_P_GRAD_C,
+  FV3_OP_D_SW,
+  FV3_OP_UPDATE_DZ_D,
+  FV3_OP_RIEM_SOLVER3,
+  FV3_OP_PK3_HALO,
+  FV3_OP_NH_P_GRAD,
+  FV3_OP_RAY_FAST,
+  FV3_OP_DIFFUSIVE_HEATING,
+  FV3_OP_GLUE,
+  FV3_OP_HALO,
+  FV3_OP_COUNT
+};
+int fv3_ctx_set_profiling(fv3_ctx *, int on); /* record an event pair around every operator of fv3_acoustic_step */
+const char *fv3_op_name(int op);
+/* accumulated milliseconds and call counts per fv3_op (arrays of FV3_OP_COUNT); waits for the events */
+int fv3_profile_read(fv3_ctx *, double *ms_sum, int64_t *calls, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,20 @@ class StencilFactory:
         if st != 0:
             raise _lib.Fv3Error(f"fv3_{name} failed ({st}): {self.lib.fv3_last_error(self._ctx).decode()}")
 
+    def set_profiling(self, on: bool):
+        """HIP-event pairs around every operator of ``fv3_acoustic_step`` (read with ``profile()``)."""
+        self.lib.fv3_ctx_set_profiling(self._ctx, int(on))
+
+    def profile(self, reset: bool = True):
+        """{operator: (total ms, calls)} accumulated since the last reset; waits for the recorded events."""
+        n = len(_lib.OP_NAMES)
+        ms = (C.c_double * n)()
+        calls = (C.c_int64 * n)()
+        st = self.lib.fv3_profile_read(self._ctx, ms, calls, int(reset))
+        if st != 0:
+            raise _lib.Fv3Error(f"fv3_profile_read failed ({st})")
+        return {name: (float(ms[i]), int(calls[i])) for i, name in enumerate(_lib.OP_NAMES) if calls[i]}
+
     def set_device_sync(self, on: bool):
         self.lib.fv3_ctx_set_device_sync(self._ctx, int(on))
 

@@ -112,6 +112,15 @@ struct fv3_ctx {
   double rf_dt = 0.0, rf_ptop = 0.0, rf_dm = 0.0;
   int rf_nd = 0, rf_nn = 0;
   std::string err;
+  // per-operator profiling (fv3_step.hip)
+  int profiling = 0;
+  struct ProfEvent {
+    int op;
+    void *e0, *e1;
+  };
+  std::vector<ProfEvent> prof_events;
+  double prof_ms[16] = {0};
+  int64_t prof_n[16] = {0};
 };
 
 struct fv3_gather_plan {
@@ -172,13 +181,18 @@ __global__ void __launch_bounds__(256) fv3_k3(Box b, int nkc, GridMap m, F f) {
   const int i = b.i0 + (int)(bx * 64 + threadIdx.x);
   const int j = b.j0 + (int)(by * 4 + threadIdx.y);
   const int t = kz / nkc;
-  const int ka = b.k0 + (kz - t * nkc) * KCH;
-  if (i <= b.i1 && j <= b.j1) {
+  if constexpr (KCH == 1) {
+    const int k = b.k0 + (kz - t * nkc);
+    if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+  } else {
+    const int ka = b.k0 + (kz - t * nkc) * KCH;
+    if (i <= b.i1 && j <= b.j1) {
 #pragma unroll
-    for (int kk = 0; kk < KCH; ++kk) {
-      const int k = ka + kk;
-      if (k > b.k1) break;
-      f(t, k, i, j);
+      for (int kk = 0; kk < KCH; ++kk) {
+        const int k = ka + kk;
+        if (k > b.k1) break;
+        f(t, k, i, j);
+      }
     }
   }
 }

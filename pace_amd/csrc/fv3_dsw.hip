@@ -240,6 +240,236 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
   return fv3_post(c, (fv3_stream_t)stream, "fxadv");
 }
 
+// ---------------------------------------------------------------------------------------------
+// divergence damping: the nord-fold Laplacian-type iteration of the corner divergence.
+// Staged form (two launches per iteration, in place on divgd, uc / vc as work arrays exactly like
+// the reference); `win` restricts every launch to a window (results exact >= 4 points inside an
+// artificial window boundary) -- used for the cube-corner patches of the marching form.
+// ---------------------------------------------------------------------------------------------
+static inline Box dd_clip(Box a, const Box *w) {
+  if (!w) return a;
+  Box r = a;
+  r.i0 = std::max(a.i0, w->i0);
+  r.i1 = std::min(a.i1, w->i1);
+  r.j0 = std::max(a.j0, w->j0);
+  r.j1 = std::min(a.j1, w->j1);
+  return r;
+}
+
+static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Box *win) {
+  const Geo g = c->g;
+  const int nz1 = k1;
+  for (int n = 1; n <= nord_max; ++n) {
+    const int ntm = nord_max - n;
+    // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
+    launch3(c, s, dd_clip(Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, k0, nz1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+      const int nord = g.nord[k];
+      if (n > nord) return;
+      const int nt = nord - n;
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const Real *dg = divgd + b;
+      const bool fill = nt != 0;
+      if (i >= 1 - 1 - nt && i <= g.nx + 1 + nt && j >= 1 - nt && j <= g.ny + 1 + nt) {
+        const Real a = fill ? dg[bc_index<1>(g, fl, i + 1, j)] : dg[IX(i + 1, j)];
+        const Real e = fill ? dg[bc_index<1>(g, fl, i, j)] : dg[IX(i, j)];
+        (vc + b)[IX(i, j)] = (a - e) * (g.divg_u + m2)[IX(i, j)];
+      }
+      if (i >= 1 - nt && i <= g.nx + 1 + nt && j >= 1 - 1 - nt && j <= g.ny + 1 + nt) {
+        const Real a = fill ? dg[bc_index<2>(g, fl, i, j + 1)] : dg[IX(i, j + 1)];
+        const Real e = fill ? dg[bc_index<2>(g, fl, i, j)] : dg[IX(i, j)];
+        (uc + b)[IX(i, j)] = (a - e) * (g.divg_v + m2)[IX(i, j)];
+      }
+    });
+    launch3(c, s, dd_clip(Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, k0, nz1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+      const int nord = g.nord[k];
+      if (n > nord) return;
+      const int nt = nord - n;
+      if (i < 1 - nt || i > g.nx + 1 + nt || j < 1 - nt || j > g.ny + 1 + nt) return;
+      const int fl = g.flags[t];
+      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+      const int npx = g.npx, npy = g.npy;
+      const bool fill = nt != 0;
+      const Real *x = vc + b, *y = uc + b;
+      auto UCR = [&](int ii, int jj) { return fill ? dg_y(x, y, g, fl, ii, jj, (Real)-1) : y[IX(ii, jj)]; };
+      auto VCR = [&](int ii, int jj) { return fill ? dg_x(x, y, g, fl, ii, jj, (Real)-1) : x[IX(ii, jj)]; };
+      Real d = UCR(i, j - 1) - UCR(i, j) + VCR(i - 1, j) - VCR(i, j);
+      if (W && S && i == 1 && j == 1) d -= UCR(1, 0);
+      if (E && S && i == npx && j == 1) d -= UCR(npx, 0);
+      if (E && N && i == npx && j == npy) d += UCR(npx, npy);
+      if (W && N && i == 1 && j == npy) d += UCR(1, npy);
+      (divgd + b)[IX(i, j)] = d * (g.rarea_c + m2)[IX(i, j)];
+    });
+  }
+}
+
+// Marching form (see fv3_tp2d.hip).  A wave owns 58 corner columns and walks j; iteration n runs
+// n rows behind the row being loaded and keeps a 3-row window of its input (with the i-neighbours
+// of the middle row) in registers; one LDS line per iteration passes the freshly produced row to
+// the neighbouring lanes.  divgd is read once, the damped divergence is written once to `out`.
+// The cube-corner terms / halo remaps are not tile-local: an 8 x 8 patch per corner is recomputed
+// with the staged form on a private copy and overwrites the marching result.
+#define DD_OUT 58
+#define DD_SEG 64
+#define DD_NMAX 3
+#define DD_PF 2
+#define DD_PATCH 8
+
+static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
+  const Geo g = c->g;
+  const int nk = k1 - k0 + 1;
+  const int nstrip = (g.nx + 1 + DD_OUT - 1) / DD_OUT, nseg = (g.ny + 1 + DD_SEG - 1) / DD_SEG;
+  const int LW = FV3_WAVE + 2;
+  const size_t smem = sizeof(Real) * DD_NMAX * LW;
+  const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const int *nord_k = g.nord;
+  const MPtr divg_u = g.divg_u, divg_v = g.divg_v, rarea_c = g.rarea_c;
+  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+    const int nord = nord_k[k];
+    if (nord == 0) return;
+    const long b = t * st + k * sk, m2 = t * st2;
+    const int i0 = 1 + blk.bx * DD_OUT;
+    const int ja = 1 + blk.by * DD_SEG;
+    const int jb = ja + DD_SEG - 1 < ny + 1 ? ja + DD_SEG - 1 : ny + 1;
+    const int imax = nx + nh + 1, jsd = 1 - nh, jmax = ny + nh + 1;  // last stored corner column / row
+    Real *ld = (Real *)smem_ + 1;  // ld[(n) * LW + lane]: row produced by iteration n (n = 0: the loaded row)
+    const Real *dq = divgd + b;
+    const MPtr dub = divg_u + m2, dvb = divg_v + m2, rab = rarea_c + m2;
+    struct Row {
+      Real d, du, dum, dv, ra;
+    };
+    Row pf[DD_PF][FV3_LPT];
+    // window of the input of iteration n (n = 1..nord): rows rho-1 (a), rho (bL bC bR), rho+1 (cL cC cR)
+    Real wa[DD_NMAX][FV3_LPT], wbL[DD_NMAX][FV3_LPT], wbC[DD_NMAX][FV3_LPT], wbR[DD_NMAX][FV3_LPT];
+    Real wcL[DD_NMAX][FV3_LPT], wcC[DD_NMAX][FV3_LPT], wcR[DD_NMAX][FV3_LPT];
+    Real ucp[DD_NMAX][FV3_LPT];  // uc of iteration n at row rho-1
+    // metrics of row r - n (delay lines), index 0 = row being loaded
+    Real mdu[DD_NMAX + 1][FV3_LPT], mdum[DD_NMAX + 1][FV3_LPT], mdv[DD_NMAX + 1][FV3_LPT], mra[DD_NMAX + 1][FV3_LPT];
+    Real newrow[DD_NMAX][FV3_LPT];
+    unsigned pcol[FV3_LPT];
+    bool own[FV3_LPT];
+    int r_beg = ja - nord, r_end = jb + nord;
+    if (r_beg < jsd) r_beg = jsd;
+    if (r_end > jmax) r_end = jmax;
+    auto load_row = [&](int r, int l) -> Row {
+      const unsigned p0 = pcol[l] + (unsigned)(r * sj32);
+      Row w;
+      w.d = dq[p0];
+      w.du = dub[p0];
+      w.dum = dub[p0 - (p0 != 0u)];
+      w.dv = dvb[p0];
+      w.ra = rab[p0];
+      return w;
+    };
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 3 + lane, ic = i < imax ? i : imax;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own[l] = i >= i0 && i < i0 + DD_OUT && i <= nx + 1;
+#pragma unroll
+      for (int n = 0; n < DD_NMAX; ++n) {
+        wa[n][l] = wbL[n][l] = wbC[n][l] = wbR[n][l] = wcL[n][l] = wcC[n][l] = wcR[n][l] = ucp[n][l] = newrow[n][l] = (Real)0;
+        if (lane == 0) {
+          ld[n * LW - 1] = (Real)0;
+          ld[n * LW + FV3_WAVE] = (Real)0;
+        }
+      }
+#pragma unroll
+      for (int n = 0; n <= DD_NMAX; ++n) mdu[n][l] = mdum[n][l] = mdv[n][l] = mra[n][l] = (Real)0;
+#pragma unroll
+      for (int n = 0; n < DD_PF; ++n) pf[n][l] = load_row(r_beg + n < r_end ? r_beg + n : r_end, l);
+    }
+    for (int r = r_beg; r <= r_end; ++r) {
+      const int rn = r + DD_PF < r_end ? r + DD_PF : r_end;
+      // ---- phase A: the new row of every iteration (own lane): iteration n produces row r - n
+      FV3_LANES(blk, lane, l) {
+        const Row cu = pf[0][l];
+#pragma unroll
+        for (int n = 0; n + 1 < DD_PF; ++n) pf[n][l] = pf[n + 1][l];
+        pf[DD_PF - 1][l] = load_row(rn, l);
+#pragma unroll
+        for (int n = DD_NMAX; n >= 1; --n) {
+          mdu[n][l] = mdu[n - 1][l];
+          mdum[n][l] = mdum[n - 1][l];
+          mdv[n][l] = mdv[n - 1][l];
+          mra[n][l] = mra[n - 1][l];
+        }
+        mdu[0][l] = cu.du;
+        mdum[0][l] = cu.dum;
+        mdv[0][l] = cu.dv;
+        mra[0][l] = cu.ra;
+        newrow[0][l] = cu.d;
+        ld[lane] = cu.d;
+      }
+      blk.wave_sync();
+#pragma unroll
+      for (int n = 1; n <= DD_NMAX; ++n) {
+        if (n <= nord) {
+          // the row produced by iteration n-1 at this step enters the window of iteration n as row c
+          FV3_LANES(blk, lane, l) {
+            wa[n - 1][l] = wbC[n - 1][l];
+            wbL[n - 1][l] = wcL[n - 1][l];
+            wbC[n - 1][l] = wcC[n - 1][l];
+            wbR[n - 1][l] = wcR[n - 1][l];
+            wcL[n - 1][l] = ld[(n - 1) * LW + lane - 1];
+            wcC[n - 1][l] = newrow[n - 1][l];
+            wcR[n - 1][l] = ld[(n - 1) * LW + lane + 1];
+            // iteration n on row rho = r - n (window middle row b), metrics of that row = delay n
+            const Real ucc = (wcC[n - 1][l] - wbC[n - 1][l]) * mdv[n][l];    // uc(i, rho)
+            const Real vcm = (wbC[n - 1][l] - wbL[n - 1][l]) * mdum[n][l];   // vc(i-1, rho)
+            const Real vcc = (wbR[n - 1][l] - wbC[n - 1][l]) * mdu[n][l];    // vc(i, rho)
+            const Real dn_ = (ucp[n - 1][l] - ucc + vcm - vcc) * mra[n][l];
+            ucp[n - 1][l] = ucc;
+            if (n < DD_NMAX) {
+              newrow[n][l] = dn_;
+              ld[n * LW + lane] = dn_;
+            }
+            if (n == nord) {
+              const int jo = r - n;
+              if (jo >= ja && jo <= jb && own[l]) (out + b)[pcol[l] + (unsigned)(jo * sj32)] = dn_;
+            }
+          }
+          blk.wave_sync();
+        }
+      }
+    }
+  });
+  // cube-corner patches
+  int any = 0;
+  for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
+  const int *nk_ = g.nord;
+  auto patch = [&](int need, bool west, bool south) {
+    if ((any & need) != need) return;
+    const int P = DD_PATCH, M = 4;
+    Box w;
+    w.i0 = west ? -3 : g.nx + 1 - P - M;
+    w.i1 = west ? P + M : g.nx + 5;
+    w.j0 = south ? -3 : g.ny + 1 - P - M;
+    w.j1 = south ? P + M : g.ny + 5;
+    w.k0 = k0;
+    w.k1 = k1;
+    // private copy of the window (the staged form works in place)
+    launch3(c, s, dd_clip(Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, &w), [=] FV3_HD(int t, int k, int i, int j) {
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      tmp[p] = divgd[p];
+    });
+    divdamp_staged(c, s, tmp, uc, vc, nord_max, k0, k1, &w);
+    const int pi0 = west ? 1 : g.nx + 2 - P, pi1 = west ? P : g.nx + 1, pj0 = south ? 1 : g.ny + 2 - P, pj1 = south ? P : g.ny + 1;
+    launch3(c, s, Box{std::max(pi0, 1), pi1, std::max(pj0, 1), pj1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+      if (nk_[k] == 0) return;
+      if ((g.flags[t] & need) != need) return;
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      out[p] = tmp[p];
+    });
+  };
+  patch(FV3_W | FV3_S, true, true);
+  patch(FV3_E | FV3_S, false, true);
+  patch(FV3_E | FV3_N, false, false);
+  patch(FV3_W | FV3_N, true, false);
+}
+
 extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,
                         const fv3_field *w_, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_,
                         const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
@@ -441,48 +671,16 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     (vdamp + b)[p] = vd;
     (ke + b)[p] += vd;
   });
-  for (int n = 1; n <= nord_max; ++n) {
-    const int ntm = nord_max - n;
-    // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
-    launch3(c, s, Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-      const int nord = g.nord[k];
-      if (n > nord) return;
-      const int nt = nord - n;
-      const int fl = g.flags[t];
-      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-      const Real *dg = divgd + b;
-      const bool fill = nt != 0;
-      if (i >= 1 - 1 - nt && i <= g.nx + 1 + nt && j >= 1 - nt && j <= g.ny + 1 + nt) {
-        const Real a = fill ? dg[bc_index<1>(g, fl, i + 1, j)] : dg[IX(i + 1, j)];
-        const Real e = fill ? dg[bc_index<1>(g, fl, i, j)] : dg[IX(i, j)];
-        (vc + b)[IX(i, j)] = (a - e) * (g.divg_u + m2)[IX(i, j)];
-      }
-      if (i >= 1 - nt && i <= g.nx + 1 + nt && j >= 1 - 1 - nt && j <= g.ny + 1 + nt) {
-        const Real a = fill ? dg[bc_index<2>(g, fl, i, j + 1)] : dg[IX(i, j + 1)];
-        const Real e = fill ? dg[bc_index<2>(g, fl, i, j)] : dg[IX(i, j)];
-        (uc + b)[IX(i, j)] = (a - e) * (g.divg_v + m2)[IX(i, j)];
-      }
-    });
-    launch3(c, s, Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-      const int nord = g.nord[k];
-      if (n > nord) return;
-      const int nt = nord - n;
-      if (i < 1 - nt || i > g.nx + 1 + nt || j < 1 - nt || j > g.ny + 1 + nt) return;
-      const int fl = g.flags[t];
-      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-      const int npx = g.npx, npy = g.npy;
-      const bool fill = nt != 0;
-      const Real *x = vc + b, *y = uc + b;
-      auto UCR = [&](int ii, int jj) { return fill ? dg_y(x, y, g, fl, ii, jj, (Real)-1) : y[IX(ii, jj)]; };
-      auto VCR = [&](int ii, int jj) { return fill ? dg_x(x, y, g, fl, ii, jj, (Real)-1) : x[IX(ii, jj)]; };
-      Real d = UCR(i, j - 1) - UCR(i, j) + VCR(i - 1, j) - VCR(i, j);
-      if (W && S && i == 1 && j == 1) d -= UCR(1, 0);
-      if (E && S && i == npx && j == 1) d -= UCR(npx, 0);
-      if (E && N && i == npx && j == npy) d += UCR(npx, npy);
-      if (W && N && i == 1 && j == npy) d += UCR(1, npy);
-      (divgd + b)[IX(i, j)] = d * (g.rarea_c + m2)[IX(i, j)];
-    });
+  // divergence-damping iteration: divgd -> dnew (levels with nord > 0)
+  Real *dnew = divgd;
+  {
+    static const bool staged_dd = getenv("FV3_DIVDAMP_STAGED") != nullptr;  // A/B switch for profiling
+    if (staged_dd || nord_max > DD_NMAX) {
+      divdamp_staged(c, s, divgd, uc, vc, nord_max, 0, nz1, nullptr);
+    } else if (nord_max > 0) {
+      dnew = c->scratch[SC_L];
+      divdamp_stream(c, s, divgd, dnew, uc, vc, c->scratch[SC_M], nord_max, 0, nz1);
+    }
   }
   // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
   Real *wkb = c->scratch[SC_DN_FX];
@@ -496,7 +694,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     Real vo = (Real)0;
     if ((Real)cf.dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + (wkb + b)[p] * (wkb + b)[p]);
     const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * vo));
-    const Real vd = damp2 * dpc + tab.dd8[k] * (divgd + b)[p];
+    const Real dn_ = (dnew + b)[p];
+    (divgd + b)[p] = dn_;  // (no-op for the in-place staged form)
+    const Real vd = damp2 * dpc + tab.dd8[k] * dn_;
     (vdamp + b)[p] = vd;
     (ke + b)[p] += vd;
   });

@@ -1,0 +1,184 @@
+// fv3_step.hip -- fv3_acoustic_step: the sequencing of AcousticDynamics.__call__ behind one C entry
+// (n_split sub-steps: c_sw, update_dz_c, riem_solver_c, p_grad_c, d_sw, update_dz_d, riem_solver3,
+// pk3_halo / edge_pe, nh_p_grad, ray_fast, then the once-per-call diffusive heating), with the 11
+// halo updates requested through a host callback (the host owns the transport: device-local gather
+// plans + RCCL point-to-point).  Python twin: pace_amd/dyn_core.py (same order, used when a
+// checkpointer is attached).  [SURVEY §3.3, §8 a1 / b; reference AcousticDynamics.__call__]
+//
+// Also here: per-operator timing with HIP events recorded on the stream the operators run on
+// (fv3_ctx_set_profiling / fv3_profile_read) -- what bench.py reports per operator.
+#include <chrono>
+
+#include "fv3_ops.h"
+
+namespace {
+
+struct OpTimer {
+  fv3_ctx *c;
+  fv3_stream_t s;
+  int id;
+  bool on;
+#ifdef FV3_HOST_EMU
+  std::chrono::steady_clock::time_point t0;
+#else
+  hipEvent_t e0, e1;
+#endif
+  OpTimer(fv3_ctx *c_, fv3_stream_t s_, int id_) : c(c_), s(s_), id(id_), on(c_->profiling != 0) {
+    if (!on) return;
+#ifdef FV3_HOST_EMU
+    t0 = std::chrono::steady_clock::now();
+#else
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+#endif
+  }
+  ~OpTimer() {
+    if (!on) return;
+#ifdef FV3_HOST_EMU
+    c->prof_ms[id] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->prof_n[id] += 1;
+#else
+    (void)hipEventRecord(e1, s);
+    c->prof_events.push_back({id, (void *)e0, (void *)e1});
+#endif
+  }
+};
+
+}  // namespace
+
+extern "C" int fv3_ctx_set_profiling(fv3_ctx *c, int on) {
+  if (!c) return FV3_ERR_ARG;
+  c->profiling = on;
+  return FV3_OK;
+}
+
+extern "C" const char *fv3_op_name(int op) {
+  static const char *names[FV3_OP_COUNT] = {"c_sw", "update_dz_c", "riem_solver_c", "p_grad_c", "d_sw", "update_dz_d", "riem_solver3",
+                                            "pk3_halo_edge_pe", "nh_p_grad", "ray_fast", "diffusive_heating", "glue", "halo"};
+  return op >= 0 && op < FV3_OP_COUNT ? names[op] : "";
+}
+
+extern "C" int fv3_profile_read(fv3_ctx *c, double *ms_sum, int64_t *calls, int reset) {
+  if (!c || !ms_sum || !calls) return FV3_ERR_ARG;
+#ifndef FV3_HOST_EMU
+  for (auto &e : c->prof_events) {
+    hipEvent_t e0 = (hipEvent_t)e.e0, e1 = (hipEvent_t)e.e1;
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+      c->prof_ms[e.op] += ms;
+      c->prof_n[e.op] += 1;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  c->prof_events.clear();
+#endif
+  for (int i = 0; i < FV3_OP_COUNT; ++i) {
+    ms_sum[i] = c->prof_ms[i];
+    calls[i] = c->prof_n[i];
+    if (reset) {
+      c->prof_ms[i] = 0.0;
+      c->prof_n[i] = 0;
+    }
+  }
+  return FV3_OK;
+}
+
+#define RUN(op, call)                   \
+  do {                                  \
+    OpTimer tm_(c, s, op);              \
+    const int st_ = (call);             \
+    if (st_ != FV3_OK) return st_;      \
+  } while (0)
+#define HALO(id, phase)                                                                                  \
+  do {                                                                                                   \
+    OpTimer tm_(c, s, FV3_OP_HALO);                                                                      \
+    const int st_ = halo(halo_user, id, phase, stream);                                                  \
+    if (st_ != 0) return fv3_fail(c, FV3_ERR_ARG, "acoustic_step: the halo callback reported an error"); \
+  } while (0)
+
+extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_workspace *ws, double timestep, int n_map, fv3_halo_fn halo, void *halo_user,
+                                 void *stream) {
+  if (!c || !st || !ws) return FV3_ERR_ARG;
+  if (!halo) return fv3_fail(c, FV3_ERR_ARG, "acoustic_step: a halo-exchange callback is required (sub-domain halos are never implicit)");
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const fv3_acoustic_config &cf = c->cfg;
+  const int n_split = cf.n_split;
+  const double dt = timestep / n_split, dt2 = 0.5 * dt;
+  const double ptop = c->ptop, akap = c->cst.rdgas / c->cst.cp_air;
+
+  HALO(FV3_HALO_Q_CON__CAPPA, 0);
+  HALO(FV3_HALO_DELP__PT, 0);
+  HALO(FV3_HALO_U__V, 0);
+  HALO(FV3_HALO_Q_CON__CAPPA, 1);
+  if (n_map == 1) {
+    RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfxd, stream));
+    RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfyd, stream));
+    RUN(FV3_OP_GLUE, fv3_zero(c, &st->cxd, stream));
+    RUN(FV3_OP_GLUE, fv3_zero(c, &st->cyd, stream));
+  }
+  RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
+  RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
+  for (int it = 0; it < n_split; ++it) {
+    const int remap_step = it == n_split - 1;
+    HALO(FV3_HALO_W, 0);
+    if (it == 0) {
+      RUN(FV3_OP_GLUE, fv3_set_gz(c, &ws->zs, &st->delz, &ws->gz, stream));
+      HALO(FV3_HALO_GZ, 0);
+      HALO(FV3_HALO_DELP__PT, 1);
+    }
+    HALO(FV3_HALO_U__V, 1);
+    HALO(FV3_HALO_W, 1);
+    RUN(FV3_OP_C_SW, fv3_c_sw(c, &st->delp, &st->pt, &st->u, &st->v, &st->w, &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
+                              &ws->delpc, &ws->ptc, dt2, stream));
+    if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 0);
+    if (it == 0) {
+      HALO(FV3_HALO_GZ, 1);
+      RUN(FV3_OP_GLUE, fv3_copy(c, &ws->gz, &ws->zh, stream));
+    } else {
+      RUN(FV3_OP_GLUE, fv3_copy(c, &ws->zh, &ws->gz, stream));
+    }
+    RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c(c, &ws->zs, &ws->ut, &ws->vt, &ws->gz, &ws->ws3, dt2, stream));
+    RUN(FV3_OP_RIEM_SOLVER_C,
+        fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &st->q_con, &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
+    RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
+    HALO(FV3_HALO_UC__VC, 0);
+    if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 1);
+    HALO(FV3_HALO_UC__VC, 1);
+    RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &st->delp, &st->pt, &st->u, &st->v, &st->w, &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
+                              &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &st->q_con, &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+    HALO(FV3_HALO_DELP__PT__Q_CON, 0);
+    HALO(FV3_HALO_DELP__PT__Q_CON, 1);
+    RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
+    RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &st->q_con, &st->delp, &st->pt, &ws->zh, &st->pe,
+                                              &ws->pkc, &ws->pk3, &st->pk, &st->peln, &st->w, stream));
+    HALO(FV3_HALO_ZH, 0);
+    HALO(FV3_HALO_PKC, 0);
+    if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &st->delp, ptop, stream));
+    RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &st->delp, ptop, akap, stream));
+    HALO(FV3_HALO_ZH, 1);
+    RUN(FV3_OP_GLUE, fv3_compute_geopotential(c, &ws->zh, &ws->gz, stream));
+    HALO(FV3_HALO_PKC, 1);
+    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad(c, &st->u, &st->v, &ws->pkc, &ws->gz, &ws->pk3, &st->delp, dt, ptop, akap, stream));
+    if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &st->w, dt, ptop, stream));
+    if (it != n_split - 1) {
+      HALO(FV3_HALO_U__V, 0);
+    } else {
+      HALO(FV3_HALO_INTERFACE_U__V, 0);
+      HALO(FV3_HALO_INTERFACE_U__V, 1);
+    }
+  }
+  if (cf.d_con > 1.0e-5) {
+    HALO(FV3_HALO_HEAT_SOURCE, 0);
+    HALO(FV3_HALO_HEAT_SOURCE, 1);
+    const double cd = 0.20 * c->g.da_min;
+    int nmax = cf.nord + 1;
+    if (nmax > 3) nmax = 3;
+    RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_del2_cubed(c, &ws->heat_source, cd, nmax, stream));
+    const double delt = dt * cf.delt_max;
+    RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_apply_diffusive_heating(c, &st->delp, &st->delz, &st->cappa, &ws->heat_source, &st->pt, delt < 0 ? -delt : delt, stream));
+  }
+  return FV3_OK;
+}

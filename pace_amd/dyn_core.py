@@ -93,6 +93,7 @@ class AcousticDynamics:
         self.qf = quantity_factory or stencil_factory.quantity_factory
         self.config = (config or stencil_factory.config).validate()
         self.checkpointer = checkpointer
+        self.native = True  # sequence the call with fv3_acoustic_step (C) rather than the Python twin below
         self.grid_data = grid_data
         c = stencil_factory.constants
         self.c = c
@@ -169,10 +170,62 @@ class AcousticDynamics:
             "zs": h.updater("cell", [(self._zs,)]),
         }
         self._state_id = id(state)
+        self._native_args = None
         phis = self._phis if self._phis is not None else state.phis
         self._phis = phis
         self._zs.storage.copy_(phis.storage * self.c.RGRAV)
         self._updaters["zs"].update()
+
+    # ------------------------------------------------------------------------------------------
+    def _build_native_args(self, state: DycoreState):
+        """fv3_state / fv3_workspace views + the halo callback for ``fv3_acoustic_step``."""
+        import ctypes as C
+
+        from . import lib as _lib
+
+        cs = self.cgrid_shallow_water_lagrangian_dynamics
+        st = _lib.fv3_state()
+        for n in _lib.STATE_FIELDS:
+            q = self._phis if n == "phis" else getattr(state, n)
+            setattr(st, n, q.field)
+        work = dict(gz=self._gz, zh=self._zh, pkc=self._pkc, pk3=self._pk3, crx=self._crx, cry=self._cry, xfx=self._xfx, yfx=self._yfx, divgd=self._divgd,
+                    ut=self._ut, vt=self._vt, delpc=cs.delpc, ptc=cs.ptc, dsw_delpc=self._vt_scratch, heat_source=self._heat_source, ws3=self._ws3,
+                    wsd=self._wsd, zs=self._zs)
+        ws = _lib.fv3_workspace()
+        for n in _lib.WORK_FIELDS:
+            setattr(ws, n, work[n].field)
+        ups = [self._updaters[n] for n in _lib.HALO_UPDATES]
+        errors = []
+
+        def halo(_user, update, phase, _stream):
+            try:
+                if phase == 0:
+                    ups[update].start()
+                else:
+                    ups[update].wait()
+                return 0
+            except Exception as e:  # never let an exception cross the C frame
+                errors.append(e)
+                return 1
+
+        self._native_args = (st, ws, _lib.fv3_halo_fn(halo), errors)
+
+    def _call_native(self, state: DycoreState, timestep: float, n_map: int):
+        import ctypes as C
+
+        if self._native_args is None:
+            self._build_native_args(state)
+        st, ws, cb, errors = self._native_args
+        sf = self.sf
+        rc = sf.lib.fv3_acoustic_step(sf.ctx, C.byref(st), C.byref(ws), float(timestep), int(n_map), cb, None, sf.stream_handle)
+        if errors:
+            e = errors.pop()
+            errors.clear()
+            raise e
+        if rc != 0:
+            from . import lib as _lib
+
+            raise _lib.Fv3Error(f"fv3_acoustic_step failed ({rc}): {sf.lib.fv3_last_error(sf.ctx).decode()}")
 
     def _checkpoint(self, name, **kw):
         if self.checkpointer is not None:
@@ -182,6 +235,11 @@ class AcousticDynamics:
     def __call__(self, state: DycoreState, timestep: float, n_map: int = 1, update_temporaries: bool = True):
         if self._updaters is None or self._state_id != id(state):
             self._bind(state)
+        # product path: the C sequencer (fv3_acoustic_step).  The Python sequence below is its twin,
+        # kept for checkpointed runs (per-operator savepoints) and selectable with native=False.
+        if self.native and self.checkpointer is None and update_temporaries and not self.config.breed_vortex_inline:
+            self._call_native(state, timestep, n_map)
+            return
         cfg, up, sf = self.config, self._updaters, self.sf
         n_split = cfg.n_split
         dt = timestep / n_split

@@ -71,6 +71,23 @@ class fv3_constants(C.Structure):
     _fields_ = [(n, C.c_double) for n in "radius omega grav rdgas rvgas cp_air dz_min pi seconds_per_day".split()]
 
 
+STATE_FIELDS = "u v w ua va uc vc delp delz pt pe pk peln pkz q_con omga cappa mfxd mfyd cxd cyd diss_estd phis".split()
+WORK_FIELDS = "gz zh pkc pk3 crx cry xfx yfx divgd ut vt delpc ptc dsw_delpc heat_source ws3 wsd zs".split()
+HALO_UPDATES = "q_con__cappa delp__pt u__v w gz divgd uc__vc delp__pt__q_con zh pkc heat_source interface_u__v".split()
+OP_NAMES = "c_sw update_dz_c riem_solver_c p_grad_c d_sw update_dz_d riem_solver3 pk3_halo_edge_pe nh_p_grad ray_fast diffusive_heating glue halo".split()
+
+
+class fv3_state(C.Structure):
+    _fields_ = [(n, fv3_field) for n in STATE_FIELDS]
+
+
+class fv3_workspace(C.Structure):
+    _fields_ = [(n, fv3_field) for n in WORK_FIELDS]
+
+
+# int (*fv3_halo_fn)(void *user, int update, int phase, void *stream)
+fv3_halo_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+
 P = C.POINTER
 F = P(fv3_field)
 _D = C.c_double
@@ -105,6 +122,10 @@ _PROTOS = {
     "fv3_copy": (C.c_int, [C.c_void_p, F, F, _S]),
     "fv3_zero": (C.c_int, [C.c_void_p, F, _S]),
     "fv3_compute_geopotential": (C.c_int, [C.c_void_p, F, F, _S]),
+    "fv3_acoustic_step": (C.c_int, [C.c_void_p, P(fv3_state), P(fv3_workspace), _D, _I, fv3_halo_fn, C.c_void_p, _S]),
+    "fv3_ctx_set_profiling": (C.c_int, [C.c_void_p, _I]),
+    "fv3_op_name": (C.c_char_p, [_I]),
+    "fv3_profile_read": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_int64), _I]),
     "fv3_gather_plan_create": (C.c_int, [C.c_void_p, P(C.c_void_p), C.c_int64, P(C.c_int64), P(C.c_int64), P(C.c_int8)]),
     "fv3_gather_plan_destroy": (C.c_int, [C.c_void_p]),
     "fv3_gather_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _I, _S]),
