@@ -1,5 +1,5 @@
 // fv3_ctx.hip -- context life cycle, argument validation, glue stencils, gather (halo) kernel.
-#include "fv3_common.h"
+#include "fv3_ops.h"
 
 std::string g_fv3_create_error;
 
@@ -266,7 +266,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     g.corner_extrap = upload(c, ce);
   }
   // scratch: full-layout 3-D work fields shared by the operators (never allocated at call time)
-  const int n_scratch = 20;
+  const int n_scratch = SC_COUNT;
   for (int s = 0; s < n_scratch; ++s) {
     Real *p = (Real *)fv3_dev_alloc(c, (size_t)g.st * g.nsub * sizeof(Real));
     if (!p) {

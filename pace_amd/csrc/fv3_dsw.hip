@@ -501,9 +501,14 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
 
   fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt);
 
-  // ---- air mass
+  // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
+  //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
+  Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
   Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
-  tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1);
+  {
+    const TpEpi e{dpn, nullptr, true};
+    tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
+  }
   launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long p = t * g.st + k * g.sk + IX(i, j);
     if (i >= 1 && i <= g.nx + 1) cx[p] += crx[p];
@@ -530,38 +535,30 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       (heat_s + b)[p] = hs;
     });
   }
-  tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1);
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk;
-    const unsigned p = IX(i, j);
-    (w + b)[p] = (delp + b)[p] * (w + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-  });
-
+  {
+    const TpEpi e{w_dp, delp, false};  // delp * w + div
+    tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
+  }
   // ---- condensate
   {
     Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-    tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1);
+    const TpEpi e{qc_dp, delp, false};
+    tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
+  }
+  // ---- potential temperature, then the divisions by the new air mass
+  {
+    const TpEpi e{pt_dp, delp, false};
+    tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk;
-    const unsigned p = IX(i, j);
-    (q_con + b)[p] = (delp + b)[p] * (q_con + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-  });
-
-  // ---- potential temperature, then the delp update and the divisions
-  tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1);
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk;
-    const unsigned p = IX(i, j);
-    const Real ra = g.rarea[t * g.st2 + p];
-    const Real ptn = (pt + b)[p] * (delp + b)[p] + ((gx + b)[p] - (gx + b)[IX(i + 1, j)] + (gy + b)[p] - (gy + b)[IX(i, j + 1)]) * ra;
-    const Real dpn = (delp + b)[p] + ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * ra;
-    (delp + b)[p] = dpn;
-    (pt + b)[p] = ptn / dpn;
-    Real wn = (w + b)[p] / dpn;
-    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + (dw + b)[p];
-    (w + b)[p] = wn;
-    (q_con + b)[p] = (q_con + b)[p] / dpn;
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    const Real dpnv = dpn[p];
+    delp[p] = dpnv;
+    pt[p] = pt_dp[p] / dpnv;
+    Real wn = w_dp[p] / dpnv;
+    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + dw[p];
+    w[p] = wn;
+    q_con[p] = qc_dp[p] / dpnv;
   });
 
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u) and cell-mean relative vorticity

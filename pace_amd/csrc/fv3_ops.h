@@ -23,7 +23,12 @@ enum {
   SC_J = 16,
   SC_K = 17,
   SC_L = 18,  // del-n corner windows (private fluxes)
-  SC_M = 19
+  SC_M = 19,
+  SC_N = 20,  // d_sw flux-form updates formed by the transport epilogues (delp_new, delp*w, delp*q_con, delp*pt)
+  SC_O = 21,
+  SC_P = 22,
+  SC_Q = 23,
+  SC_COUNT = 24
 };
 
 // Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]
@@ -42,9 +47,19 @@ FV3_HD inline int deln_nord(const Deln &d, int k) { return d.nord_k ? d.nord_k[k
 FV3_HD inline Real deln_damp(const Deln &d, int k) { return d.damp_k ? d.damp_k[k] : d.damp_u; }
 FV3_HD inline bool deln_on(const Deln &d, int k) { return d.on_k ? d.on_k[k] > d.on_thr : d.on_u; }
 
+// Optional epilogue of fv_tp_2d: the flux-form update the callers apply right after the transport,
+//   out = (mult ? mult * q : q) + (fx - fx[i+1] + fy - fy[j+1]) * rarea       on the compute cells,
+// formed in the transport kernel itself (the fluxes of the neighbouring faces are already in the
+// wave) instead of a second pass over fx / fy.  write_flux = false: fx / fy are not stored at all.
+struct TpEpi {
+  Real *out;
+  const Real *mult;
+  bool write_flux;
+};
+
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-          const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1);
+          const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi = nullptr);
 
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);

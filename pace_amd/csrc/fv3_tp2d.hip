@@ -925,7 +925,7 @@ static void tp2d_fused_level(fv3_ctx *c, fv3_stream_t s, const Real *q, const Re
 #define TS_PF 2  // rows fetched ahead of their use
 
 static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-                        const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
+                        const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   const Geo g = c->g;
   Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
   const bool damped = dn != nullptr;
@@ -937,7 +937,11 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   }
   const int nk = k1 - k0 + 1;
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT, nseg = (g.ny + TS_SEG - 1) / TS_SEG;
-  const size_t smem = sizeof(Real) * (2 * TS_LINE + 2 * (FV3_WAVE + 1));
+  const size_t smem = sizeof(Real) * (2 * TS_LINE + 3 * (FV3_WAVE + 1));
+  Real *epi_out = epi ? epi->out : nullptr;
+  const Real *epi_mult = epi ? epi->mult : nullptr;
+  const bool wflux = epi ? epi->write_flux : true;
+  const MPtr rarea = g.rarea;
   // The hot loop touches only these scalars; everything the rare paths need (cube-corner remaps,
   // tile-edge metric terms) is read through gp inside those paths, so it does not occupy SGPRs
   // (or spill lanes) across the march.
@@ -957,6 +961,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     Real *lqi = lq + TS_LINE;         // q_i three rows behind
     Real *exp_ = lqi + TS_LINE;       // xfx * fx_in of the lane (read by lane - 1)
     Real *exx = exp_ + FV3_WAVE + 1;  // xfx
+    Real *exf = exx + FV3_WAVE + 1;   // final fx of the lane's face (epilogue: read by lane - 1)
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
     const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
@@ -965,13 +970,18 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     const bool on = damped && deln_on(d, k);
     const Real damp = on ? deln_damp(d, k) : (Real)0;
     const int r_end = jb + 3 < jed ? jb + 3 : jed;
+    const bool need_mc = mass && (on || (epi_out && epi_mult == mass));  // mass(i, r-2): damping weight and / or epilogue multiplier
 
     // per-lane marching state
     struct Row {  // the inputs of one step, fetched TS_PF steps ahead of their use
       Real qy, cx, xv, ar, cy, yv, ar3;
-      Real mx, my, dx, dy, ma, mc;  // optional: mass fluxes, damping fluxes, mass(i-1, r-3), mass(i, r-2)
     };
+    // optional inputs consumed at the end of a step (mass fluxes, damping fluxes, mass(i-1, r-3), mass(i, r-2),
+    // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
+    // (loads return in order) leaves the prefetched rows in flight
+    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT];
     Real mb[FV3_LPT];  // mass(i, r-3) = mass(i, r-2) of the previous step
+    Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
     Real v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], v5[FV3_LPT], al_v[FV3_LPT];  // q_j likewise
@@ -994,21 +1004,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
       w.ar = areab[p0];
       w.cy = cryb[pf];
       w.yv = yfxb[pf];
-      const unsigned p3 = pcol[l] + (unsigned)(r3 * sj32);
-      w.ar3 = areab[p3];
-      w.mx = w.my = w.dx = w.dy = w.ma = w.mc = (Real)0;
-      if (mfx) {
-        w.mx = (mfx + b)[p3];
-        w.my = (mfy + b)[pf];
-      }
-      if (on) {
-        w.dx = (dfx + b)[p3];
-        w.dy = (dfy + b)[pf];
-        if (mass) {
-          w.ma = (mass + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
-          w.mc = (mass + b)[pf];
-        }
-      }
+      w.ar3 = areab[pcol[l] + (unsigned)(r3 * sj32)];
       return w;
     };
     FV3_LANES(blk, lane, l) {
@@ -1018,6 +1014,8 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
       own_y[l] = i >= i0 && i < i0 + TS_OUT && i <= nx;
       w2[l] = w3[l] = w4[l] = w5[l] = al_q[l] = v2[l] = v3[l] = v4[l] = v5[l] = al_v[l] = (Real)0;
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+      fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
+      if (lane == 0) exf[FV3_WAVE] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
@@ -1036,6 +1034,24 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
         const bool corner_row = halo_cols && (r < 1 || r > ny);
         // ---- phase 1: prefetch row r+2; inner y-flux at face r-2, q_i at row r-3
         FV3_LANES(blk, lane, l) {
+          {
+            const int rf = r - 2 < jsd ? jsd : r - 2;
+            const unsigned p3 = pcol[l] + (unsigned)(r3 * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
+            if (mfx) {
+              o_mx[l] = (mfx + b)[p3];
+              o_my[l] = (mfy + b)[pf];
+            }
+            if (on) {
+              o_dx[l] = (dfx + b)[p3];
+              o_dy[l] = (dfy + b)[pf];
+              if (mass) o_ma[l] = (mass + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
+            }
+            if (need_mc) o_mc[l] = (mass + b)[pf];
+            if (epi_out) {
+              era[l] = (rarea + m2)[p3];
+              if (epi_mult && epi_mult != mass) emu[l] = (epi_mult + b)[p3];
+            }
+          }
           cur[l] = nxt[l];
           nxt[l] = nx2[l];
           nx2[l] = load_row(rn, l);
@@ -1092,11 +1108,14 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
             fxin = ppm_flux_int(a[0], a[1], a[2], a[3], a[4], a[5], cx, hord);
             fxout = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord);
           }
-          if (fx_row && own_x[l]) {
-            const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
-            Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx ? cur[l].mx : xv3[l]);
-            if (on) v = mass ? v + (Real)0.5 * damp * (cur[l].ma + mb[l]) * cur[l].dx : v + cur[l].dx;
-            (fx + b)[p] = v;
+          {
+            Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx ? o_mx[l] : xv3[l]);
+            if (on) v = mass ? v + (Real)0.5 * damp * (o_ma[l] + mb[l]) * o_dx[l] : v + o_dx[l];
+            if (wflux && fx_row && own_x[l]) (fx + b)[pcol[l] + (unsigned)(jr * sj32)] = v;  // own lanes: ic == i
+            if (epi_out) {
+              fxk[l] = v;
+              exf[lane] = v;
+            }
           }
           fi3[l] = fi2[l];
           fi2[l] = fi1[l];
@@ -1135,13 +1154,22 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           al_v[l] = al_new;
           const Real fyout = ppm_face(cv[l], co, cur[l].cy);
           cv[l] = co;
-          if (fy_row && own_y[l]) {
-            const unsigned p = pcol[l] + (unsigned)(jf * sj32);
-            Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy ? cur[l].my : cur[l].yv);
-            if (on) v = mass ? v + (Real)0.5 * damp * (mb[l] + cur[l].mc) * cur[l].dy : v + cur[l].dy;
-            (fy + b)[p] = v;
+          {
+            Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy ? o_my[l] : cur[l].yv);
+            if (on) v = mass ? v + (Real)0.5 * damp * (mb[l] + o_mc[l]) * o_dy[l] : v + o_dy[l];
+            if (wflux && fy_row && own_y[l]) (fy + b)[pcol[l] + (unsigned)(jf * sj32)] = v;
+            if (epi_out) {
+              // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
+              if (fx_row && own_y[l]) {
+                const Real qc = w2[l];  // q(i, r-3)
+                const Real mu = epi_mult ? (epi_mult == mass ? mb[l] : emu[l]) : (Real)1;
+                const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
+                (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult ? mu * qc + dv_ : qc + dv_;
+              }
+              fyp[l] = v;
+            }
           }
-          mb[l] = cur[l].mc;
+          mb[l] = o_mc[l];
         }
         blk.wave_sync();
       }
@@ -1154,7 +1182,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 }
 
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-          const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
+          const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   // FV3_TP2D_MODE = staged | kwalk | level | stream (default): A/B switch for profiling
   static const char *mode_env = getenv("FV3_TP2D_MODE");
   static const int mode = !mode_env ? 3 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "kwalk") ? 1 : (!strcmp(mode_env, "level") ? 2 : 3)));
@@ -1164,8 +1192,21 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     tp2d_fused_kwalk(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
   else if (mode == 2)
     tp2d_fused_level(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
-  else
-    tp2d_stream(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
+  else {
+    tp2d_stream(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+    return;
+  }
+  if (epi) {  // the non-marching forms always store the fluxes; apply the update in a second pass
+    const Geo g = c->g;
+    Real *out = epi->out;
+    const Real *mult = epi->mult;
+    launch3(c, s, Box{1, g.nx, 1, g.ny, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long b = t * g.st + k * g.sk;
+      const unsigned p = IX(i, j);
+      const Real dv_ = ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+      (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
+    });
+  }
 }
 
 extern "C" int fv3_fv_tp_2d(fv3_ctx *c, const fv3_field *q_, const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_,
