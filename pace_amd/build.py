@@ -54,7 +54,7 @@ def build(precision: int = 64, hostemu: bool = False, force: bool = False, verbo
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     real = [] if precision == 64 else ["-DFV3_REAL=float"]
-    flags = (HOST_FLAGS if hostemu else HIP_FLAGS) + real
+    flags = (HOST_FLAGS if hostemu else HIP_FLAGS) + real + os.environ.get("FV3_EXTRA_FLAGS", "").split()
     cc = os.environ.get("CXX", "g++") if hostemu else HIPCC
     stamp = os.path.join(objdir, "stamp")
     dig = _digest(srcs + hdrs, flags)

@@ -48,7 +48,11 @@ typedef FV3_REAL Real;
 // address space (address_space(4)) lets the compiler hoist them out of the level loop of launch3,
 // but it then hoists ALL of them at once: the metric-heavy kernels (c_sw B/D, fxadv, the KE kernel)
 // went to 155-256 VGPRs and ran 1.5-4x slower on MI355X, so the plain generic pointer stays.
+#if defined(FV3_CONST_METRICS) && !defined(FV3_HOST_EMU)
+typedef const Real __attribute__((address_space(4))) * MPtr;
+#else
 typedef const Real *MPtr;
+#endif
 
 struct Geo {
   int nx, ny, nz, nh, nsub;
@@ -184,6 +188,14 @@ __global__ void __launch_bounds__(256) fv3_k3(Box b, int nkc, GridMap m, F f) {
   if constexpr (KCH == 1) {
     const int k = b.k0 + (kz - t * nkc);
     if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+  } else if constexpr (KCH == 2) {
+    // two levels per thread as straight-line code (no loop: nothing to hoist); with the metric
+    // terms in the constant address space the second body reuses the first one's metric reads
+    const int k = b.k0 + (kz - t * nkc) * 2;
+    if (i <= b.i1 && j <= b.j1) {
+      f(t, k, i, j);
+      if (k + 1 <= b.k1) f(t, k + 1, i, j);
+    }
   } else {
     const int ka = b.k0 + (kz - t * nkc) * KCH;
     if (i <= b.i1 && j <= b.j1) {
@@ -219,7 +231,10 @@ inline GridMap fv3_grid(int gx, int gy, int nplanes, dim3 *grid) {
 }
 #endif
 
-template <int KCH = 1, class F>
+#ifndef FV3_KCH_DEFAULT
+#define FV3_KCH_DEFAULT 1
+#endif
+template <int KCH = FV3_KCH_DEFAULT, class F>
 inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
   const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nk = b.k1 - b.k0 + 1;
   if (ni <= 0 || nj <= 0 || nk <= 0) return;
