@@ -142,7 +142,10 @@ struct FxAdv {
   }
 };
 
-void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt) {
+// cx / cy (optional): accumulated Courant numbers of the tracer sub-cycling, cx += crx, cy += cry on the
+// faces d_sw accumulates them (i in 1..nx+1 resp. j in 1..ny+1, all halo rows / columns)
+void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt, Real *cx,
+           Real *cy) {
   const Geo g = c->g;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   launch3(c, s, Box{isd, ied, jsd, jed, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -155,13 +158,16 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       (ut + b)[p] = utv;
       if (i >= 1 && i <= g.nx + 1) {
         const Real x = dt * utv;
+        Real cr;
         if (x > (Real)0) {
-          (crx + b)[p] = x * (g.rdxa + m2)[IX(i - 1, j)];
+          cr = x * (g.rdxa + m2)[IX(i - 1, j)];
           (xfx + b)[p] = (g.dy + m2)[p] * x * (g.sin_sg3 + m2)[IX(i - 1, j)];
         } else {
-          (crx + b)[p] = x * (g.rdxa + m2)[p];
+          cr = x * (g.rdxa + m2)[p];
           (xfx + b)[p] = (g.dy + m2)[p] * x * (g.sin_sg1 + m2)[p];
         }
+        (crx + b)[p] = cr;
+        if (cx) (cx + b)[p] += cr;
       }
     }
     if (j >= 0) {  // vt on isd..ied, js-1..je+3
@@ -169,13 +175,16 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       (vt + b)[p] = vtv;
       if (j >= 1 && j <= g.ny + 1) {
         const Real y = dt * vtv;
+        Real cr;
         if (y > (Real)0) {
-          (cry + b)[p] = y * (g.rdya + m2)[IX(i, j - 1)];
+          cr = y * (g.rdya + m2)[IX(i, j - 1)];
           (yfx + b)[p] = (g.dx + m2)[p] * y * (g.sin_sg4 + m2)[IX(i, j - 1)];
         } else {
-          (cry + b)[p] = y * (g.rdya + m2)[p];
+          cr = y * (g.rdya + m2)[p];
           (yfx + b)[p] = (g.dx + m2)[p] * y * (g.sin_sg2 + m2)[p];
         }
+        (cry + b)[p] = cr;
+        if (cy) (cy + b)[p] += cr;
       }
     }
   });
@@ -236,7 +245,7 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
                          const fv3_field *yfx_, const fv3_field *ut_, const fv3_field *vt_, double dt, void *stream) {
   if (!c) return FV3_ERR_ARG;
   FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_) FV3_FIELD(crx, crx_) FV3_FIELD(cry, cry_) FV3_FIELD(xfx, xfx_) FV3_FIELD(yfx, yfx_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_)
-  fxadv(c, (fv3_stream_t)stream, uc, vc, crx, cry, xfx, yfx, ut, vt, (Real)dt);
+  fxadv(c, (fv3_stream_t)stream, uc, vc, crx, cry, xfx, yfx, ut, vt, (Real)dt, nullptr, nullptr);
   return fv3_post(c, (fv3_stream_t)stream, "fxadv");
 }
 
@@ -499,23 +508,17 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     nord_max = std::max(nord_max, c->nord_h[k]);
   }
 
-  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt);
+  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy);
 
   // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
   //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
   Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
   Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
   {
-    const TpEpi e{dpn, nullptr, true};
+    // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
+    const TpEpi e{dpn, nullptr, true, mfx, mfy};
     tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
   }
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long p = t * g.st + k * g.sk + IX(i, j);
-    if (i >= 1 && i <= g.nx + 1) cx[p] += crx[p];
-    if (j >= 1 && j <= g.ny + 1) cy[p] += cry[p];
-    if (i >= 1 && i <= g.nx + 1 && j >= 1 && j <= g.ny) mfx[p] += fx[p];
-    if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny + 1) mfy[p] += fy[p];
-  });
 
   // ---- vertical velocity: del-n damping + heat, then transport with the mass fluxes
   {
@@ -536,18 +539,18 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     });
   }
   {
-    const TpEpi e{w_dp, delp, false};  // delp * w + div
+    const TpEpi e{w_dp, delp, false, nullptr, nullptr};  // delp * w + div
     tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
   // ---- condensate
   {
     Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-    const TpEpi e{qc_dp, delp, false};
+    const TpEpi e{qc_dp, delp, false, nullptr, nullptr};
     tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
   }
   // ---- potential temperature, then the divisions by the new air mass
   {
-    const TpEpi e{pt_dp, delp, false};
+    const TpEpi e{pt_dp, delp, false, nullptr, nullptr};
     tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {

@@ -51,10 +51,12 @@ FV3_HD inline bool deln_on(const Deln &d, int k) { return d.on_k ? d.on_k[k] > d
 //   out = (mult ? mult * q : q) + (fx - fx[i+1] + fy - fy[j+1]) * rarea       on the compute cells,
 // formed in the transport kernel itself (the fluxes of the neighbouring faces are already in the
 // wave) instead of a second pass over fx / fy.  write_flux = false: fx / fy are not stored at all.
+// acc_x / acc_y (optional): acc += flux on the owned faces (d_sw's mfx / mfy accumulation).
 struct TpEpi {
   Real *out;
   const Real *mult;
   bool write_flux;
+  Real *acc_x, *acc_y;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

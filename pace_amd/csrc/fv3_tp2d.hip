@@ -941,6 +941,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   Real *epi_out = epi ? epi->out : nullptr;
   const Real *epi_mult = epi ? epi->mult : nullptr;
   const bool wflux = epi ? epi->write_flux : true;
+  Real *acc_x = epi ? epi->acc_x : nullptr, *acc_y = epi ? epi->acc_y : nullptr;
   const MPtr rarea = g.rarea;
   // The hot loop touches only these scalars; everything the rare paths need (cube-corner remaps,
   // tile-edge metric terms) is read through gp inside those paths, so it does not occupy SGPRs
@@ -1111,7 +1112,11 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           {
             Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx ? o_mx[l] : xv3[l]);
             if (on) v = mass ? v + (Real)0.5 * damp * (o_ma[l] + mb[l]) * o_dx[l] : v + o_dx[l];
-            if (wflux && fx_row && own_x[l]) (fx + b)[pcol[l] + (unsigned)(jr * sj32)] = v;  // own lanes: ic == i
+            if (wflux && fx_row && own_x[l]) {
+              const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
+              (fx + b)[p] = v;
+              if (acc_x) (acc_x + b)[p] += v;
+            }
             if (epi_out) {
               fxk[l] = v;
               exf[lane] = v;
@@ -1157,7 +1162,11 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           {
             Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy ? o_my[l] : cur[l].yv);
             if (on) v = mass ? v + (Real)0.5 * damp * (mb[l] + o_mc[l]) * o_dy[l] : v + o_dy[l];
-            if (wflux && fy_row && own_y[l]) (fy + b)[pcol[l] + (unsigned)(jf * sj32)] = v;
+            if (wflux && fy_row && own_y[l]) {
+              const unsigned p = pcol[l] + (unsigned)(jf * sj32);
+              (fy + b)[p] = v;
+              if (acc_y) (acc_y + b)[p] += v;
+            }
             if (epi_out) {
               // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
               if (fx_row && own_y[l]) {
@@ -1200,11 +1209,16 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     const Geo g = c->g;
     Real *out = epi->out;
     const Real *mult = epi->mult;
-    launch3(c, s, Box{1, g.nx, 1, g.ny, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+    Real *ax = epi->acc_x, *ay = epi->acc_y;
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
       const unsigned p = IX(i, j);
-      const Real dv_ = ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-      (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
+      if (out && i <= g.nx && j <= g.ny) {
+        const Real dv_ = ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
+        (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
+      }
+      if (ax && j <= g.ny) (ax + b)[p] += (fx + b)[p];
+      if (ay && i <= g.nx) (ay + b)[p] += (fy + b)[p];
     });
   }
 }
