@@ -250,6 +250,130 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Corner kinetic energy, marching form (interior corners: no tile-edge formula within reach).
+// Lane = corner column, the wave walks j.  ytp_v runs from a 4-row register window of v two rows
+// behind the loaded row (shared edge values / cell reconstructions between consecutive faces);
+// xtp_u, ub and vb are evaluated on that same row with u exchanged through one LDS line.
+//   ke = 0.5 * (vb * ytp_v(vb, v) + ub * xtp_u(ub, u))
+// ---------------------------------------------------------------------------------------------
+#define KE_OUT 58
+#define KE_SEG 64
+#define KE_PF 2
+
+static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1) {
+  const Geo g = c->g;
+  const int nk = k1 - k0 + 1;
+  const int nstrip = (g.nx + 1 + KE_OUT - 1) / KE_OUT, nseg = (g.ny + 1 + KE_SEG - 1) / KE_SEG;
+  const size_t smem = sizeof(Real) * (FV3_WAVE + 6);
+  const Geo *gp = c->g_dev;
+  const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const MPtr cosa = g.cosa, rsina = g.rsina, rdx = g.rdx, rdy = g.rdy;
+  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+    const int fl = gp->flags[t];
+    const long b = t * st + k * sk, m2 = t * st2;
+    // corners of this sub-domain that take the interior formulas
+    const int ia = (fl & FV3_W) ? 4 : 1, ib = (fl & FV3_E) ? npx - 3 : nx + 1;
+    const int ja_ = (fl & FV3_S) ? 4 : 1, jb_ = (fl & FV3_N) ? npy - 3 : ny + 1;
+    const int i0 = 1 + blk.bx * KE_OUT;
+    int j0 = 1 + blk.by * KE_SEG, j1 = j0 + KE_SEG - 1;
+    if (j0 < ja_) j0 = ja_;
+    if (j1 > jb_) j1 = jb_;
+    if (j0 > j1) return;
+    const int ilo = i0 > ia ? i0 : ia, ihi = i0 + KE_OUT - 1 < ib ? i0 + KE_OUT - 1 : ib;
+    if (ilo > ihi) return;
+    Real *lu = (Real *)smem_;  // u of row jf;  lu[lane + 3 + d] <-> column i + d
+    const int imax = nx + nh + 1, jmax = ny + nh;
+    const Real *ub_ = u + b, *vb_ = v + b, *ucb = uc + b, *vcb = vc + b;
+    const MPtr cob = cosa + m2, rsb = rsina + m2, rdxb = rdx + m2, rdyb = rdy + m2;
+    const Real dt5 = (Real)0.5 * dt;
+    struct Row {  // row jf = r - 2 of everything but v, whose window runs two rows ahead
+      Real vnew, uu, ucc, vcc, vcm, co, rs, rx, rxm, ry;
+    };
+    Row pf[KE_PF][FV3_LPT];
+    Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_v[FV3_LPT];
+    PpmCell cv[FV3_LPT];
+    Real uc_prev[FV3_LPT], ry_prev[FV3_LPT];
+    unsigned pcol[FV3_LPT];
+    bool own[FV3_LPT];
+    const int r_beg = j0 - 1, r_end = j1 + 2;  // v rows j0-3 .. are fed by the start-up below
+    auto load_row = [&](int r, int l) -> Row {
+      int rv = r < 1 - nh ? 1 - nh : r;
+      if (rv > jmax) rv = jmax;
+      int jf = r - 2 < 1 - nh ? 1 - nh : r - 2;
+      if (jf > jmax) jf = jmax;
+      const unsigned pv = pcol[l] + (unsigned)(rv * sj32), p = pcol[l] + (unsigned)(jf * sj32);
+      Row w;
+      w.vnew = vb_[pv];
+      w.uu = ub_[p];
+      w.ucc = ucb[p];
+      w.vcc = vcb[p];
+      w.vcm = vcb[p - (p != 0u)];
+      w.co = cob[p];
+      w.rs = rsb[p];
+      w.rx = rdxb[p];
+      w.rxm = rdxb[p - (p != 0u)];
+      w.ry = rdyb[p];
+      return w;
+    };
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 3 + lane, ic = i < imax ? i : imax;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own[l] = i >= ilo && i <= ihi;
+      w2[l] = w3[l] = w4[l] = w5[l] = al_v[l] = uc_prev[l] = ry_prev[l] = (Real)0;
+      cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+      if (lane < 3) lu[lane] = lu[FV3_WAVE + 3 + lane] = (Real)0;
+    }
+    // start-up: the window needs v rows j0-3 .. j0+2 before the first face j0; steps r = j0-3 .. feed it
+    const int r_first = r_beg - 2;
+    FV3_LANES(blk, lane, l) {
+#pragma unroll
+      for (int n = 0; n < KE_PF; ++n) pf[n][l] = load_row(r_first + n, l);
+    }
+    for (int r = r_first; r <= r_end; ++r) {
+      const int rn = r + KE_PF;
+      const int jf = r - 2;  // face of ytp_v / row of everything else
+      Real uu_[FV3_LPT], ubv_[FV3_LPT], vbv_[FV3_LPT], vfl_[FV3_LPT], rx_[FV3_LPT], rxm_[FV3_LPT];
+      FV3_LANES(blk, lane, l) {
+        const Row cu = pf[0][l];
+#pragma unroll
+        for (int n = 0; n + 1 < KE_PF; ++n) pf[n][l] = pf[n + 1][l];
+        pf[KE_PF - 1][l] = load_row(rn, l);
+        // v window: rows r-3 .. r;  al(r-1), cell r-2, face jf = r-2 between cells r-3 and r-2
+        w2[l] = w3[l];
+        w3[l] = w4[l];
+        w4[l] = w5[l];
+        w5[l] = cu.vnew;
+        const Real al_new = PPM_P1 * (w3[l] + w4[l]) + PPM_P2 * (w2[l] + w5[l]);
+        const PpmCell co = ppm_cell(al_v[l], al_new, w3[l], hord);
+        al_v[l] = al_new;
+        const Real vbv = dt5 * (cu.vcm + cu.vcc - (uc_prev[l] + cu.ucc) * cu.co) * cu.rs;
+        const Real ubv = dt5 * (uc_prev[l] + cu.ucc - (cu.vcm + cu.vcc) * cu.co) * cu.rs;
+        vfl_[l] = ppm_face_cfl(cv[l], co, vbv, ry_prev[l], cu.ry);
+        cv[l] = co;
+        uc_prev[l] = cu.ucc;
+        ry_prev[l] = cu.ry;
+        vbv_[l] = vbv;
+        ubv_[l] = ubv;
+        uu_[l] = cu.uu;
+        rx_[l] = cu.rx;
+        rxm_[l] = cu.rxm;
+        lu[3 + lane] = cu.uu;
+      }
+      blk.wave_sync();
+      const bool row_ok = jf >= j0 && jf <= j1;
+      FV3_LANES(blk, lane, l) {
+        const Real *a = lu + lane;  // a[0] = u(i-3, jf)
+        const Real ufl = ppm_flux_int_cfl(a[0], a[1], a[2], a[3], a[4], a[5], ubv_[l], hord, rxm_[l], rx_[l]);
+        if (row_ok && own[l]) (ke + b)[pcol[l] + (unsigned)(jf * sj32)] = (Real)0.5 * (vbv_[l] * vfl_[l] + ubv_[l] * ufl);
+      }
+      blk.wave_sync();
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
 // divergence damping: the nord-fold Laplacian-type iteration of the corner divergence.
 // Staged form (two launches per iteration, in place on divgd, uc / vc as work arrays exactly like
 // the reference); `win` restricts every launch to a window (results exact >= 4 points inside an
@@ -564,12 +688,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     q_con[p] = qc_dp[p] / dpnv;
   });
 
-  // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u) and cell-mean relative vorticity
+  // ---- cell-mean relative vorticity
   launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-    const int npx = g.npx, npy = g.npy;
     const unsigned p = IX(i, j);
     {
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
@@ -577,7 +698,16 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       const Real e = (v + b)[p] * (g.dy + m2)[p], e1 = (v + b)[IX(i + 1, j)] * (g.dy + m2)[IX(i + 1, j)];
       (wk + b)[p] = (g.rarea + m2)[p] * (a - a1 - e + e1);
     }
-    if (i < 1 || i > g.nx + 1 || j < 1 || j > g.ny + 1) return;
+  });
+  // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
+  static const bool ke_staged = getenv("FV3_KE_STAGED") != nullptr;  // A/B switch for profiling
+  // ke_point: one corner, any position (tile-edge forms of ub / vb, one-sided PPM, corner overrides)
+  auto ke_point = [=] FV3_HD(int t, int k, int i, int j) {
+    const int fl = g.flags[t];
+    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    const int npx = g.npx, npy = g.npy;
+    const unsigned p = IX(i, j);
     const Real dt5 = (Real)0.5 * dt, dt4 = (Real)0.25 * dt;
     const Real *utl = ut + b, *vtl = vt + b, *ucl = uc + b, *vcl = vc + b, *ul = u + b, *vl = v + b;
     Real kev;
@@ -631,7 +761,32 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       kev = (Real)0.5 * (vbv * vflux + ubv * uflux);
     }
     (ke + b)[p] = kev;
-  });
+  };
+  if (ke_staged) {
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, ke_point);
+  } else {
+    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, nz1);
+    // frame: the 3 outermost corner rows / columns next to a cube-tile edge
+    const int nfr = g.nx + 1 > g.ny + 1 ? g.nx + 1 : g.ny + 1;
+    launch3(c, s, Box{1, nfr, 1, 12, 0, nz1}, [=] FV3_HD(int t, int k, int a, int side) {
+      const int fl = g.flags[t];
+      int i, j;
+      // side 1-3: columns 1..3 (W)   4-6: columns npx-2..npx (E)   7-9: rows 1..3 (S)   10-12: rows npy-2..npy (N)
+      if (side <= 6) {
+        if (a > g.ny + 1) return;
+        if (!(fl & (side <= 3 ? FV3_W : FV3_E))) return;
+        i = side <= 3 ? side : g.npx - 6 + side;
+        j = a;
+      } else {
+        if (a > g.nx + 1) return;
+        if (!(fl & (side <= 9 ? FV3_S : FV3_N))) return;
+        j = side <= 9 ? side - 6 : g.npy - 12 + side;
+        i = a;
+        if (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2)) return;  // covered by the column sides
+      }
+      ke_point(t, k, i, j);
+    });
+  }
 
   // ---- divergence damping.  delpc: un-iterated divergence; divgd iterated in place; uc / vc are
   //      the work arrays of the iteration exactly as in the reference (their C-grid values are dead).

@@ -125,3 +125,27 @@ FV3_HD inline Real ppm_flux_int(Real a, Real b, Real c_, Real d, Real e, Real f,
   const PpmCell m = ppm_cell(al_m, al_0, c_, mord), o = ppm_cell(al_0, al_p, d, mord);
   return ppm_face(m, o, cr);
 }
+
+// variants with Courant-number scales (xtp_u / ytp_v: c is a displacement, cfl = c * rdx of the upwind cell)
+FV3_HD inline Real ppm_face_cfl(const PpmCell &m, const PpmCell &o, Real c, Real cfl_m, Real cfl_0) {
+  Real fx1, flux;
+  if (c > (Real)0) {
+    const Real cfl = c * cfl_m;
+    fx1 = ((Real)1 - cfl) * (m.br - cfl * (m.bl + m.br));
+    flux = m.q;
+  } else {
+    const Real cfl = c * cfl_0;
+    fx1 = ((Real)1 + cfl) * (o.bl + cfl * (o.bl + o.br));
+    flux = o.q;
+  }
+  if (m.sm || o.sm) flux = flux + fx1;
+  return flux;
+}
+
+FV3_HD inline Real ppm_flux_int_cfl(Real a, Real b, Real c_, Real d, Real e, Real f, Real cr, int mord, Real cfl_m, Real cfl_0) {
+  const Real al_m = PPM_P1 * (b + c_) + PPM_P2 * (a + d);
+  const Real al_0 = PPM_P1 * (c_ + d) + PPM_P2 * (b + e);
+  const Real al_p = PPM_P1 * (d + e) + PPM_P2 * (c_ + f);
+  const PpmCell m = ppm_cell(al_m, al_0, c_, mord), o = ppm_cell(al_0, al_p, d, mord);
+  return ppm_face_cfl(m, o, cr, cfl_m, cfl_0);
+}
