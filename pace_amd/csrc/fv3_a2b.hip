@@ -186,7 +186,8 @@ void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int k
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk;
   const int nstrip = (nx + 1 + AB_OUT - 1) / AB_OUT;
-  int nseg = (ny + 1 + 32) / 64;
+  const int seg = fv3_pick_seg((long)nstrip * ((ny + 64) / 64) * g.nsub * nk, 8);
+  int nseg = (ny + 1 + seg / 2) / seg;
   if (nseg < 1) nseg = 1;
   const int seglen = (ny + 1 + nseg - 1) / nseg;
   const size_t smem = sizeof(Real) * 2 * (FV3_WAVE + 3);

@@ -362,6 +362,16 @@ __global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(W
 }
 #endif
 
+// Rows a marching wave owns (FV3_SEG overrides for experiments).  Shorter segments were tried to
+// shorten the tail of small launches (C384 / C192 per-GPU loads): 16 or 32 rows were 1-7 % slower
+// than 64 at every size measured on MI355X, so 64 stays.
+inline int fv3_pick_seg(long waves_at_64, int wpe) {
+  static const char *e = getenv("FV3_SEG");
+  (void)waves_at_64;
+  (void)wpe;
+  return e ? atoi(e) : 64;
+}
+
 template <int WPE = 3, class F>
 inline void launch_waves(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int gz, size_t smem_bytes, F f) {
   if (gx <= 0 || gy <= 0 || gz <= 0) return;

@@ -263,7 +263,9 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
 static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1) {
   const Geo g = c->g;
   const int nk = k1 - k0 + 1;
-  const int nstrip = (g.nx + 1 + KE_OUT - 1) / KE_OUT, nseg = (g.ny + 1 + KE_SEG - 1) / KE_SEG;
+  const int nstrip = (g.nx + 1 + KE_OUT - 1) / KE_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 64) / 64) * g.nsub * nk, 4);
+  const int nseg = (g.ny + 1 + seg - 1) / seg;
   const size_t smem = sizeof(Real) * (FV3_WAVE + 6);
   const Geo *gp = c->g_dev;
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
@@ -277,7 +279,7 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
     const int ia = (fl & FV3_W) ? 4 : 1, ib = (fl & FV3_E) ? npx - 3 : nx + 1;
     const int ja_ = (fl & FV3_S) ? 4 : 1, jb_ = (fl & FV3_N) ? npy - 3 : ny + 1;
     const int i0 = 1 + blk.bx * KE_OUT;
-    int j0 = 1 + blk.by * KE_SEG, j1 = j0 + KE_SEG - 1;
+    int j0 = 1 + blk.by * seg, j1 = j0 + seg - 1;
     if (j0 < ja_) j0 = ja_;
     if (j1 > jb_) j1 = jb_;
     if (j0 > j1) return;
@@ -452,7 +454,9 @@ static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Re
 static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
   const Geo g = c->g;
   const int nk = k1 - k0 + 1;
-  const int nstrip = (g.nx + 1 + DD_OUT - 1) / DD_OUT, nseg = (g.ny + 1 + DD_SEG - 1) / DD_SEG;
+  const int nstrip = (g.nx + 1 + DD_OUT - 1) / DD_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 64) / 64) * g.nsub * nk, 4);
+  const int nseg = (g.ny + 1 + seg - 1) / seg;
   const int LW = FV3_WAVE + 2;
   const size_t smem = sizeof(Real) * DD_NMAX * LW;
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
@@ -465,8 +469,8 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
     if (nord == 0) return;
     const long b = t * st + k * sk, m2 = t * st2;
     const int i0 = 1 + blk.bx * DD_OUT;
-    const int ja = 1 + blk.by * DD_SEG;
-    const int jb = ja + DD_SEG - 1 < ny + 1 ? ja + DD_SEG - 1 : ny + 1;
+    const int ja = 1 + blk.by * seg;
+    const int jb = ja + seg - 1 < ny + 1 ? ja + seg - 1 : ny + 1;
     const int imax = nx + nh + 1, jsd = 1 - nh, jmax = ny + nh + 1;  // last stored corner column / row
     Real *ld = (Real *)smem_ + 1;  // ld[(n) * LW + lane]: row produced by iteration n (n = 0: the loaded row)
     const Real *dq = divgd + b;

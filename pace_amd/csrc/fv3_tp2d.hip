@@ -158,7 +158,9 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
   const Geo g = c->g;
   const Deln d = dn;
   const int nk = k1 - k0 + 1;
-  const int nstrip = (g.nx + 1 + D6_OUT - 1) / D6_OUT, nseg = (g.ny + D6_SEG - 1) / D6_SEG;
+  const int nstrip = (g.nx + 1 + D6_OUT - 1) / D6_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 4);
+  const int nseg = (g.ny + seg - 1) / seg;
   const size_t smem = sizeof(Real) * 2 * (D6_NMAX + 1) * (FV3_WAVE + 2);
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
@@ -170,8 +172,8 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
     const Real damp = deln_damp(d, k);
     const long b = t * st + k * sk, m2 = t * st2;
     const int i0 = 1 + blk.bx * D6_OUT;
-    const int ja = 1 + blk.by * D6_SEG;
-    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + D6_SEG - 1;
+    const int ja = 1 + blk.by * seg;
+    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
     Real *ld = (Real *)smem_ + 1;                         // ld[s * LW + lane]: d2_s of the lane's cell (read by lane + 1)
     Real *lf = ld + (D6_NMAX + 1) * (FV3_WAVE + 2);       // lf[s * LW + lane]: fx_s of the lane's west face (read by lane - 1)
@@ -936,7 +938,9 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
   }
   const int nk = k1 - k0 + 1;
-  const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT, nseg = (g.ny + TS_SEG - 1) / TS_SEG;
+  const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
+  const int nseg = (g.ny + seg - 1) / seg;
   const size_t smem = sizeof(Real) * (2 * TS_LINE + 3 * (FV3_WAVE + 1));
   Real *epi_out = epi ? epi->out : nullptr;
   const Real *epi_mult = epi ? epi->mult : nullptr;
@@ -955,8 +959,8 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     const int i0 = 1 + blk.bx * TS_OUT;                            // first owned face / cell
-    const int ja = 1 + blk.by * TS_SEG;                            // first owned row / face
-    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + TS_SEG - 1;  // last owned face (rows stop at ny)
+    const int ja = 1 + blk.by * seg;                            // first owned row / face
+    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;  // last owned face (rows stop at ny)
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
     Real *lq = (Real *)smem_;         // q on the row being loaded (x-sweep view); index = i - i0 + 6
     Real *lqi = lq + TS_LINE;         // q_i three rows behind
