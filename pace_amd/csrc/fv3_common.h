@@ -11,6 +11,7 @@
 // against the oracle in the GPU-less build container.  The host-emulation build is test
 // infrastructure: the product loader refuses it (see pace_amd/lib.py).
 #pragma once
+#include <algorithm>
 
 #include <cmath>
 #include <cstdint>
@@ -251,6 +252,70 @@ inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
   const int nkc = (nk + KCH - 1) / KCH;
   const GridMap m = fv3_grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nkc, &grid);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3<KCH, F>), grid, block, 0, s, b, nkc, m, f);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch3 restricted to up to four windows (the cube-corner patches of the marching kernels) in
+// ONE launch: f(t, k, i, j) runs on natural ∩ window for every window.  The windows must be
+// pairwise disjoint when f writes (callers check); n == 0 means "no restriction".
+// ---------------------------------------------------------------------------------------------
+struct Wins {
+  int n;
+  Box w[4];
+};
+FV3_HD inline Box fv3_clip(Box a, const Box &w) {
+  Box r = a;
+  r.i0 = a.i0 > w.i0 ? a.i0 : w.i0;
+  r.i1 = a.i1 < w.i1 ? a.i1 : w.i1;
+  r.j0 = a.j0 > w.j0 ? a.j0 : w.j0;
+  r.j1 = a.j1 < w.j1 ? a.j1 : w.j1;
+  return r;
+}
+inline bool fv3_wins_disjoint(const Wins &ws) {
+  for (int a = 0; a < ws.n; ++a)
+    for (int b = a + 1; b < ws.n; ++b)
+      if (ws.w[a].i0 <= ws.w[b].i1 && ws.w[b].i0 <= ws.w[a].i1 && ws.w[a].j0 <= ws.w[b].j1 && ws.w[b].j0 <= ws.w[a].j1) return false;
+  return true;
+}
+#ifndef FV3_HOST_EMU
+template <class F>
+__global__ void __launch_bounds__(256) fv3_k3w(Box nat, Wins ws, int nk, GridMap m, F f) {
+  int bx, by, kz;
+  if (!fv3_tile(m, bx, by, kz)) return;
+  const int wi = kz % ws.n;
+  const int tk = kz / ws.n;
+  const int t = tk / nk;
+  const int k = nat.k0 + (tk - t * nk);
+  const Box b = fv3_clip(nat, ws.w[wi]);
+  const int i = b.i0 + (int)(bx * 64 + threadIdx.x);
+  const int j = b.j0 + (int)(by * 4 + threadIdx.y);
+  if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+}
+#endif
+template <class F>
+inline void launch3w(const fv3_ctx *c, fv3_stream_t s, Box nat, const Wins &ws, F f) {
+  if (ws.n == 0) {
+    launch3(c, s, nat, f);
+    return;
+  }
+#ifdef FV3_HOST_EMU
+  for (int w = 0; w < ws.n; ++w) {
+    Box b = fv3_clip(nat, ws.w[w]);
+    launch3(c, s, b, f);
+  }
+#else
+  int ni = 0, nj = 0;
+  for (int w = 0; w < ws.n; ++w) {
+    const Box b = fv3_clip(nat, ws.w[w]);
+    ni = std::max(ni, b.i1 - b.i0 + 1);
+    nj = std::max(nj, b.j1 - b.j0 + 1);
+  }
+  const int nk = nat.k1 - nat.k0 + 1;
+  if (ni <= 0 || nj <= 0 || nk <= 0) return;
+  dim3 block(64, 4, 1), grid;
+  const GridMap m = fv3_grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nk * ws.n, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3w<F>), grid, block, 0, s, nat, ws, nk, m, f);
 #endif
 }
 

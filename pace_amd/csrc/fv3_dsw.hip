@@ -381,23 +381,16 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
 // the reference); `win` restricts every launch to a window (results exact >= 4 points inside an
 // artificial window boundary) -- used for the cube-corner patches of the marching form.
 // ---------------------------------------------------------------------------------------------
-static inline Box dd_clip(Box a, const Box *w) {
-  if (!w) return a;
-  Box r = a;
-  r.i0 = std::max(a.i0, w->i0);
-  r.i1 = std::min(a.i1, w->i1);
-  r.j0 = std::max(a.j0, w->j0);
-  r.j1 = std::min(a.j1, w->j1);
-  return r;
-}
-
-static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Box *win) {
+static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Wins *wins_) {
   const Geo g = c->g;
+  Wins ws;
+  ws.n = 0;
+  if (wins_) ws = *wins_;
   const int nz1 = k1;
   for (int n = 1; n <= nord_max; ++n) {
     const int ntm = nord_max - n;
     // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
-    launch3(c, s, dd_clip(Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, k0, nz1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+    launch3w(c, s, Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, k0, nz1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
       const int nord = g.nord[k];
       if (n > nord) return;
       const int nt = nord - n;
@@ -416,7 +409,7 @@ static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Re
         (uc + b)[IX(i, j)] = (a - e) * (g.divg_v + m2)[IX(i, j)];
       }
     });
-    launch3(c, s, dd_clip(Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, k0, nz1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+    launch3w(c, s, Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, k0, nz1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
       const int nord = g.nord[k];
       if (n > nord) return;
       const int nt = nord - n;
@@ -573,38 +566,59 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
       }
     }
   });
-  // cube-corner patches
+  // cube-corner patches (all corners in one set of launches when their windows are disjoint)
   int any = 0;
   for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
   const int *nk_ = g.nord;
-  auto patch = [&](int need, bool west, bool south) {
-    if ((any & need) != need) return;
-    const int P = DD_PATCH, M = 4;
-    Box w;
-    w.i0 = west ? -3 : g.nx + 1 - P - M;
-    w.i1 = west ? P + M : g.nx + 5;
-    w.j0 = south ? -3 : g.ny + 1 - P - M;
-    w.j1 = south ? P + M : g.ny + 5;
-    w.k0 = k0;
-    w.k1 = k1;
-    // private copy of the window (the staged form works in place)
-    launch3(c, s, dd_clip(Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, &w), [=] FV3_HD(int t, int k, int i, int j) {
+  const int P = DD_PATCH, M = 4;
+  struct Corner {
+    int need;
+    bool west, south;
+  };
+  const Corner corners[4] = {{FV3_W | FV3_S, true, true}, {FV3_E | FV3_S, false, true}, {FV3_E | FV3_N, false, false}, {FV3_W | FV3_N, true, false}};
+  Wins wins, patches;
+  int needs[4];
+  wins.n = patches.n = 0;
+  for (const Corner &cn : corners) {
+    if ((any & cn.need) != cn.need) continue;
+    Box w{cn.west ? -3 : g.nx + 1 - P - M, cn.west ? P + M : g.nx + 5, cn.south ? -3 : g.ny + 1 - P - M, cn.south ? P + M : g.ny + 5, k0, k1};
+    Box pb{cn.west ? 1 : std::max(g.nx + 2 - P, 1), cn.west ? P : g.nx + 1, cn.south ? 1 : std::max(g.ny + 2 - P, 1), cn.south ? P : g.ny + 1, k0, k1};
+    needs[wins.n] = cn.need;
+    wins.w[wins.n++] = w;
+    patches.w[patches.n++] = pb;
+  }
+  if (wins.n == 0) return;
+  auto run = [&](const Wins &ws, const Wins &ps, const int *nd) {
+    // private copy of the windows (the staged form works in place)
+    launch3w(c, s, Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       tmp[p] = divgd[p];
     });
-    divdamp_staged(c, s, tmp, uc, vc, nord_max, k0, k1, &w);
-    const int pi0 = west ? 1 : g.nx + 2 - P, pi1 = west ? P : g.nx + 1, pj0 = south ? 1 : g.ny + 2 - P, pj1 = south ? P : g.ny + 1;
-    launch3(c, s, Box{std::max(pi0, 1), pi1, std::max(pj0, 1), pj1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+    divdamp_staged(c, s, tmp, uc, vc, nord_max, k0, k1, &ws);
+    Wins psc = ps;
+    int n0 = nd[0], n1 = ps.n > 1 ? nd[1] : 0, n2 = ps.n > 2 ? nd[2] : 0, n3 = ps.n > 3 ? nd[3] : 0;
+    launch3w(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, ps, [=] FV3_HD(int t, int k, int i, int j) {
       if (nk_[k] == 0) return;
-      if ((g.flags[t] & need) != need) return;
+      int need = 0;
+      const int nn[4] = {n0, n1, n2, n3};
+      for (int w = 0; w < psc.n; ++w)
+        if (i >= psc.w[w].i0 && i <= psc.w[w].i1 && j >= psc.w[w].j0 && j <= psc.w[w].j1) need = nn[w];
+      if (need == 0 || (g.flags[t] & need) != need) return;
       const long p = t * g.st + k * g.sk + IX(i, j);
       out[p] = tmp[p];
     });
   };
-  patch(FV3_W | FV3_S, true, true);
-  patch(FV3_E | FV3_S, false, true);
-  patch(FV3_E | FV3_N, false, false);
-  patch(FV3_W | FV3_N, true, false);
+  if (fv3_wins_disjoint(wins)) {
+    run(wins, patches, needs);
+  } else {
+    for (int w = 0; w < wins.n; ++w) {
+      Wins one, pone;
+      one.n = pone.n = 1;
+      one.w[0] = wins.w[w];
+      pone.w[0] = patches.w[w];
+      run(one, pone, &needs[w]);
+    }
+  }
 }
 
 extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,

@@ -27,12 +27,19 @@ static inline Box clip(Box a, const Box *w) {
 // for the few tiles next to a cube corner, where the corner-halo remap makes a tile-local
 // evaluation awkward; results are valid 4 cells inside the window.
 static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1,
-                                const Box *win) {
+                                const Box *win_, const Wins *wins_ = nullptr) {
+  Wins ws;
+  ws.n = 0;
+  if (wins_) ws = *wins_;
+  else if (win_) {
+    ws.n = 1;
+    ws.w[0] = *win_;
+  }
   const Geo g = c->g;
   const int nm = dn.nord_max;
   const Deln d = dn;
   // d2 = damp * q on (is-1-nord .. ie+1+nord)^2
-  launch3(c, s, clip(Box{-nm, g.nx + 1 + nm, -nm, g.ny + 1 + nm, k0, k1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+  launch3w(c, s, Box{-nm, g.nx + 1 + nm, -nm, g.ny + 1 + nm, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
     if (!deln_on(d, k)) return;
     const int n = deln_nord(d, k);
     if (i < -n || i > g.nx + 1 + n || j < -n || j > g.ny + 1 + n) return;
@@ -40,7 +47,7 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
     d2[p] = q_raw ? q[p] : deln_damp(d, k) * q[p];
   });
   // first fluxes (copy_corners only when nord > 0)
-  launch3(c, s, clip(Box{1 - nm, g.nx + nm + 1, 1 - nm, g.ny + nm + 1, k0, k1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+  launch3w(c, s, Box{1 - nm, g.nx + nm + 1, 1 - nm, g.ny + nm + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
     if (!deln_on(d, k)) return;
     const int n = deln_nord(d, k);
     const int fl = g.flags[t];
@@ -59,7 +66,7 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
     }
   });
   for (int n = 1; n <= nm; ++n) {
-    launch3(c, s, clip(Box{-(nm - n), g.nx + 1 + (nm - n), -(nm - n), g.ny + 1 + (nm - n), k0, k1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+    launch3w(c, s, Box{-(nm - n), g.nx + 1 + (nm - n), -(nm - n), g.ny + 1 + (nm - n), k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(d, k)) return;
       const int nord = deln_nord(d, k);
       if (n > nord) return;
@@ -69,7 +76,7 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
       const unsigned p = IX(i, j);
       (d2 + b)[p] = ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
     });
-    launch3(c, s, clip(Box{1 - (nm - n), g.nx + (nm - n) + 1, 1 - (nm - n), g.ny + (nm - n) + 1, k0, k1}, win), [=] FV3_HD(int t, int k, int i, int j) {
+    launch3w(c, s, Box{1 - (nm - n), g.nx + (nm - n) + 1, 1 - (nm - n), g.ny + (nm - n) + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(d, k)) return;
       const int nord = deln_nord(d, k);
       if (n > nord) return;
@@ -128,30 +135,52 @@ static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
   for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
   Real *tfx = c->scratch[SC_L], *tfy = c->scratch[SC_M];
   const Deln dd = dn;
-  auto patch = [&](int need, bool west, bool south) {
-    if ((any & need) != need) return;
-    const int P = D6_PATCH, M = 4;  // staged results are exact >= 4 points inside an artificial window boundary
-    Box w;
-    w.i0 = west ? -3 : g.nx + 1 - P - M;
-    w.i1 = west ? P + M : g.nx + 4;
-    w.j0 = south ? -3 : g.ny + 1 - P - M;
-    w.j1 = south ? P + M : g.ny + 4;
-    w.k0 = k0;
-    w.k1 = k1;
-    del6_vt_flux_staged(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, &w);
-    const int pi0 = west ? 1 : g.nx + 2 - P, pi1 = west ? P : g.nx + 1, pj0 = south ? 1 : g.ny + 2 - P, pj1 = south ? P : g.ny + 1;
-    launch3(c, s, Box{std::max(pi0, 1), pi1, std::max(pj0, 1), pj1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
+  const int P = D6_PATCH, M = 4;  // staged results are exact >= 4 points inside an artificial window boundary
+  struct Corner {
+    int need;
+    bool west, south;
+  };
+  const Corner corners[4] = {{FV3_W | FV3_S, true, true}, {FV3_E | FV3_S, false, true}, {FV3_E | FV3_N, false, false}, {FV3_W | FV3_N, true, false}};
+  Wins wins, patches;
+  int needs[4];
+  wins.n = patches.n = 0;
+  for (const Corner &cn : corners) {
+    if ((any & cn.need) != cn.need) continue;
+    Box w{cn.west ? -3 : g.nx + 1 - P - M, cn.west ? P + M : g.nx + 4, cn.south ? -3 : g.ny + 1 - P - M, cn.south ? P + M : g.ny + 4, k0, k1};
+    Box pb{cn.west ? 1 : std::max(g.nx + 2 - P, 1), cn.west ? P : g.nx + 1, cn.south ? 1 : std::max(g.ny + 2 - P, 1), cn.south ? P : g.ny + 1, k0, k1};
+    needs[wins.n] = cn.need;
+    wins.w[wins.n++] = w;
+    patches.w[patches.n++] = pb;
+  }
+  if (wins.n == 0) return;
+  auto run = [&](const Wins &ws, const Wins &ps, const int *nd) {
+    del6_vt_flux_staged(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, nullptr, &ws);
+    Wins psc = ps;
+    int n0 = nd[0], n1 = ps.n > 1 ? nd[1] : 0, n2 = ps.n > 2 ? nd[2] : 0, n3 = ps.n > 3 ? nd[3] : 0;
+    launch3w(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, ps, [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(dd, k) || deln_nord(dd, k) == 0) return;
-      if ((g.flags[t] & need) != need) return;
+      // which corner's patch is this point in (patches handled together are disjoint)
+      int need = 0;
+      const int nn[4] = {n0, n1, n2, n3};
+      for (int w = 0; w < psc.n; ++w)
+        if (i >= psc.w[w].i0 && i <= psc.w[w].i1 && j >= psc.w[w].j0 && j <= psc.w[w].j1) need = nn[w];
+      if (need == 0 || (g.flags[t] & need) != need) return;
       const long p = t * g.st + k * g.sk + IX(i, j);
       if (j <= g.ny) fx2[p] = tfx[p];
       if (i <= g.nx) fy2[p] = tfy[p];
     });
   };
-  patch(FV3_W | FV3_S, true, true);
-  patch(FV3_E | FV3_S, false, true);
-  patch(FV3_E | FV3_N, false, false);
-  patch(FV3_W | FV3_N, true, false);
+  if (fv3_wins_disjoint(wins)) {
+    run(wins, patches, needs);  // one set of launches for all corners
+  } else {                      // tiny sub-domains: windows overlap, one corner at a time
+    for (int w = 0; w < wins.n; ++w) {
+      Wins one, pone;
+      one.n = pone.n = 1;
+      one.w[0] = wins.w[w];
+      pone.w[0] = patches.w[w];
+      run(one, pone, &needs[w]);
+    }
+  }
 }
 
 static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
