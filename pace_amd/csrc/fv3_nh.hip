@@ -299,39 +299,39 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v
   const Real dt = (Real)dtd;
   const Real top = (Real)std::pow(ptop, akap);
   const int nz = g.nz;
+  // corner-interpolated pp / pk3 / gz / delp go to scratch: the reference interpolates pp, pk3 and gz in
+  // place, but nothing reads them afterwards (gz and pk3 are rebuilt every sub-step), so the three
+  // copy-back passes are not spent; the inputs come back unchanged.
+  Real *ppb = c->scratch[SC_B], *pk3b = c->scratch[SC_C], *gzb = c->scratch[SC_D], *wk1 = c->scratch[SC_A];
   launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long tb = t * g.st;
-    const unsigned pix = IX(i, j);
-    const long p = tb + pix;
-    (void)p;
-    pp[p] = (Real)0;
-    pk3[p] = top;
+    const long p = t * g.st + IX(i, j);
+    ppb[p] = (Real)0;
+    pk3b[p] = top;
   });
-  a2b_ord4(c, s, pp, pp, 1, 1, nz, true);
-  a2b_ord4(c, s, pk3, pk3, 1, 1, nz, true);
-  a2b_ord4(c, s, gz, gz, 0, 0, nz + 1, true);
-  Real *wk1 = c->scratch[SC_A];
+  a2b_ord4(c, s, pp, ppb, 1, 1, nz, false);
+  a2b_ord4(c, s, pk3, pk3b, 1, 1, nz, false);
+  a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false);
   a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
     const unsigned p = IX(i, j);
-    auto WK = [&](unsigned q) { return (pk3 + b1)[q] - (pk3 + b)[q]; };
+    auto WK = [&](unsigned q) { return (pk3b + b1)[q] - (pk3b + b)[q]; };
     if (i <= g.nx) {
       const unsigned pe_ = IX(i + 1, j);
       const Real du = dt / (WK(p) + WK(pe_)) *
-                      (((gz + b1)[p] - (gz + b)[pe_]) * ((pk3 + b1)[pe_] - (pk3 + b)[p]) + ((gz + b)[p] - (gz + b1)[pe_]) * ((pk3 + b1)[p] - (pk3 + b)[pe_]));
+                      (((gzb + b1)[p] - (gzb + b)[pe_]) * ((pk3b + b1)[pe_] - (pk3b + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pe_]) * ((pk3b + b1)[p] - (pk3b + b)[pe_]));
       (u + b)[p] = ((u + b)[p] + du +
                   dt / ((wk1 + b)[p] + (wk1 + b)[pe_]) *
-                      (((gz + b1)[p] - (gz + b)[pe_]) * ((pp + b1)[pe_] - (pp + b)[p]) + ((gz + b)[p] - (gz + b1)[pe_]) * ((pp + b1)[p] - (pp + b)[pe_]))) *
+                      (((gzb + b1)[p] - (gzb + b)[pe_]) * ((ppb + b1)[pe_] - (ppb + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pe_]) * ((ppb + b1)[p] - (ppb + b)[pe_]))) *
                  (g.rdx + m2)[p];
     }
     if (j <= g.ny) {
       const unsigned pn = IX(i, j + 1);
       const Real dv = dt / (WK(p) + WK(pn)) *
-                      (((gz + b1)[p] - (gz + b)[pn]) * ((pk3 + b1)[pn] - (pk3 + b)[p]) + ((gz + b)[p] - (gz + b1)[pn]) * ((pk3 + b1)[p] - (pk3 + b)[pn]));
+                      (((gzb + b1)[p] - (gzb + b)[pn]) * ((pk3b + b1)[pn] - (pk3b + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pn]) * ((pk3b + b1)[p] - (pk3b + b)[pn]));
       (v + b)[p] = ((v + b)[p] + dv +
                   dt / ((wk1 + b)[p] + (wk1 + b)[pn]) *
-                      (((gz + b1)[p] - (gz + b)[pn]) * ((pp + b1)[pn] - (pp + b)[p]) + ((gz + b)[p] - (gz + b1)[pn]) * ((pp + b1)[p] - (pp + b)[pn]))) *
+                      (((gzb + b1)[p] - (gzb + b)[pn]) * ((ppb + b1)[pn] - (ppb + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pn]) * ((ppb + b1)[p] - (ppb + b)[pn]))) *
                  (g.rdy + m2)[p];
     }
   });

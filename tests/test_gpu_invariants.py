@@ -89,8 +89,10 @@ def test_fp32_build_tracks_fp64(gpu_backend):
 
 
 @pytest.mark.gpu
-def test_two_process_decomposition_is_bitwise_identical(tmp_path):
-    """The same C48 cube stepped by one process and by two processes (6 sub-domains split 3 + 3,
+@pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4)])
+def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, world):
+    """The same cube stepped by one process and by `world` processes (C48: 6 sub-domains split 3 + 3;
+    C24 layout 2x2: 24 sub-domains, 6 per process, tiles straddling processes as on 4 / 8 GPUs;
     messages over gloo staged through pinned host memory because the box has one GPU; the 8-GPU
     bench uses RCCL with the identical pack / unpack plans) must give bitwise equal fields."""
     import subprocess
@@ -100,10 +102,11 @@ def test_two_process_decomposition_is_bitwise_identical(tmp_path):
     tool = os.path.join(root, "tools", "multi_gpu_check.py")
     env = dict(os.environ, FV3_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     w1, w2 = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    subprocess.run([sys.executable, tool, "--out", w1], check=True, env=env, timeout=600)
+    size = ["--nx", str(nx), "--layout", str(layout)]
+    subprocess.run([sys.executable, tool, "--out", w1] + size, check=True, env=env, timeout=600)
     subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533", tool,
-         "--backend", "gloo", "--out", w2],
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+         str(29533 + world), tool, "--backend", "gloo", "--out", w2] + size,
         check=True, env=env, timeout=600,
     )
     subprocess.run([sys.executable, tool, "--compare", w1, w2], check=True, timeout=60)
