@@ -18,6 +18,7 @@ neighbours on the same device never touch RCCL.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -116,6 +117,16 @@ class HaloExchanger:
         self.st = self.sk * self.nk
         self._phases: Dict[Tuple[str, int], _Phase] = {}
         self._buffers: Dict[Tuple, torch.Tensor] = {}
+        # Second HIP stream for the exchange: pack / device-local copies / RCCL point-to-point / unpack
+        # run there, ordered against the compute stream by two events (start: comm waits for compute;
+        # wait: compute waits for comm), so everything the sequencer issues between start() and wait()
+        # overlaps with the exchange.  Used when there is a network transfer to hide (world_size > 1);
+        # with all sub-domains on one GPU the "exchange" is a few small copy kernels and the extra stream
+        # measured 1 % slower (MI355X, C768), so it stays on the compute stream there.
+        # FV3_HALO_STREAM=1 / 0 forces it on / off.
+        want = os.environ.get("FV3_HALO_STREAM", "1" if layout.world_size > 1 else "0") != "0"
+        if comm_stream is None and torch.device(sf.device).type == "cuda" and want:
+            comm_stream = torch.cuda.Stream(device=sf.device)
         self.comm_stream = comm_stream
         # gloo cannot move device memory: with a gloo group and device-resident fields the packed
         # messages are staged through pinned host buffers (used to exercise the multi-process
@@ -227,9 +238,26 @@ class HaloUpdater:
     def _stream(self):
         return self.ex.sf.stream_handle
 
+    def _on_comm_stream(self):
+        """Context manager + raw handle of the stream the exchange runs on."""
+        ex = self.ex
+        if ex.comm_stream is None:
+            import contextlib
+
+            return contextlib.nullcontext(), self._stream()
+        return torch.cuda.stream(ex.comm_stream), ex.comm_stream.cuda_stream
+
     def start(self):
         ex, ph = self.ex, self.ph
-        stream = self._stream()
+        if ex.comm_stream is not None:
+            # the exchange may start once everything enqueued so far on the compute stream is done
+            ex.comm_stream.wait_stream(torch.cuda.current_stream(ex.sf.device))
+        ctx, stream = self._on_comm_stream()
+        with ctx:
+            self._start(stream)
+
+    def _start(self, stream):
+        ex, ph = self.ex, self.ph
         reqs = []
         if ph.send or ph.recv:
             import torch.distributed as dist
@@ -263,12 +291,20 @@ class HaloUpdater:
         self._inflight = reqs
 
     def wait(self):
-        ex, ph = self.ex, self.ph
+        ex = self.ex
         if self._inflight is None:
             return
+        ctx, stream = self._on_comm_stream()
+        with ctx:
+            self._wait(stream)
+        if ex.comm_stream is not None:
+            # what follows on the compute stream sees the filled halos
+            torch.cuda.current_stream(ex.sf.device).wait_stream(ex.comm_stream)
+
+    def _wait(self, stream):
+        ex, ph = self.ex, self.ph
         for r in self._inflight:
             r.wait()
-        stream = self._stream()
         for peer, cnt in ph.recv_count.items():
             buf = self._recv_bufs[peer]
             if ex.host_staged:
