@@ -1,0 +1,139 @@
+"""Dycore-only driver: runs the acoustic dynamics from a pace driver yaml.
+
+    python -m pace_amd.driver driver/examples/configs/baroclinic_c12.yaml [--steps N] [--out perf.json]
+
+It reproduces the reference's time loop for ``dycore_only: true`` + ``disable_step_physics: true``
+[REF driver/pace/driver/driver.py:627-662]: one "mainloop" timer entry per model step, a step being
+``k_split`` AcousticDynamics calls (tracer advection / remapping / physics are outside this build),
+and writes the per-step times in the layout the reference's performance collector uses
+(``{"times": {"mainloop": {"times": [[...per rank...]]}}}``) so that
+[REF .jenkins/print_performance_number.py:13-14] (mean of steps 2..N per rank) works on it.
+The number of steps comes from ``seconds`` / ``minutes`` / ``hours`` / ``days`` and ``dt_atmos`` as in
+the reference [REF driver/pace/driver/driver.py:305-337 (total_time / n_steps)].
+
+Keys read from the yaml: ``nx_tile, nz, layout, dt_atmos, seconds|minutes|hours|days,
+dycore_config.*`` (the fields of ``AcousticDynamicsConfig``), ``stencil_config.compilation_config.
+{backend, device_sync}``, ``initialization.type`` (``analytic``/anything else -> the synthetic
+recipe of SURVEY §8d; the analytic baroclinic state is not part of this build and the driver says
+so).  ``backend`` values other than ``hip:gfx950`` are reported and replaced: this build has one
+backend.  Multi-process runs take RANK / WORLD_SIZE / LOCAL_RANK from the environment like bench.py.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import yaml
+
+
+def load_config(path: str):
+    with open(path) as f:
+        y = yaml.safe_load(f)
+    from .config import AcousticDynamicsConfig
+
+    known = {f.name for f in dataclasses.fields(AcousticDynamicsConfig)}
+    dy = {k: v for k, v in (y.get("dycore_config") or {}).items() if k in known}
+    ignored = sorted(k for k in (y.get("dycore_config") or {}) if k not in known)
+    total = 0.0
+    for key, mult in (("seconds", 1.0), ("minutes", 60.0), ("hours", 3600.0), ("days", 86400.0)):
+        total += float(y.get(key, 0) or 0) * mult
+    dt_atmos = float(y["dt_atmos"])
+    run = dict(
+        nx_tile=int(y["nx_tile"]),
+        nz=int(y["nz"]),
+        layout=tuple(int(v) for v in y.get("layout", (1, 1))),
+        dt_atmos=dt_atmos,
+        n_steps=max(1, int(round(total / dt_atmos))) if total > 0 else 1,
+        backend=((y.get("stencil_config") or {}).get("compilation_config") or {}).get("backend", "hip:gfx950"),
+        device_sync=bool(((y.get("stencil_config") or {}).get("compilation_config") or {}).get("device_sync", False)),
+        init=(y.get("initialization") or {}).get("type", "analytic"),
+        case=(((y.get("initialization") or {}).get("config") or {}).get("case", "baroclinic")),
+        dycore_only=bool(y.get("dycore_only", False)),
+        disable_step_physics=bool(y.get("disable_step_physics", False)),
+        experiment=((y.get("performance_config") or {}).get("experiment_name", os.path.splitext(os.path.basename(path))[0])),
+    )
+    return run, dy, ignored
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("config")
+    ap.add_argument("--steps", type=int, default=None, help="override the number of model steps from the yaml")
+    ap.add_argument("--out", default=None, help="performance json (default: <experiment>_fv3_mi355x.json)")
+    ap.add_argument("--precision", type=int, default=64)
+    a = ap.parse_args(argv)
+    run, dy, ignored = load_config(a.config)
+
+    import torch
+
+    from .harness import DycoreHarness
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    say = (lambda *x: print("[driver]", *x, flush=True)) if rank == 0 else (lambda *x: None)
+    if run["backend"] not in ("hip:gfx950", "hip"):
+        say(f"backend {run['backend']!r} requested by the yaml -> running 'hip:gfx950' (the only backend of this build)")
+    if not (run["dycore_only"] and run["disable_step_physics"]):
+        say("physics / tracer advection / remapping are outside this build: running the dycore-only acoustic loop")
+    if run["init"] == "analytic" and str(run["case"]).startswith("baroclinic"):
+        init = "baroclinic"
+        say("initialization: JW2006 baroclinic wave (pace_amd.init.baroclinic_state; restated from the paper, see its docstring)")
+    else:
+        init = "synthetic"
+        say(f"initialization {run['init']!r}/{run['case']!r} is not available in this build: using the synthetic recipe of SURVEY §8d")
+    if ignored:
+        say("dycore_config keys not read by the acoustic path:", ", ".join(ignored))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n_ranks = 6 * run["layout"][0] * run["layout"][1]
+    if n_ranks % world:
+        sys.exit(f"{n_ranks} sub-domains are not divisible over {world} processes")
+    dtype = torch.float64 if a.precision == 64 else torch.float32
+    kw = {k: dy[k] for k in ("k_split", "n_split") if k in dy}
+    h = DycoreHarness(nx_tile=run["nx_tile"], nz=run["nz"], layout=run["layout"], dt_atmos=run["dt_atmos"], world_size=world, proc=rank,
+                      device=f"cuda:{local_rank}", dtype=dtype, verbose=(rank == 0), init=init, config_overrides={k: v for k, v in dy.items() if k not in ("k_split", "n_split")}, **kw)
+    if run["device_sync"]:
+        h.sf.set_device_sync(True)
+    n_steps = a.steps or run["n_steps"]
+    times = []
+    for step in range(n_steps):
+        h.synchronize()
+        t0 = time.perf_counter()
+        h.step()  # "mainloop": dycore.step_dynamics for dycore_only + disable_step_physics
+        h.synchronize()
+        times.append(time.perf_counter() - t0)
+    ok = all(v[2] for v in h.sanity().values())
+    local = {r: times for r in h.layout.local_ranks}
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        local = {}
+        for g in gathered:
+            local.update(g)
+        dist.destroy_process_group()
+    if rank == 0:
+        per_rank = [local[r] for r in sorted(local)]
+        mean = sum(per_rank[0][1:]) / max(1, len(per_rank[0]) - 1) if n_steps > 1 else per_rank[0][0]
+        sdpd = run["dt_atmos"] / mean
+        out = a.out or f"{run['experiment']}_fv3_mi355x.json"
+        json.dump({"setup": {"experiment": run["experiment"], "nx_tile": run["nx_tile"], "nz": run["nz"], "layout": list(run["layout"]), "dt_atmos": run["dt_atmos"],
+                             "k_split": h.cfg.k_split, "n_split": h.cfg.n_split, "n_gpus": world, "backend": "hip:gfx950", "dycore_only": True, "finite": ok},
+                   "times": {"mainloop": {"times": per_rank, "hits": [len(t) for t in per_rank]}},
+                   "simulated_days_per_day": sdpd}, open(out, "w"))
+        say(f"{n_steps} steps of dt_atmos={run['dt_atmos']:g}s: mainloop mean (first step dropped) {mean * 1e3:.2f} ms -> {sdpd:.2f} simulated-days/day; state finite: {ok}; wrote {out}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

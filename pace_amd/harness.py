@@ -52,10 +52,13 @@ class DycoreHarness:
         seed: int = 20261002,
         noise: float = 0.01,
         verbose: bool = False,
+        config_overrides: Optional[dict] = None,
+        init: str = "synthetic",
     ):
         self.c = get_constants()
         self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
-        self.cfg = AcousticDynamicsConfig(npx=nx_tile + 1, npy=nx_tile + 1, npz=nz, layout=tuple(layout), dt_atmos=dt_atmos, k_split=k_split, n_split=n_split)
+        self.cfg = AcousticDynamicsConfig(npx=nx_tile + 1, npy=nx_tile + 1, npz=nz, layout=tuple(layout), dt_atmos=dt_atmos, k_split=k_split, n_split=n_split,
+                                          **(config_overrides or {}))
         self.layout = Layout(self.part, world_size, proc)
         self.layout.group = group
         t0 = time.time()
@@ -66,8 +69,16 @@ class DycoreHarness:
         self.state = DycoreState(self.sf.quantity_factory)
         t0 = time.time()
         on_device = not self.sf.hostemu
+        if init not in ("synthetic", "baroclinic"):
+            raise ValueError(f"init {init!r}: 'synthetic' (SURVEY §8d recipe) or 'baroclinic' (JW2006 wave)")
         for i, (g, r) in enumerate(zip(self.grids, self.layout.local_ranks)):
-            if on_device:
+            if init == "baroclinic":
+                from .init import baroclinic_state
+
+                s = baroclinic_state(g, self.c)
+                for n in STATE_NAMES + ["phis"]:
+                    getattr(self.state, n).set_numpy(s[n], i)
+            elif on_device:
                 # evaluate the recipe with torch on the GPU (numpy needs ~1 min per 384^2 x 79 rank)
                 s = synthetic_state_device(g, self.sf.device, seed=seed, rank=r, noise=noise)
                 for n in STATE_NAMES + ["phis"]:

@@ -237,3 +237,112 @@ def synthetic_state_device(grid: GridData, device, seed: int = 20261002, constan
         st[n][:, :, nz] = st[n][:, :, nz - 1]
     st["phis"] = torch.zeros(shp2, dtype=f64, device=dev)
     return st
+
+
+# ---------------------------------------------------------------------------------------------
+# Jablonowski & Williamson (2006) baroclinic-wave test case -- the reference's default analytic
+# initial state (`initialization: {type: analytic, config: {case: baroclinic}}`
+# [REF driver/examples/configs/baroclinic_c12.yaml:8-11; tests/main/fv3core/test_dycore_call.py:108-118]).
+# pyFV3's `init_analytic_state` is un-vendored, so this is a restatement of the published
+# formulas (JW2006, QJRMS 132, eqs. 2-10), sampled the way the acoustic path expects its inputs:
+# point values at cell centres and at the layer-mean eta, D-grid winds as projections of the
+# zonal wind on the local edge directions, pt = T / pkz, delz in discrete hydrostatic balance,
+# w = 0, dry (q_con = 0, cappa = kappa).  pyFV3 integrates some fields over the cell / layer instead
+# of sampling them, so values will differ from it at truncation-error level: parity against the
+# reference for this state is UNPINNED like the rest.
+# ---------------------------------------------------------------------------------------------
+JW_U0 = 35.0
+JW_ETA0 = 0.252
+JW_ETA_T = 0.2
+JW_T0 = 288.0
+JW_GAMMA = 0.005
+JW_DELTA_T = 4.8e5
+JW_UP = 1.0
+JW_LON_C = np.pi / 9.0
+JW_LAT_C = 2.0 * np.pi / 9.0
+
+
+def jw_temperature(lat, eta, c: ConstantSet):
+    """T(lat, eta): horizontal-mean profile + the thermal-wind balanced deviation (JW2006 eqs. 4-6)."""
+    eta_v = (eta - JW_ETA0) * 0.5 * np.pi
+    tbar = JW_T0 * eta ** (c.RDGAS * JW_GAMMA / c.GRAV)
+    tbar = np.where(eta < JW_ETA_T, tbar + JW_DELTA_T * np.maximum(JW_ETA_T - eta, 0.0) ** 5, tbar)
+    s, co = np.sin(lat), np.cos(lat)
+    a_term = (-2.0 * s**6 * (co**2 + 1.0 / 3.0) + 10.0 / 63.0) * 2.0 * JW_U0 * np.cos(eta_v) ** 1.5
+    b_term = (1.6 * co**3 * (s**2 + 2.0 / 3.0) - 0.25 * np.pi) * c.RADIUS * c.OMEGA
+    return tbar + 0.75 * eta * np.pi * JW_U0 / c.RDGAS * np.sin(eta_v) * np.sqrt(np.cos(eta_v)) * (a_term + b_term)
+
+
+def jw_surface_geopotential(lat, c: ConstantSet):
+    """phis(lat) balancing the zonal flow at eta = 1 (JW2006 eq. 7)."""
+    cz = np.cos((1.0 - JW_ETA0) * 0.5 * np.pi) ** 1.5
+    s, co = np.sin(lat), np.cos(lat)
+    return JW_U0 * cz * ((-2.0 * s**6 * (co**2 + 1.0 / 3.0) + 10.0 / 63.0) * JW_U0 * cz + (1.6 * co**3 * (s**2 + 2.0 / 3.0) - 0.25 * np.pi) * c.RADIUS * c.OMEGA)
+
+
+def jw_zonal_wind(lon, lat, eta, c: ConstantSet, perturbation=True):
+    """u(lon, lat, eta) (JW2006 eq. 2) + the Gaussian perturbation centred at (20E, 40N) (eq. 10)."""
+    eta_v = (eta - JW_ETA0) * 0.5 * np.pi
+    u = JW_U0 * np.cos(eta_v) ** 1.5 * np.sin(2.0 * lat) ** 2
+    if perturbation:
+        r = np.arccos(np.clip(np.sin(JW_LAT_C) * np.sin(lat) + np.cos(JW_LAT_C) * np.cos(lat) * np.cos(lon - JW_LON_C), -1.0, 1.0))
+        u = u + JW_UP * np.exp(-((r * 10.0) ** 2))  # R = a / 10, r in units of a
+    return u
+
+
+def baroclinic_state(grid: GridData, constants: Optional[ConstantSet] = None, perturbation: bool = True) -> Dict[str, np.ndarray]:
+    """JW2006 baroclinic wave for one rank; same array conventions as :func:`synthetic_state`."""
+    c = constants or get_constants()
+    nh, nx, ny, nz = grid.n_halo, grid.nx, grid.ny, grid.nz
+    shp2 = (nx + 2 * nh + 1, ny + 2 * nh + 1)
+    shp = shp2 + (nz + 1,)
+    st = {n: np.zeros(shp) for n in STATE_3D}
+    ak, bk = grid.ak, grid.bk
+    p0 = 1.0e5
+    pe1 = ak + bk * p0  # interface pressure (ps = p0 everywhere)
+    eta = 0.5 * (pe1[1:] + pe1[:-1]) / p0  # layer-mean eta
+    delp1 = pe1[1:] - pe1[:-1]
+    pm1 = delp1 / np.log(pe1[1:] / pe1[:-1])
+    lat_a, lon_a = grid.lat_agrid, grid.lon_agrid
+    temp = jw_temperature(lat_a[:, :, None], eta[None, None, :], c)
+    delp = np.broadcast_to(delp1[None, None, :], shp2 + (nz,)).copy()
+    pm = np.broadcast_to(pm1[None, None, :], shp2 + (nz,))
+    pkz = pm**c.KAPPA
+    st["delp"][:, :, :nz] = delp
+    st["pt"][:, :, :nz] = temp / pkz
+    st["delz"][:, :, :nz] = -c.RDGAS * temp * delp / (c.GRAV * pm)
+    st["cappa"][:, :, :nz] = c.KAPPA
+    st["pkz"][:, :, :nz] = pkz
+    pem = np.broadcast_to(pe1[None, None, :], shp)
+    st["pe"][:, :, :] = pem
+    st["peln"][:, :, :] = np.log(pem)
+    st["pk"][:, :, :] = np.exp(c.KAPPA * np.log(pem))
+    for n in ("delp", "pt", "delz", "cappa"):
+        st[n][:, :, nz] = st[n][:, :, nz - 1]
+
+    # D-grid winds: zonal wind at the edge mid-points projected on the edge direction
+    Pc = _sph(grid.lon, grid.lat)
+
+    def edges(a, b):
+        e = b - a
+        m = a + b
+        m /= np.linalg.norm(m, axis=-1, keepdims=True)
+        e -= np.sum(e * m, -1, keepdims=True) * m
+        e /= np.linalg.norm(e, axis=-1, keepdims=True)
+        return e, m
+
+    def project(e, m):
+        lon = np.arctan2(m[..., 1], m[..., 0])
+        lat = np.arcsin(np.clip(m[..., 2], -1.0, 1.0))
+        east = np.stack([-np.sin(lon), np.cos(lon), np.zeros_like(lon)], axis=-1)
+        along = np.sum(east * e, -1)  # cos of the angle between the edge and the local east
+        return jw_zonal_wind(lon[:, :, None], lat[:, :, None], eta[None, None, :], c, perturbation) * along[:, :, None]
+
+    ex, mx = edges(Pc[:-1, :, :], Pc[1:, :, :])
+    ey, my = edges(Pc[:, :-1, :], Pc[:, 1:, :])
+    st["u"][:-1, :, :nz] = project(ex, mx)
+    st["v"][:, :-1, :nz] = project(ey, my)
+    phis = np.zeros(shp2 + (1,))
+    phis[:, :, 0] = jw_surface_geopotential(lat_a, c)
+    st["phis"] = phis
+    return st

@@ -1,0 +1,62 @@
+"""The yaml-driven dycore-only driver: config parsing on CPU, a short run on the GPU."""
+import json
+import os
+
+import pytest
+
+from pace_amd import driver
+
+YAML = """
+dycore_only: true
+disable_step_physics: true
+stencil_config:
+  compilation_config:
+    backend: gt:gpu
+    device_sync: false
+initialization:
+  type: analytic
+  config:
+    case: baroclinic
+performance_config:
+  collect_performance: true
+  experiment_name: c12_test
+nx_tile: 12
+nz: 79
+dt_atmos: 225
+minutes: 15
+layout: [1, 1]
+dycore_config:
+  a_imp: 1.0
+  beta: 0.
+  d4_bg: 0.15
+  hord_dp: 6
+  hord_tr: 8
+  k_split: 1
+  n_split: 2
+  nord: 3
+  kord_tm: -9
+  n_sponge: 48
+"""
+
+
+def test_yaml_is_mapped_like_the_reference_driver(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text(YAML)
+    run, dy, ignored = driver.load_config(str(p))
+    assert run["nx_tile"] == 12 and run["nz"] == 79 and run["layout"] == (1, 1)
+    assert run["n_steps"] == 4  # 15 minutes / 225 s  [REF driver.py: total_time / dt_atmos]
+    assert run["dycore_only"] and run["disable_step_physics"] and run["backend"] == "gt:gpu"
+    assert dy["n_split"] == 2 and dy["nord"] == 3 and dy["d4_bg"] == 0.15
+    assert "kord_tm" in ignored and "hord_dp" not in ignored  # remap options: outside the acoustic path
+
+
+@pytest.mark.gpu
+def test_driver_runs_the_reference_c12_config_shape(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text(YAML)
+    out = tmp_path / "perf.json"
+    assert driver.main([str(p), "--steps", "3", "--out", str(out)]) == 0
+    d = json.load(open(out))
+    times = d["times"]["mainloop"]["times"]
+    assert len(times) == 6 and all(len(t) == 3 for t in times)  # one entry per rank and step, as the reference collector
+    assert d["setup"]["finite"] and d["simulated_days_per_day"] > 0
