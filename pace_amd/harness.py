@@ -91,7 +91,7 @@ class DycoreHarness:
                     getattr(self.state, n).set_numpy(s[n], i)
             del s
         if verbose:
-            print(f"[harness] synthetic state in {time.time() - t0:.1f}s", flush=True)
+            print(f"[harness] {init} state in {time.time() - t0:.1f}s", flush=True)
         self.dyn = AcousticDynamics(self.layout, self.grids, self.sf, config=self.cfg, phis=self.state.phis, state=self.state)
         # shared D-grid interface winds must be single-valued across sub-domains (they are in any
         # physical state; the per-rank white noise of the synthetic recipe breaks it)
