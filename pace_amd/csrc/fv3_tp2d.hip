@@ -2,12 +2,14 @@
 // CPU twin: oracle/fv3_oracle/fvtp2d.py.  [SURVEY A.4, A.4.3; reference operator
 // FiniteVolumeTransport, REF examples/notebooks/functions.py:935-951]
 //
-// Baseline structure (round 1): 3 launches for the transport proper
-//   (1) inner fluxes fy2 = yppm(q), fx2 = xppm(q)           -- q read through the corner remap
-//   (2) q_i, q_j (flux-updated in the cross direction)
-//   (3) outer fluxes, averaged with the inner ones and scaled by the area / mass flux
-// plus the del-n chain when damping is on.  HBM traffic per level is dominated by the four
-// intermediates (fy2, fx2, q_i, q_j); fusing them through LDS is the next step.
+// Two forms of each operator:
+//  * staged (one launch per stage, intermediates in global scratch): the first correct version,
+//    kept as the A/B reference (FV3_TP2D_MODE / FV3_DEL6_MODE = staged) and used on the small
+//    cube-corner windows of the marching del-n kernel;
+//  * marching wave kernels (tp2d_stream, del6_stream): the product path, see the comments there.
+// LDS-tiled workgroup variants (64 x 8 / 64 x 16 tiles, 256 threads, per-level and k-walking)
+// were measured in between and removed: 13.4 ms / 23 ms per transport against 8 ms for the
+// marching form and 18 ms staged (C768, MI355X).
 #include <type_traits>
 
 #include "fv3_ops.h"
@@ -93,24 +95,6 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// LDS-fused del-n chain: the (TI+6) x (TJ+6) tile of q is read once, d2 / fx2 / fy2 of every
-// iteration live in LDS, only the final fluxes on the owned faces are written.  HBM traffic per
-// level: q in, fx2 + fy2 out (3 passes) instead of ~15 for the staged chain at nord = 2.
-// Tiles whose halo touches a cube-corner block are skipped here and served by the staged form
-// restricted to a window (see above).
-// ---------------------------------------------------------------------------------------------
-#define DL_TI 64
-#define DL_TJ 16
-#define DL_EW (DL_TI + 6)
-#define DL_EH (DL_TJ + 6)
-
-FV3_HD static inline bool dl_corner_tile(const Geo &g, int fl, int i0, int j0) {
-  const bool lo_i = i0 - 3 < 1, hi_i = i0 + DL_TI + 2 > g.nx, lo_j = j0 - 3 < 1, hi_j = j0 + DL_TJ + 2 > g.ny;
-  const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-  return (W && S && lo_i && lo_j) || (E && S && hi_i && lo_j) || (E && N && hi_i && hi_j) || (W && N && lo_i && hi_j);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Marching del-n chain (orders 0..2 = del-2, del-4, del-6; fv_tp_2d / d_sw never ask for more:
@@ -322,120 +306,13 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
 }
 
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
-  // FV3_DEL6_MODE = staged | tile | stream (default): A/B switch for profiling
+  // FV3_DEL6_MODE = staged | stream (default): the staged form is the reference / A-B path
   static const char *mode_env = getenv("FV3_DEL6_MODE");
-  static const int mode = !mode_env ? 2 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "tile") ? 1 : 2));
-  if (mode == 0) {
+  static const bool staged = mode_env && !strcmp(mode_env, "staged");
+  if (staged || dn.nord_max > D6_NMAX)
     del6_vt_flux_staged(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1, nullptr);
-    return;
-  }
-  if (mode == 2 && dn.nord_max <= D6_NMAX) {
+  else
     del6_stream(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
-    return;
-  }
-  const Geo g = c->g;
-  const int gx = (g.nx + 1 + DL_TI - 1) / DL_TI, gy = (g.ny + 1 + DL_TJ - 1) / DL_TJ;
-  // cube-corner tiles first, through the staged chain on windows (later overwritten where the
-  // window overlaps faces owned by regular tiles)
-  if (dn.nord_max > 0) {
-    int any = 0;
-    for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
-    auto window = [&](bool west, bool south) {
-      // bounding box of the tiles flagged "corner" on that side, plus a margin of 4
-      int bi0 = west ? 0 : gx, bi1 = west ? 0 : gx - 1, bj0 = south ? 0 : gy, bj1 = south ? 0 : gy - 1;
-      if (!west)
-        for (int bx = 0; bx < gx; ++bx)
-          if (1 + bx * DL_TI + DL_TI + 2 > g.nx) { bi0 = bx; break; }
-      if (!south)
-        for (int by = 0; by < gy; ++by)
-          if (1 + by * DL_TJ + DL_TJ + 2 > g.ny) { bj0 = by; break; }
-      Box w{1 + bi0 * DL_TI - 4, 1 + (bi1 + 1) * DL_TI - 1 + 4, 1 + bj0 * DL_TJ - 4, 1 + (bj1 + 1) * DL_TJ - 1 + 4, k0, k1};
-      // chain into private work arrays, then copy only the faces owned by corner tiles: windows
-      // of neighbouring corners overlap and must not clobber each other's results
-      Real *tfx = c->scratch[SC_L], *tfy = c->scratch[SC_M];
-      del6_vt_flux_staged(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, &w);
-      const Deln dd = dn;
-      launch3(c, s, clip(Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, &w), [=] FV3_HD(int t, int k, int i, int j) {
-        if (!deln_on(dd, k) || deln_nord(dd, k) == 0) return;
-        const int tbx = (i - 1) / DL_TI, tby = (j - 1) / DL_TJ;
-        if (tbx < bi0 || tbx > bi1 || tby < bj0 || tby > bj1) return;  // tiles of THIS corner only
-        if (!dl_corner_tile(g, g.flags[t], 1 + tbx * DL_TI, 1 + tby * DL_TJ)) return;
-        const long p = t * g.st + k * g.sk + IX(i, j);
-        if (j <= g.ny) fx2[p] = tfx[p];
-        if (i <= g.nx) fy2[p] = tfy[p];
-      });
-    };
-    if ((any & FV3_W) && (any & FV3_S)) window(true, true);
-    if ((any & FV3_E) && (any & FV3_S)) window(false, true);
-    if ((any & FV3_E) && (any & FV3_N)) window(false, false);
-    if ((any & FV3_W) && (any & FV3_N)) window(true, false);
-  }
-  const Deln d = dn;
-  const int nk = k1 - k0 + 1;
-  const size_t smem = sizeof(Real) * 3 * DL_EW * DL_EH;
-  launch_blocks(c, s, gx, gy, g.nsub * nk, 256, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
-    if (!deln_on(d, k)) return;
-    const int nord = deln_nord(d, k);
-    const int fl = g.flags[t];
-    const int i0 = 1 + blk.bx * DL_TI, j0 = 1 + blk.by * DL_TJ;
-    if (nord > 0 && dl_corner_tile(g, fl, i0, j0)) return;  // served by the staged window
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const int ie0 = i0 - 3, je0 = j0 - 3;
-    Real *sd = (Real *)smem_;        // d2   [EH][EW] cells
-    Real *sfx = sd + DL_EW * DL_EH;  // fx2  [EH][EW] west face of cell
-    Real *sfy = sfx + DL_EW * DL_EH; // fy2  [EH][EW] south face of cell
-    const Real damp = deln_damp(d, k);
-    // ---- d2_0 = damp * q on (is-1-nord .. ie+1+nord)^2
-    for (int w = blk.tid; w < DL_EW * DL_EH; w += blk.nthr) {
-      const int i = ie0 + w % DL_EW, j = je0 + w / DL_EW;
-      Real v = (Real)0;
-      if (i >= -nord && i <= g.nx + 1 + nord && j >= -nord && j <= g.ny + 1 + nord) {
-        const Real qv = (q + b)[IX(i, j)];
-        v = q_raw ? qv : damp * qv;
-      }
-      sd[w] = v;
-    }
-    blk.sync();
-    // ---- first fluxes
-    for (int w = blk.tid; w < DL_EW * DL_EH; w += blk.nthr) {
-      const int li = w % DL_EW, lj = w / DL_EW;
-      const int i = ie0 + li, j = je0 + lj;
-      Real vx = (Real)0, vy = (Real)0;
-      if (li > 0 && i >= 1 - nord && i <= g.nx + nord + 1 && j >= 1 - nord && j <= g.ny + nord) vx = (g.del6_v + m2)[IX(i, j)] * (sd[w - 1] - sd[w]);
-      if (lj > 0 && i >= 1 - nord && i <= g.nx + nord && j >= 1 - nord && j <= g.ny + nord + 1) vy = (g.del6_u + m2)[IX(i, j)] * (sd[w - DL_EW] - sd[w]);
-      sfx[w] = vx;
-      sfy[w] = vy;
-    }
-    blk.sync();
-    for (int n = 1; n <= nord; ++n) {
-      const int nt = nord - n;
-      for (int w = blk.tid; w < DL_EW * DL_EH; w += blk.nthr) {
-        const int li = w % DL_EW, lj = w / DL_EW;
-        const int i = ie0 + li, j = je0 + lj;
-        if (li < DL_EW - 1 && lj < DL_EH - 1 && i >= -nt && i <= g.nx + 1 + nt && j >= -nt && j <= g.ny + 1 + nt)
-          sd[w] = (sfx[w] - sfx[w + 1] + sfy[w] - sfy[w + DL_EW]) * (g.rarea + m2)[IX(i, j)];
-      }
-      blk.sync();
-      for (int w = blk.tid; w < DL_EW * DL_EH; w += blk.nthr) {
-        const int li = w % DL_EW, lj = w / DL_EW;
-        const int i = ie0 + li, j = je0 + lj;
-        if (li > 0 && i >= 1 - nt && i <= g.nx + nt + 1 && j >= 1 - nt && j <= g.ny + nt) sfx[w] = (g.del6_v + m2)[IX(i, j)] * (sd[w] - sd[w - 1]);
-        if (lj > 0 && i >= 1 - nt && i <= g.nx + nt && j >= 1 - nt && j <= g.ny + nt + 1) sfy[w] = (g.del6_u + m2)[IX(i, j)] * (sd[w] - sd[w - DL_EW]);
-      }
-      blk.sync();
-    }
-    // ---- final fluxes on the owned faces
-    for (int w = blk.tid; w < DL_TI * DL_TJ; w += blk.nthr) {
-      const int li = w % DL_TI, lj = w / DL_TI;
-      const int i = i0 + li, j = j0 + lj;
-      if (i > g.nx + 1 || j > g.ny + 1) continue;
-      const int e = (li + 3) + (lj + 3) * DL_EW;
-      if (j <= g.ny) (fx2 + b)[IX(i, j)] = sfx[e];
-      if (i <= g.nx) (fy2 + b)[IX(i, j)] = sfy[e];
-    }
-  });
-  (void)d2;
 }
 
 static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
@@ -526,420 +403,6 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   });
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// LDS-fused transport.  One workgroup owns a TI x TJ tile of faces; the (TI+6) x (TJ+6) cell tile
-// of q is staged in LDS once and the four intermediates of the Lin-Rood operator (fy2, fx2, q_i,
-// q_j) never leave the CU.  HBM traffic per level: q, crx, cry, xfx, yfx (+ mfx, mfy, mass, damping
-// fluxes) in, fx, fy out -- against 4 extra written + re-read fields in the staged form.
-// Cube-corner cells are not staged: sweeps that enter a corner block read q through the same
-// copy_corners remap (global, L2-resident) as the staged kernels.
-// ---------------------------------------------------------------------------------------------
-#define TP_TI 64
-#define TP_TJ 8
-#define TP_EW (TP_TI + 6)
-#define TP_EH (TP_TJ + 6)
-
-#ifdef FV3_HOST_EMU
-#define TP_PREFETCH 0
-#else
-#define TP_PREFETCH 1
-#endif
-#define TP_NT 256
-#define TP_NQ ((TP_EW * TP_EH + TP_NT - 1) / TP_NT)
-#define TP_NCX (((TP_TI + 1) * TP_EH + TP_NT - 1) / TP_NT)
-#define TP_NCY ((TP_EW * (TP_TJ + 1) + TP_NT - 1) / TP_NT)
-#define TP_NOUT ((TP_TI * TP_TJ + TP_NT - 1) / TP_NT)
-
-// One workgroup owns a TI x TJ tile of one sub-domain and WALKS k: while level k is computed
-// from LDS, the inputs of level k+1 are already in flight into registers (software prefetch), so
-// HBM latency overlaps the PPM arithmetic instead of serialising with it.  The 2-D cell area of
-// the tile is staged once for all levels.
-static void tp2d_fused_kwalk(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-                       const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
-  const Geo g = c->g;
-  Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
-  const bool damped = dn != nullptr;
-  Deln d;
-  memset(&d, 0, sizeof(d));
-  if (damped) {
-    d = *dn;
-    del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
-  }
-  const int gx = (g.nx + 1 + TP_TI - 1) / TP_TI, gy = (g.ny + 1 + TP_TJ - 1) / TP_TJ;
-  const size_t smem = sizeof(Real) * (2 * TP_EW * TP_EH + 2 * (TP_TI + 1) * TP_EH + 2 * TP_EW * (TP_TJ + 1)  // q, area, crx, xfx, cry, yfx
-                                      + TP_EW * (TP_TJ + 1) + (TP_TI + 1) * TP_EH + TP_EW * TP_TJ + TP_TI * TP_EH);  // fy2, fx2, q_i, q_j
-  launch_blocks(c, s, gx, gy, g.nsub, TP_NT, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz;
-    const int fl = g.flags[t];
-    const long m2 = t * g.st2;
-    const int i0 = 1 + blk.bx * TP_TI, j0 = 1 + blk.by * TP_TJ;
-    const int ie0 = i0 - 3, je0 = j0 - 3;  // first cell of the extended tile
-    Real *sq = (Real *)smem_;                  // [EH][EW]
-    Real *sar = sq + TP_EW * TP_EH;            // [EH][EW]   cell area (all levels)
-    Real *scx = sar + TP_EW * TP_EH;           // [EH][TI+1] crx on faces i0..i0+TI
-    Real *sxf = scx + (TP_TI + 1) * TP_EH;     // [EH][TI+1] xfx
-    Real *scy = sxf + (TP_TI + 1) * TP_EH;     // [TJ+1][EW] cry on faces j0..j0+TJ
-    Real *syf = scy + TP_EW * (TP_TJ + 1);     // [TJ+1][EW] yfx
-    Real *sfy2 = syf + TP_EW * (TP_TJ + 1);    // [TJ+1][EW]
-    Real *sfx2 = sfy2 + TP_EW * (TP_TJ + 1);   // [EH][TI+1]
-    Real *sqi = sfx2 + (TP_TI + 1) * TP_EH;    // [TJ][EW]
-    Real *sqj = sqi + TP_EW * TP_TJ;           // [EH][TI]
-    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-    const int imax = g.nx + g.nh + 1, jmax = g.ny + g.nh + 1;  // last storage index (local numbering)
-    const bool lo_i = ie0 < 1, hi_i = i0 + TP_TI + 2 > g.nx, lo_j = je0 < 1, hi_j = j0 + TP_TJ + 2 > g.ny;
-    const bool corner = (W && S && lo_i && lo_j) || (E && S && hi_i && lo_j) || (E && N && hi_i && hi_j) || (W && N && lo_i && hi_j);
-    // element -> global offset helpers (offset < 0: outside the allocation, stage 0)
-    auto off_q = [&](int w) -> long {
-      const int i = ie0 + w % TP_EW, j = je0 + w / TP_EW;
-      return (i <= imax && j <= jmax) ? (long)IX(i, j) : -1L;
-    };
-    auto off_x = [&](int w) -> long {  // x faces: [EH][TI+1]
-      const int i = i0 + w % (TP_TI + 1), j = je0 + w / (TP_TI + 1);
-      return (i <= g.nx + 1 && j <= g.ny + g.nh) ? (long)IX(i, j) : -1L;
-    };
-    auto off_y = [&](int w) -> long {  // y faces: [TJ+1][EW]
-      const int i = ie0 + w % TP_EW, j = j0 + w / TP_EW;
-      return (i <= g.nx + g.nh && j <= g.ny + 1) ? (long)IX(i, j) : -1L;
-    };
-    for (int w = blk.tid; w < TP_EW * TP_EH; w += blk.nthr) {
-      const long o = off_q(w);
-      sar[w] = o >= 0 ? (g.area + m2)[o] : (Real)1;
-    }
-#if TP_PREFETCH
-    Real rq[TP_NQ], rcx[TP_NCX], rxf[TP_NCX], rcy[TP_NCY], ryf[TP_NCY];
-    auto fetch = [&](int k) {
-      const long b = t * g.st + k * g.sk;
-#pragma unroll
-      for (int n = 0; n < TP_NQ; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        const long o = w < TP_EW * TP_EH ? off_q(w) : -1;
-        rq[n] = o >= 0 ? (q + b)[o] : (Real)0;
-      }
-#pragma unroll
-      for (int n = 0; n < TP_NCX; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        const long o = w < (TP_TI + 1) * TP_EH ? off_x(w) : -1;
-        rcx[n] = o >= 0 ? (crx + b)[o] : (Real)0;
-        rxf[n] = o >= 0 ? (xfx + b)[o] : (Real)0;
-      }
-#pragma unroll
-      for (int n = 0; n < TP_NCY; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        const long o = w < TP_EW * (TP_TJ + 1) ? off_y(w) : -1;
-        rcy[n] = o >= 0 ? (cry + b)[o] : (Real)0;
-        ryf[n] = o >= 0 ? (yfx + b)[o] : (Real)0;
-      }
-    };
-    fetch(k0);
-#endif
-    for (int k = k0; k <= k1; ++k) {
-      const long b = t * g.st + k * g.sk;
-      const Real *qq = q + b;
-      // ---- stage the inputs of this level
-#if TP_PREFETCH
-#pragma unroll
-      for (int n = 0; n < TP_NQ; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        if (w < TP_EW * TP_EH) sq[w] = rq[n];
-      }
-#pragma unroll
-      for (int n = 0; n < TP_NCX; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        if (w < (TP_TI + 1) * TP_EH) {
-          scx[w] = rcx[n];
-          sxf[w] = rxf[n];
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < TP_NCY; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        if (w < TP_EW * (TP_TJ + 1)) {
-          scy[w] = rcy[n];
-          syf[w] = ryf[n];
-        }
-      }
-#else
-      for (int w = blk.tid; w < TP_EW * TP_EH; w += blk.nthr) {
-        const long o = off_q(w);
-        sq[w] = o >= 0 ? qq[o] : (Real)0;
-      }
-      for (int w = blk.tid; w < (TP_TI + 1) * TP_EH; w += blk.nthr) {
-        const long o = off_x(w);
-        scx[w] = o >= 0 ? (crx + b)[o] : (Real)0;
-        sxf[w] = o >= 0 ? (xfx + b)[o] : (Real)0;
-      }
-      for (int w = blk.tid; w < TP_EW * (TP_TJ + 1); w += blk.nthr) {
-        const long o = off_y(w);
-        scy[w] = o >= 0 ? (cry + b)[o] : (Real)0;
-        syf[w] = o >= 0 ? (yfx + b)[o] : (Real)0;
-      }
-#endif
-      blk.sync();
-#if TP_PREFETCH
-      if (k < k1) fetch(k + 1);  // in flight during the three compute phases below
-#endif
-      // per-thread scalars of the owned faces (issued now, consumed in phase 3)
-      const bool on = damped && deln_on(d, k);
-      Real o_m0[TP_NOUT], o_mx[TP_NOUT], o_my[TP_NOUT], o_sx[TP_NOUT], o_sy[TP_NOUT], o_dx[TP_NOUT], o_dy[TP_NOUT];
-#pragma unroll
-      for (int n = 0; n < TP_NOUT; ++n) {
-        o_m0[n] = o_mx[n] = o_my[n] = o_sx[n] = o_sy[n] = o_dx[n] = o_dy[n] = (Real)0;
-#if TP_PREFETCH
-        const int w = blk.tid + n * TP_NT;
-        const int i = i0 + w % TP_TI, j = j0 + w / TP_TI;
-        if (w < TP_TI * TP_TJ && i <= g.nx + 1 && j <= g.ny + 1) {
-          const unsigned p = IX(i, j);
-          if (mfx) {
-            o_sx[n] = (mfx + b)[p];
-            o_sy[n] = (mfy + b)[p];
-          }
-          if (on) {
-            o_dx[n] = (dfx + b)[p];
-            o_dy[n] = (dfy + b)[p];
-            if (mass) {
-              o_m0[n] = (mass + b)[p];
-              o_mx[n] = (mass + b)[IX(i - 1, j)];
-              o_my[n] = (mass + b)[IX(i, j - 1)];
-            }
-          }
-        }
-#endif
-      }
-      auto SQ = [&](int i, int j) -> Real { return sq[(i - ie0) + (j - je0) * TP_EW]; };
-      // ---- phase 1: inner fluxes
-      for (int w = blk.tid; w < TP_EW * (TP_TJ + 1); w += blk.nthr) {
-        const int i = ie0 + w % TP_EW, jf = j0 + w / TP_EW;
-        Real v = (Real)0;
-        if (i <= g.nx + g.nh && jf <= g.ny + 1) {
-          auto M = [&](int s_) { return (g.dya + m2)[IX(i, s_)]; };
-          if (corner && (i < 1 || i > g.nx)) {
-            auto Q = [&](int s_) { return cc<2>(qq, g, fl, i, s_); };
-            v = ppm_flux(Q, M, scy[w], jf, S, N, g.npy, hord);
-          } else {
-            auto Q = [&](int s_) { return SQ(i, s_); };
-            v = ppm_flux(Q, M, scy[w], jf, S, N, g.npy, hord);
-          }
-        }
-        sfy2[w] = v;
-      }
-      for (int w = blk.tid; w < (TP_TI + 1) * TP_EH; w += blk.nthr) {
-        const int i_f = i0 + w % (TP_TI + 1), jr = je0 + w / (TP_TI + 1);
-        Real v = (Real)0;
-        if (jr <= g.ny + g.nh && i_f <= g.nx + 1) {
-          auto M = [&](int s_) { return (g.dxa + m2)[IX(s_, jr)]; };
-          if (corner && (jr < 1 || jr > g.ny)) {
-            auto Q = [&](int s_) { return cc<1>(qq, g, fl, s_, jr); };
-            v = ppm_flux(Q, M, scx[w], i_f, W, E, g.npx, hord);
-          } else {
-            auto Q = [&](int s_) { return SQ(s_, jr); };
-            v = ppm_flux(Q, M, scx[w], i_f, W, E, g.npx, hord);
-          }
-        }
-        sfx2[w] = v;
-      }
-      blk.sync();
-      // ---- phase 2: cross-direction updates
-      for (int w = blk.tid; w < TP_EW * TP_TJ; w += blk.nthr) {
-        const int li = w % TP_EW, lj = w / TP_EW;
-        const int i = ie0 + li, j = j0 + lj;
-        Real v = (Real)0;
-        if (i <= g.nx + g.nh && j <= g.ny) {
-          const Real ar = sar[li + (lj + 3) * TP_EW];
-          const Real y0 = syf[li + lj * TP_EW], y1 = syf[li + (lj + 1) * TP_EW];
-          v = (SQ(i, j) * ar + y0 * sfy2[li + lj * TP_EW] - y1 * sfy2[li + (lj + 1) * TP_EW]) / (ar + y0 - y1);
-        }
-        sqi[w] = v;
-      }
-      for (int w = blk.tid; w < TP_TI * TP_EH; w += blk.nthr) {
-        const int li = w % TP_TI, lj = w / TP_TI;
-        const int i = i0 + li, j = je0 + lj;
-        Real v = (Real)0;
-        if (i <= g.nx && j <= g.ny + g.nh) {
-          const Real ar = sar[(li + 3) + lj * TP_EW];
-          const Real x0 = sxf[li + lj * (TP_TI + 1)], x1 = sxf[li + 1 + lj * (TP_TI + 1)];
-          v = (SQ(i, j) * ar + x0 * sfx2[li + lj * (TP_TI + 1)] - x1 * sfx2[li + 1 + lj * (TP_TI + 1)]) / (ar + x0 - x1);
-        }
-        sqj[w] = v;
-      }
-      blk.sync();
-      // ---- phase 3: outer fluxes on the faces this tile owns
-#if TP_PREFETCH
-#pragma unroll
-      for (int n = 0; n < TP_NOUT; ++n) {
-        const int w = blk.tid + n * TP_NT;
-        if (w >= TP_TI * TP_TJ) continue;
-#else
-      for (int w = blk.tid; w < TP_TI * TP_TJ; w += blk.nthr) {
-        const int n = 0;
-#endif
-        const int li = w % TP_TI, lj = w / TP_TI;
-        const int i = i0 + li, j = j0 + lj;
-        if (i > g.nx + 1 || j > g.ny + 1) continue;
-        const unsigned p = IX(i, j);
-#if !TP_PREFETCH
-        if (mfx) {
-          o_sx[n] = (mfx + b)[p];
-          o_sy[n] = (mfy + b)[p];
-        }
-        if (on) {
-          o_dx[n] = (dfx + b)[p];
-          o_dy[n] = (dfy + b)[p];
-          if (mass) {
-            o_m0[n] = (mass + b)[p];
-            o_mx[n] = (mass + b)[IX(i - 1, j)];
-            o_my[n] = (mass + b)[IX(i, j - 1)];
-          }
-        }
-#endif
-        if (j <= g.ny) {
-          auto Q = [&](int s_) { return sqi[(s_ - ie0) + lj * TP_EW]; };
-          auto M = [&](int s_) { return (g.dxa + m2)[IX(s_, j)]; };
-          const Real f = ppm_flux(Q, M, scx[li + (lj + 3) * (TP_TI + 1)], i, W, E, g.npx, hord);
-          Real v = (Real)0.5 * (f + sfx2[li + (lj + 3) * (TP_TI + 1)]) * (mfx ? o_sx[n] : sxf[li + (lj + 3) * (TP_TI + 1)]);
-          if (on) v = mass ? v + (Real)0.5 * deln_damp(d, k) * (o_mx[n] + o_m0[n]) * o_dx[n] : v + o_dx[n];
-          (fx + b)[p] = v;
-        }
-        if (i <= g.nx) {
-          auto Q = [&](int s_) { return sqj[li + (s_ - je0) * TP_TI]; };
-          auto M = [&](int s_) { return (g.dya + m2)[IX(i, s_)]; };
-          const Real f = ppm_flux(Q, M, scy[(li + 3) + lj * TP_EW], j, S, N, g.npy, hord);
-          Real v = (Real)0.5 * (f + sfy2[(li + 3) + lj * TP_EW]) * (mfy ? o_sy[n] : syf[(li + 3) + lj * TP_EW]);
-          if (on) v = mass ? v + (Real)0.5 * deln_damp(d, k) * (o_my[n] + o_m0[n]) * o_dy[n] : v + o_dy[n];
-          (fy + b)[p] = v;
-        }
-      }
-      blk.sync();  // LDS inputs are overwritten by the next level
-    }
-  });
-}
-
-
-// Per-level variant: one workgroup per (tile, level, sub-domain); 32 KB of LDS (q + the four
-// intermediates), Courant numbers / area fluxes read straight from global memory in the phase
-// that needs them.  More resident workgroups per CU than the k-walking form.
-static void tp2d_fused_level(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-                             const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1) {
-  const Geo g = c->g;
-  Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
-  const bool damped = dn != nullptr;
-  Deln d;
-  memset(&d, 0, sizeof(d));
-  if (damped) {
-    d = *dn;
-    del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
-  }
-  const int nk = k1 - k0 + 1;
-  const int gx = (g.nx + 1 + TP_TI - 1) / TP_TI, gy = (g.ny + 1 + TP_TJ - 1) / TP_TJ;
-  const size_t smem = sizeof(Real) * (TP_EW * TP_EH + TP_EW * (TP_TJ + 1) + (TP_TI + 1) * TP_EH + TP_EW * TP_TJ + TP_TI * TP_EH);
-  launch_blocks(c, s, gx, gy, g.nsub * nk, 256, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
-    const int fl = g.flags[t];
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const int i0 = 1 + blk.bx * TP_TI, j0 = 1 + blk.by * TP_TJ;
-    const int ie0 = i0 - 3, je0 = j0 - 3;
-    Real *sq = (Real *)smem_;
-    Real *sfy2 = sq + TP_EW * TP_EH;          // [TJ+1][EW]
-    Real *sfx2 = sfy2 + TP_EW * (TP_TJ + 1);  // [EH][TI+1]
-    Real *sqi = sfx2 + (TP_TI + 1) * TP_EH;   // [TJ][EW]
-    Real *sqj = sqi + TP_EW * TP_TJ;          // [EH][TI]
-    const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
-    const MPtr areab = g.area + m2, dxab = g.dxa + m2, dyab = g.dya + m2;
-    // tile-level edge flags: the one-sided PPM formulas only exist within 3 faces of a tile edge,
-    // so most workgroups take the branch-free interior form
-    const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TP_TI + 1 >= g.npx - 1;
-    const bool S = (fl & FV3_S) && j0 <= 3, N = (fl & FV3_N) && j0 + TP_TJ + 1 >= g.npy - 1;
-    const int imax = g.nx + g.nh + 1, jmax = g.ny + g.nh + 1;
-    const bool lo_i = ie0 < 1, hi_i = i0 + TP_TI + 2 > g.nx, lo_j = je0 < 1, hi_j = j0 + TP_TJ + 2 > g.ny;
-    const bool corner = ((fl & FV3_W) && (fl & FV3_S) && lo_i && lo_j) || ((fl & FV3_E) && (fl & FV3_S) && hi_i && lo_j) ||
-                        ((fl & FV3_E) && (fl & FV3_N) && hi_i && hi_j) || ((fl & FV3_W) && (fl & FV3_N) && lo_i && hi_j);
-    for (int w = blk.tid; w < TP_EW * TP_EH; w += blk.nthr) {
-      const int i = ie0 + w % TP_EW, j = je0 + w / TP_EW;
-      sq[w] = (i <= imax && j <= jmax) ? qq[IX(i, j)] : (Real)0;
-    }
-    blk.sync();
-    auto SQ = [&](int i, int j) -> Real { return sq[(i - ie0) + (j - je0) * TP_EW]; };
-    for (int w = blk.tid; w < TP_EW * (TP_TJ + 1); w += blk.nthr) {
-      const int i = ie0 + w % TP_EW, jf = j0 + w / TP_EW;
-      Real v = (Real)0;
-      if (i <= g.nx + g.nh && jf <= g.ny + 1) {
-        auto M = [&](int s_) { return dyab[IX(i, s_)]; };
-        if (corner && (i < 1 || i > g.nx)) {
-          auto Q = [&](int s_) { return cc<2>(qq, g, fl, i, s_); };
-          v = ppm_flux(Q, M, cryb[IX(i, jf)], jf, S, N, g.npy, hord);
-        } else {
-          auto Q = [&](int s_) { return SQ(i, s_); };
-          v = ppm_flux(Q, M, cryb[IX(i, jf)], jf, S, N, g.npy, hord);
-        }
-      }
-      sfy2[w] = v;
-    }
-    for (int w = blk.tid; w < (TP_TI + 1) * TP_EH; w += blk.nthr) {
-      const int i_f = i0 + w % (TP_TI + 1), jr = je0 + w / (TP_TI + 1);
-      Real v = (Real)0;
-      if (jr <= g.ny + g.nh && i_f <= g.nx + 1) {
-        auto M = [&](int s_) { return dxab[IX(s_, jr)]; };
-        if (corner && (jr < 1 || jr > g.ny)) {
-          auto Q = [&](int s_) { return cc<1>(qq, g, fl, s_, jr); };
-          v = ppm_flux(Q, M, crxb[IX(i_f, jr)], i_f, W, E, g.npx, hord);
-        } else {
-          auto Q = [&](int s_) { return SQ(s_, jr); };
-          v = ppm_flux(Q, M, crxb[IX(i_f, jr)], i_f, W, E, g.npx, hord);
-        }
-      }
-      sfx2[w] = v;
-    }
-    blk.sync();
-    for (int w = blk.tid; w < TP_EW * TP_TJ; w += blk.nthr) {
-      const int li = w % TP_EW, lj = w / TP_EW;
-      const int i = ie0 + li, j = j0 + lj;
-      Real v = (Real)0;
-      if (i <= g.nx + g.nh && j <= g.ny) {
-        const unsigned p = IX(i, j), pn = IX(i, j + 1);
-        const Real ar = areab[p];
-        const Real y0 = yfxb[p], y1 = yfxb[pn];
-        v = (SQ(i, j) * ar + y0 * sfy2[li + lj * TP_EW] - y1 * sfy2[li + (lj + 1) * TP_EW]) / (ar + y0 - y1);
-      }
-      sqi[w] = v;
-    }
-    for (int w = blk.tid; w < TP_TI * TP_EH; w += blk.nthr) {
-      const int li = w % TP_TI, lj = w / TP_TI;
-      const int i = i0 + li, j = je0 + lj;
-      Real v = (Real)0;
-      if (i <= g.nx && j <= g.ny + g.nh) {
-        const unsigned p = IX(i, j), pe = IX(i + 1, j);
-        const Real ar = areab[p];
-        const Real x0 = xfxb[p], x1 = xfxb[pe];
-        v = (SQ(i, j) * ar + x0 * sfx2[li + lj * (TP_TI + 1)] - x1 * sfx2[li + 1 + lj * (TP_TI + 1)]) / (ar + x0 - x1);
-      }
-      sqj[w] = v;
-    }
-    blk.sync();
-    const bool on = damped && deln_on(d, k);
-    for (int w = blk.tid; w < TP_TI * TP_TJ; w += blk.nthr) {
-      const int li = w % TP_TI, lj = w / TP_TI;
-      const int i = i0 + li, j = j0 + lj;
-      if (i > g.nx + 1 || j > g.ny + 1) continue;
-      const unsigned p = IX(i, j);
-      if (j <= g.ny) {
-        auto Q = [&](int s_) { return sqi[(s_ - ie0) + lj * TP_EW]; };
-        auto M = [&](int s_) { return dxab[IX(s_, j)]; };
-        const Real f = ppm_flux(Q, M, crxb[p], i, W, E, g.npx, hord);
-        Real v = (Real)0.5 * (f + sfx2[li + (lj + 3) * (TP_TI + 1)]) * (mfx ? (mfx + b)[p] : xfxb[p]);
-        if (on) v = mass ? v + (Real)0.5 * deln_damp(d, k) * ((mass + b)[IX(i - 1, j)] + (mass + b)[p]) * (dfx + b)[p] : v + (dfx + b)[p];
-        (fx + b)[p] = v;
-      }
-      if (i <= g.nx) {
-        auto Q = [&](int s_) { return sqj[li + (s_ - je0) * TP_TI]; };
-        auto M = [&](int s_) { return dyab[IX(i, s_)]; };
-        const Real f = ppm_flux(Q, M, cryb[p], j, S, N, g.npy, hord);
-        Real v = (Real)0.5 * (f + sfy2[(li + 3) + lj * TP_EW]) * (mfy ? (mfy + b)[p] : yfxb[p]);
-        if (on) v = mass ? v + (Real)0.5 * deln_damp(d, k) * ((mass + b)[IX(i, j - 1)] + (mass + b)[p]) * (dfy + b)[p] : v + (dfy + b)[p];
-        (fy + b)[p] = v;
-      }
-    }
-  });
-}
 
 // ---------------------------------------------------------------------------------------------
 // Marching form.  One wavefront = a strip of 64 columns (58 owned + 3 halo columns a side) of
@@ -1225,19 +688,14 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
           const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
-  // FV3_TP2D_MODE = staged | kwalk | level | stream (default): A/B switch for profiling
+  // FV3_TP2D_MODE = staged | stream (default): the staged form is the reference / A-B path
   static const char *mode_env = getenv("FV3_TP2D_MODE");
-  static const int mode = !mode_env ? 3 : (!strcmp(mode_env, "staged") ? 0 : (!strcmp(mode_env, "kwalk") ? 1 : (!strcmp(mode_env, "level") ? 2 : 3)));
-  if (mode == 0)
-    tp2d_staged(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
-  else if (mode == 1)
-    tp2d_fused_kwalk(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
-  else if (mode == 2)
-    tp2d_fused_level(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
-  else {
+  static const bool staged = mode_env && !strcmp(mode_env, "staged");
+  if (!staged) {
     tp2d_stream(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
     return;
   }
+  tp2d_staged(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1);
   if (epi) {  // the non-marching forms always store the fluxes; apply the update in a second pass
     const Geo g = c->g;
     Real *out = epi->out;
