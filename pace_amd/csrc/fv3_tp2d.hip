@@ -416,7 +416,12 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 #define TS_OUT 58
 #define TS_SEG 64
 #define TS_LINE (FV3_WAVE + 6)
-#define TS_PF 2  // rows fetched ahead of their use
+#ifndef TS_WPE
+#define TS_WPE 2  // waves per SIMD the register allocation is sized for
+#endif
+#ifndef TS_PF
+#define TS_PF 2  // rows fetched ahead of their use (1 or 2)
+#endif
 
 static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
                         const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
@@ -446,7 +451,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr area = g.area;
-  launch_waves<2>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+  launch_waves<TS_WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
@@ -517,7 +522,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
       nxt[l] = load_row(ja - 3, l);
-      nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l);
+      if (TS_PF == 2) nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l);
     }
 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
@@ -550,8 +555,12 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
             }
           }
           cur[l] = nxt[l];
-          nxt[l] = nx2[l];
-          nx2[l] = load_row(rn, l);
+          if (TS_PF == 2) {
+            nxt[l] = nx2[l];
+            nx2[l] = load_row(rn, l);
+          } else {
+            nxt[l] = load_row(rn, l);
+          }
           Real qy = cur[l].qy, qx = qy;
           if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
             const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
