@@ -658,7 +658,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
   {
     // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
-    const TpEpi e{dpn, nullptr, true, mfx, mfy};
+    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr};
     tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
   }
 
@@ -681,18 +681,18 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     });
   }
   {
-    const TpEpi e{w_dp, delp, false, nullptr, nullptr};  // delp * w + div
+    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr};  // delp * w + div
     tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
   // ---- condensate
   {
     Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-    const TpEpi e{qc_dp, delp, false, nullptr, nullptr};
+    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr};
     tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
   }
   // ---- potential temperature, then the divisions by the new air mass
   {
-    const TpEpi e{pt_dp, delp, false, nullptr, nullptr};
+    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr};
     tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -706,7 +706,8 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     q_con[p] = qc_dp[p] / dpnv;
   });
 
-  // ---- cell-mean relative vorticity
+  // ---- cell-mean relative vorticity (+ absolute vorticity)
+  Real *vabs = c->scratch[SC_R];
   launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const unsigned p = IX(i, j);
@@ -714,7 +715,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
       const Real a = (u + b)[p] * (g.dx + m2)[p], a1 = (u + b)[IX(i, j + 1)] * (g.dx + m2)[IX(i, j + 1)];
       const Real e = (v + b)[p] * (g.dy + m2)[p], e1 = (v + b)[IX(i + 1, j)] * (g.dy + m2)[IX(i + 1, j)];
-      (wk + b)[p] = (g.rarea + m2)[p] * (a - a1 - e + e1);
+      const Real wkv = (g.rarea + m2)[p] * (a - a1 - e + e1);
+      (wk + b)[p] = wkv;
+      (vabs + b)[p] = wkv + (g.f0 + m2)[p];  // absolute vorticity for the transport below
     }
   });
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
@@ -874,19 +877,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     (ke + b)[p] += vd;
   });
 
-  // ---- vorticity transport: absolute vorticity, fluxes, wind update
-  Real *vabs = c->scratch[SC_DN_FY];
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const unsigned p = IX(i, j);
-    vabs[t * g.st + k * g.sk + p] = wk[t * g.st + k * g.sk + p] + g.f0[t * g.st2 + p];
-  });
-  tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1);
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const unsigned p = IX(i, j);
-    if (i <= g.nx) (u + b)[p] = (u + b)[p] * (g.dx + m2)[p] + (ke + b)[p] - (ke + b)[IX(i + 1, j)] + (fy + b)[p];
-    if (j <= g.ny) (v + b)[p] = (v + b)[p] * (g.dy + m2)[p] + (ke + b)[p] - (ke + b)[IX(i, j + 1)] - (fx + b)[p];
-  });
+  // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
+  //      transport kernel's epilogue (the vorticity fluxes are never stored)
+  {
+    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke};
+    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
+  }
 
   // ---- del-n damping of the relative vorticity, heat from the damped kinetic energy
   Real *utd = c->scratch[SC_TP_FX2], *vtd = c->scratch[SC_TP_FY2];  // free: no transport call follows

@@ -28,7 +28,8 @@ enum {
   SC_O = 21,
   SC_P = 22,
   SC_Q = 23,
-  SC_COUNT = 24
+  SC_R = 24,  // d_sw absolute vorticity
+  SC_COUNT = 25
 };
 
 // Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]
@@ -52,11 +53,15 @@ FV3_HD inline bool deln_on(const Deln &d, int k) { return d.on_k ? d.on_k[k] > d
 // formed in the transport kernel itself (the fluxes of the neighbouring faces are already in the
 // wave) instead of a second pass over fx / fy.  write_flux = false: fx / fy are not stored at all.
 // acc_x / acc_y (optional): acc += flux on the owned faces (d_sw's mfx / mfy accumulation).
+// wind_u / wind_v / wind_ke (optional): d_sw's wind update from the vorticity fluxes, in place,
+//   u = u * dx + ke - ke[i+1] + fy   (i in 1..nx, j in 1..ny+1),   v = v * dy + ke - ke[j+1] - fx   (i in 1..nx+1, j in 1..ny).
 struct TpEpi {
   Real *out;
   const Real *mult;
   bool write_flux;
   Real *acc_x, *acc_y;
+  Real *wind_u, *wind_v;
+  const Real *wind_ke;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

@@ -443,7 +443,9 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   const Real *epi_mult = epi ? epi->mult : nullptr;
   const bool wflux = epi ? epi->write_flux : true;
   Real *acc_x = epi ? epi->acc_x : nullptr, *acc_y = epi ? epi->acc_y : nullptr;
-  const MPtr rarea = g.rarea;
+  Real *wind_u = epi ? epi->wind_u : nullptr, *wind_v = epi ? epi->wind_v : nullptr;
+  const Real *wind_ke = epi ? epi->wind_ke : nullptr;
+  const MPtr rarea = g.rarea, gdx = g.dx, gdy = g.dy;
   // The hot loop touches only these scalars; everything the rare paths need (cube-corner remaps,
   // tile-edge metric terms) is read through gp inside those paths, so it does not occupy SGPRs
   // (or spill lanes) across the march.
@@ -484,6 +486,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT];
     Real mb[FV3_LPT];  // mass(i, r-3) = mass(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
+    Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
     Real v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], v5[FV3_LPT], al_v[FV3_LPT];  // q_j likewise
@@ -516,6 +519,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
       own_y[l] = i >= i0 && i < i0 + TS_OUT && i <= nx;
       w2[l] = w3[l] = w4[l] = w5[l] = al_q[l] = v2[l] = v3[l] = v4[l] = v5[l] = al_v[l] = (Real)0;
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+      wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
@@ -552,6 +556,15 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
             if (epi_out) {
               era[l] = (rarea + m2)[p3];
               if (epi_mult && epi_mult != mass) emu[l] = (epi_mult + b)[p3];
+            }
+            if (wind_u) {
+              wu[l] = (wind_u + b)[pf];
+              wdx[l] = (gdx + m2)[pf];
+              wkf[l] = (wind_ke + b)[pf];      // ke(i, jf) -- also ke(i, jr + 1)
+              wke[l] = (wind_ke + b)[pf + 1];  // ke(i + 1, jf)
+              wv[l] = (wind_v + b)[p3];
+              wdy[l] = (gdy + m2)[p3];
+              wkr[l] = (wind_ke + b)[p3];      // ke(i, jr)
             }
           }
           cur[l] = nxt[l];
@@ -622,6 +635,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
               (fx + b)[p] = v;
               if (acc_x) (acc_x + b)[p] += v;
             }
+            if (wind_v && fx_row && own_x[l]) (wind_v + b)[pcol[l] + (unsigned)(jr * sj32)] = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
             if (epi_out) {
               fxk[l] = v;
               exf[lane] = v;
@@ -672,6 +686,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
               (fy + b)[p] = v;
               if (acc_y) (acc_y + b)[p] += v;
             }
+            if (wind_u && fy_row && own_y[l]) (wind_u + b)[pcol[l] + (unsigned)(jf * sj32)] = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
             if (epi_out) {
               // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
               if (fx_row && own_y[l]) {
@@ -710,9 +725,16 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     Real *out = epi->out;
     const Real *mult = epi->mult;
     Real *ax = epi->acc_x, *ay = epi->acc_y;
+    Real *wu_ = epi->wind_u, *wv_ = epi->wind_v;
+    const Real *wk_ = epi->wind_ke;
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
       const unsigned p = IX(i, j);
+      if (wu_) {
+        const long m2 = t * g.st2;
+        if (i <= g.nx) (wu_ + b)[p] = (wu_ + b)[p] * (g.dx + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i + 1, j)] + (fy + b)[p];
+        if (j <= g.ny) (wv_ + b)[p] = (wv_ + b)[p] * (g.dy + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i, j + 1)] - (fx + b)[p];
+      }
       if (out && i <= g.nx && j <= g.ny) {
         const Real dv_ = ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
         (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
