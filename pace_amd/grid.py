@@ -398,9 +398,9 @@ def make_grid(
         for i in range(npx, npx + 3):
             sin[4][i + o, 0 + o] = sin[3][npx - 1 + o, npx - i + o]
     if flags["east"] and flags["north"]:
-        for i in range(npy, npy + 3):
-            sin[1][npx + o, i + o] = sin[4][i + o, npy - 1 + o]
-            sin[2][i + o, npy + o] = sin[3][npx - 1 + o, i + o]
+        for d in range(3):  # distance from the corner (local indices: nx != ny on non-square sub-domains)
+            sin[1][npx + o, npy + d + o] = sin[4][npx + d + o, npy - 1 + o]
+            sin[2][npx + d + o, npy + o] = sin[3][npx - 1 + o, npy + d + o]
 
     cosa_u = np.zeros((shape[0], shape[1] - 1))
     sina_u = np.ones((shape[0], shape[1] - 1))

@@ -41,8 +41,8 @@ def test_mass_conservation_and_edge_flux_symmetry():
 def test_decomposition_identity():
     nz = 5
     outs = []
-    for lay in (1, 2):
-        part, cfg, grids, st, phis, dyn = oracle_cube(12, (lay, lay), nz, dict(n_split=2), noise=0.0)
+    for lay in ((1, 1), (2, 2), (1, 2), (2, 1)):  # square and non-square sub-domains (>= 6 cells per direction)
+        part, cfg, grids, st, phis, dyn = oracle_cube(12, lay, nz, dict(n_split=2), noise=0.0)
         dyn(st, 225.0, 1)
         glob = {}
         for name in NAMES:
@@ -55,8 +55,9 @@ def test_decomposition_identity():
                 G[t, x0 : x0 + part.nx + ex, y0 : y0 + part.ny + ey] = st[r][name][compute_slice(name, part.nx, part.ny, nz)]
             glob[name] = G
         outs.append(glob)
-    for name in NAMES:
-        assert np.array_equal(outs[0][name], outs[1][name]), name
+    for other in outs[1:]:
+        for name in NAMES:
+            assert np.array_equal(outs[0][name], other[name]), name
 
 
 def test_determinism_and_statelessness():

@@ -209,6 +209,17 @@ def test_full_acoustic_call(backend, layout, n_split):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
+@pytest.mark.parametrize("layout", [(1, 2), (3, 1)])
+def test_full_acoustic_call_non_square_subdomains(backend, layout):
+    """Layouts with nx != ny per sub-domain (24 x 12, 8 x 24)."""
+    nz = 5
+    part, cfg, grids, ost, phis, odyn = oracle_cube(24, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 112.5, 1)
+    got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 112.5)
+    compare_cubes(got, ost, part, nz, STATE, TOL)
+
+
 def test_full_acoustic_call_multi_tile(backend):
     """C96: sub-domains span several LDS tiles (64 x 8 transport, 64 x 16 del-n), so interior,
     tile-edge, cube-corner-window and partial tiles of the fused kernels are all exercised."""
