@@ -708,6 +708,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
 
   // ---- cell-mean relative vorticity (+ absolute vorticity)
   Real *vabs = c->scratch[SC_R];
+  // Levels that form the damping heat (d_con > 1e-5) WITHOUT vorticity damping (damp_vt <= 1e-5) read the
+  // pre-update u*dx / v*dy where the damping fluxes would be (the work arrays keep those values in the
+  // reference's data flow); only non-default configs (do_vort_damp off / vtdm4 = 0) have such levels.
+  bool keep_uv_dx = false;
+  for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
+  Real *ut2 = c->scratch[SC_E], *vt2 = c->scratch[SC_F];  // = the utd / vtd slots below (damping fluxes overwrite them on damped levels)
   launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const unsigned p = IX(i, j);
@@ -718,6 +724,10 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       const Real wkv = (g.rarea + m2)[p] * (a - a1 - e + e1);
       (wk + b)[p] = wkv;
       (vabs + b)[p] = wkv + (g.f0 + m2)[p];  // absolute vorticity for the transport below
+      if (keep_uv_dx) {
+        (vt2 + b)[p] = a;
+        (ut2 + b)[p] = e;
+      }
     }
   });
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
@@ -885,7 +895,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   }
 
   // ---- del-n damping of the relative vorticity, heat from the damped kinetic energy
-  Real *utd = c->scratch[SC_TP_FX2], *vtd = c->scratch[SC_TP_FY2];  // free: no transport call follows
+  Real *utd = c->scratch[SC_E], *vtd = c->scratch[SC_F];  // (the tracer-flux slots: free since the tracer transports are done)
   {
     Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
     del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, nz1);
@@ -902,12 +912,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       auto UB = [&](int ii, int jj) {
         const unsigned q = IX(ii, jj);
         const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii + 1, jj)];
-        return (d0 + (dv ? (vtd + b)[q] : (u + b)[q] * (Real)0)) * (g.rdx + m2)[q];
+        return (d0 + (vtd + b)[q]) * (g.rdx + m2)[q];  // vtd: damping flux, or the kept u*dx on undamped levels
       };
       auto VB = [&](int ii, int jj) {
         const unsigned q = IX(ii, jj);
         const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii, jj + 1)];
-        return (d0 - (dv ? (utd + b)[q] : (v + b)[q] * (Real)0)) * (g.rdy + m2)[q];
+        return (d0 - (utd + b)[q]) * (g.rdy + m2)[q];
       };
       const Real ub0 = UB(i, j), ub1 = UB(i, j + 1), vb0 = VB(i, j), vb1 = VB(i + 1, j);
       const Real fy0 = (u + b)[p] * (g.rdx + m2)[p], fy1 = (u + b)[IX(i, j + 1)] * (g.rdx + m2)[IX(i, j + 1)];

@@ -220,6 +220,22 @@ def test_full_acoustic_call_non_square_subdomains(backend, layout):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
+VARIANTS = [dict(nord=0), dict(nord=1), dict(nord=2), dict(d_con=0.0), dict(do_vort_damp=False), dict(vtdm4=0.0), dict(hord_dp=5, hord_mt=5, hord_tm=5, hord_vt=5),
+            dict(rf_fast=False), dict(d2_bg=0.02, d4_bg=0.0), dict(dddmp=0.0), dict(n_sponge=0), dict(ke_bg=1e-4), dict(p_fac=0.1), dict(d2_bg_k1=0.0, d2_bg_k2=0.0)]
+
+
+@pytest.mark.parametrize("kw", VARIANTS, ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_full_acoustic_call_config_variants(backend, kw):
+    """Every dycore_config switch the acoustic path reads, away from the reference defaults
+    (damping orders, heating / vorticity damping off, hord 5, Rayleigh damping off, sponge variants)."""
+    nz = 8
+    part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=2, **kw))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 112.5, 1)
+    got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 112.5)
+    compare_cubes(got, ost, part, nz, STATE, TOL)
+
+
 def test_full_acoustic_call_multi_tile(backend):
     """C96: sub-domains span several LDS tiles (64 x 8 transport, 64 x 16 del-n), so interior,
     tile-edge, cube-corner-window and partial tiles of the fused kernels are all exercised."""
