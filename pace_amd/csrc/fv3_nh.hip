@@ -18,24 +18,37 @@ namespace {
 struct Sim1 {
   Geo g;
   Real rgas, rgrav, p_fac, ptop;
+  // setup(k, pm, dz): produces (and stores) the layer-mean pressure and thickness of level k; called once per
+  //   level, in increasing k, from inside the first sweep (the caller's own prefix sums live in the functor);
+  // finish(k, dz): consumes the new thickness of level k; called once per level, in decreasing k, from inside
+  //   the last sweep;
+  // wout (optional): receives the new w (written in the pressure-perturbation sweep, after the old w is read).
+  // The sweeps are fused where their directions agree: 6 column walks instead of 8, no read-back of PM / DZ
+  // in the first one and of DZ / W2 in the last one.
+  template <class Setup, class Finish>
   FV3_HD void run(long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *w1, Real ws, Real *PM, Real *DZ, Real *W2, Real *PP,
-                  Real *GAM, Real *PE) const {
+                  Real *GAM, Real *PE, Real *wout, Setup setup, Finish finish) const {
     const int nz = g.nz;
     const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
     auto DM = [&](int k) { return K_(delp, k) * rgrav; };
     auto GM = [&](int k) { return (Real)1.0 / ((Real)1.0 - K_(cappa, k)); };
-    auto PE1 = [&](int k) { return exp(GM(k) * log(-DM(k) / K_(DZ, k) * rgas * K_(pt, k))) - K_(PM, k); };
-    // ---- pressure perturbation: tridiagonal solve for pp
+    // ---- sweep 1 (up): caller's setup + forward elimination for pp
     {
-      Real pe_k = PE1(0);
+      Real pm_k, dz_k;
+      setup(0, pm_k, dz_k);
+      Real dm_m = (Real)0, dm_k = DM(0);
+      Real pe_k = exp(GM(0) * log(-dm_k / dz_k * rgas * K_(pt, 0))) - pm_k;
       Real bet = (Real)0;
       K_(PP, 0) = (Real)0;
       for (int k = 0; k < nz; ++k) {
         Real bb, dd;
-        Real pe_n = (Real)0;
+        Real pe_n = (Real)0, dm_n = (Real)0;
         if (k < nz - 1) {
-          const Real g_rat = DM(k) / DM(k + 1);
-          pe_n = PE1(k + 1);
+          Real pm_n, dz_n;
+          setup(k + 1, pm_n, dz_n);
+          dm_n = DM(k + 1);
+          const Real g_rat = dm_k / dm_n;
+          pe_n = exp(GM(k + 1) * log(-dm_n / dz_n * rgas * K_(pt, k + 1))) - pm_n;
           bb = (Real)2.0 * ((Real)1.0 + g_rat);
           dd = (Real)3.0 * (pe_k + g_rat * pe_n);
         } else {
@@ -46,17 +59,20 @@ struct Sim1 {
           bet = bb;
           K_(PP, 1) = dd / bet;
         } else {
-          const Real g_prev = DM(k - 1) / DM(k);
+          const Real g_prev = dm_m / dm_k;
           const Real gam = g_prev / bet;
           K_(GAM, k) = gam;
           bet = bb - gam;
           K_(PP, k + 1) = (dd - K_(PP, k)) / bet;
         }
         pe_k = pe_n;
+        dm_m = dm_k;
+        dm_k = dm_n;
       }
+      // ---- sweep 2 (down): back substitution
       for (int k = nz - 1; k >= 1; --k) K_(PP, k) = K_(PP, k) - K_(GAM, k) * K_(PP, k + 1);
     }
-    // ---- w solve
+    // ---- sweep 3 (up): forward elimination for w
     {
       // pem[k] rolling prefix sum (same operation order as the setup pass)
       Real pem_k = ptop;  // pem[0]
@@ -86,19 +102,30 @@ struct Sim1 {
       K_(GAM, nz - 1) = gam;
       bet = DM(nz - 1) - (aa_k + p1 + aa_k * gam);
       K_(W2, nz - 1) = (DM(nz - 1) * K_(w1, nz - 1) + dt * (K_(PP, nz) - K_(PP, nz - 1)) - p1 * ws - aa_k * K_(W2, nz - 2)) / bet;
+      // ---- sweep 4 (down): back substitution
       for (int k = nz - 2; k >= 0; --k) K_(W2, k) = K_(W2, k) - K_(GAM, k + 1) * K_(W2, k + 1);
     }
-    // ---- new pressure perturbation and layer thickness
+    // ---- sweep 5 (up): new pressure perturbation (+ the new w leaves through wout)
     K_(PE, 0) = (Real)0;
-    for (int k = 0; k < nz; ++k) K_(PE, k + 1) = K_(PE, k) + DM(k) * (K_(W2, k) - K_(w1, k)) * rdt;
+    for (int k = 0; k < nz; ++k) {
+      const Real w2k = K_(W2, k);
+      K_(PE, k + 1) = K_(PE, k) + DM(k) * (w2k - K_(w1, k)) * rdt;
+      if (wout) K_(wout, k) = w2k;
+    }
+    // ---- sweep 6 (down): new layer thickness, handed to the caller's finish
     Real p1 = (K_(PE, nz - 1) + (Real)2.0 * K_(PE, nz)) * r3;
-    K_(DZ, nz - 1) = -DM(nz - 1) * rgas * K_(pt, nz - 1) *
-                     exp((K_(cappa, nz - 1) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, nz - 1), p1 + K_(PM, nz - 1))));
+    {
+      const Real dzn = -DM(nz - 1) * rgas * K_(pt, nz - 1) * exp((K_(cappa, nz - 1) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, nz - 1), p1 + K_(PM, nz - 1))));
+      K_(DZ, nz - 1) = dzn;
+      finish(nz - 1, dzn);
+    }
     for (int k = nz - 2; k >= 0; --k) {
       const Real g_rat = DM(k) / DM(k + 1);
       const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
       p1 = (K_(PE, k) + bb * K_(PE, k + 1) + g_rat * K_(PE, k + 2)) * r3 - g_rat * p1;
-      K_(DZ, k) = -DM(k) * rgas * K_(pt, k) * exp((K_(cappa, k) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, k), p1 + K_(PM, k))));
+      const Real dzn = -DM(k) * rgas * K_(pt, k) * exp((K_(cappa, k) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, k), p1 + K_(PM, k))));
+      K_(DZ, k) = dzn;
+      finish(k, dzn);
     }
   }
 };
@@ -180,28 +207,32 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
     const unsigned pix = IX(i, j);
     const long p = tb + pix;
     (void)p;
-    // setup: layer-mean pressure without condensate, thickness
+    // setup (inside the solver's first sweep): layer-mean pressure without condensate, thickness
     Real peg = ptop;
-    for (int k = 0; k < nz; ++k) {
+    auto setup = [&](int k, Real &pm, Real &dz) {
       const Real dm = K_(delpc, k);
       const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
-      K_(PM, k) = (peg_n - peg) / log(peg_n / peg);
-      K_(DZ, k) = K_(gz, k + 1) - K_(gz, k);
+      pm = (peg_n - peg) / log(peg_n / peg);
+      dz = K_(gz, k + 1) - K_(gz, k);
+      K_(PM, k) = pm;
+      K_(DZ, k) = dz;
       peg = peg_n;
-    }
-    sim.run(tb, pix, dt2, delpc, cappa, ptc, w3, ws[t * g.st2 + IX(i, j)], PM, DZ, W2, PP, GAM, pef);
-    // full interface pressure and geopotential
+    };
+    // finish (inside the last sweep): geopotential from the new thickness
+    Real z = phis[t * g.st2 + IX(i, j)];
+    const Real z_bot = z;
+    auto finish = [&](int k, Real dz) {
+      z = z - dz * grav;
+      K_(gz, k) = z;
+    };
+    sim.run(tb, pix, dt2, delpc, cappa, ptc, w3, ws[t * g.st2 + IX(i, j)], PM, DZ, W2, PP, GAM, pef, (Real *)nullptr, setup, finish);
+    K_(gz, nz) = z_bot;  // (after the solve: setup reads the incoming gz[nz])
+    // full interface pressure
     Real pem = ptop;
     K_(pef, 0) = ptop;
     for (int k = 0; k < nz; ++k) {
       pem = pem + K_(delpc, k);
       K_(pef, k + 1) = K_(pef, k + 1) + pem;
-    }
-    Real z = phis[t * g.st2 + IX(i, j)];
-    K_(gz, nz) = z;
-    for (int k = nz - 1; k >= 0; --k) {
-      z = z - K_(DZ, k) * grav;
-      K_(gz, k) = z;
     }
   });
   return fv3_post(c, s, "riem_solver_c");
@@ -236,7 +267,9 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
       K_(pk, 0) = K_(pk3, 0);
       K_(pe, 0) = pem;
     }
-    for (int k = 0; k < nz; ++k) {
+    (void)peln_k;
+    // setup (inside the solver's first sweep): interface pressures / Exner functions, layer-mean pressure, thickness
+    auto setup = [&](int k, Real &pm, Real &dz) {
       const Real dm = K_(delp, k);
       pem = pem + dm;
       const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
@@ -248,20 +281,22 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
         K_(pk, k + 1) = pk3v;
         K_(pe, k + 1) = pem;
       }
-      K_(PM, k) = (peg_n - peg) / (pelng_n - pelng_k);
-      K_(delz, k) = K_(zh, k + 1) - K_(zh, k);  // dz2 lives in the output array
+      pm = (peg_n - peg) / (pelng_n - pelng_k);
+      dz = K_(zh, k + 1) - K_(zh, k);
+      K_(PM, k) = pm;
+      K_(delz, k) = dz;  // dz2 lives in the output array
       peg = peg_n;
       pelng_k = pelng_n;
-    }
-    (void)peln_k;
-    sim.run(tb, pix, dt, delp, cappa, pt, w, wsd[t * g.st2 + IX(i, j)], PM, delz, W2, PP, GAM, ppe);
+    };
+    // finish (inside the last sweep): interface heights from the new thickness
     Real z = zs[t * g.st2 + IX(i, j)];
-    K_(zh, nz) = z;
-    for (int k = nz - 1; k >= 0; --k) {
-      K_(w, k) = K_(W2, k);
-      z = z - K_(delz, k);
+    const Real z_bot = z;
+    auto finish = [&](int k, Real dz) {
+      z = z - dz;
       K_(zh, k) = z;
-    }
+    };
+    sim.run(tb, pix, dt, delp, cappa, pt, w, wsd[t * g.st2 + IX(i, j)], PM, delz, W2, PP, GAM, ppe, w, setup, finish);
+    K_(zh, nz) = z_bot;
   });
   return fv3_post(c, s, "riem_solver3");
 }

@@ -236,6 +236,16 @@ def test_full_acoustic_call_config_variants(backend, kw):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
+@pytest.mark.parametrize("nz", [3, 127])
+def test_full_acoustic_call_level_counts(backend, nz):
+    """Smallest supported and largest configured level count (BASELINE cfg-5 uses L127)."""
+    part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 112.5, 1)
+    got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 112.5)
+    compare_cubes(got, ost, part, nz, STATE, TOL)
+
+
 def test_full_acoustic_call_multi_tile(backend):
     """C96: sub-domains span several LDS tiles (64 x 8 transport, 64 x 16 del-n), so interior,
     tile-edge, cube-corner-window and partial tiles of the fused kernels are all exercised."""
