@@ -486,20 +486,22 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
       }
     });
   }
-  // transport of every interface height + del-n damping
-  tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, fx, fy, nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz);
+  // transport of every interface height: the advective-form update is the transport kernel's epilogue
+  // (zadv; the height fluxes are never stored), then the del-n damping term
+  Real *zadv = fx;
+  {
+    const TpEpi e{zadv, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true};
+    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz, &e);
+  }
   int nord_max = 0;
   for (int k = 0; k <= nz; ++k) nord_max = std::max(nord_max, c->nord_v_h[k]);
   Deln dn{g.nord_v, g.damp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
   del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
-    const Real ar = (g.area + m2)[p];
-    const Real ra_x = ar + (xfx_a + b)[p] - (xfx_a + b)[pe_];
-    const Real ra_y = ar + (yfx_a + b)[p] - (yfx_a + b)[pn];
-    Real z = ((zh + b)[p] * ar + (fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) / (ra_x + ra_y - ar);
-    if (g.damp_vt[k] > (Real)1.0e-5) z = z + ((fx2 + b)[p] - (fx2 + b)[pe_] + (fy2 + b)[p] - (fy2 + b)[pn]) * (g.rarea + m2)[p];
+    const unsigned p = IX(i, j);
+    Real z = (zadv + b)[p];
+    if (g.damp_vt[k] > (Real)1.0e-5) z = z + ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * (g.rarea + m2)[p];
     (zh + b)[p] = z;
   });
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {

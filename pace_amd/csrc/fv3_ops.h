@@ -62,6 +62,9 @@ struct TpEpi {
   Real *acc_x, *acc_y;
   Real *wind_u, *wind_v;
   const Real *wind_ke;
+  // area_form: out = (q * area + fx - fx[i+1] + fy - fy[j+1]) / (ra_x + ra_y - area) with ra_x = area + xfx - xfx[i+1],
+  // ra_y = area + yfx - yfx[j+1]  (update_dz_d's advective-form height update) instead of the flux form above
+  bool area_form;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

@@ -438,7 +438,8 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
   const int nseg = (g.ny + seg - 1) / seg;
-  const size_t smem = sizeof(Real) * (2 * TS_LINE + 3 * (FV3_WAVE + 1));
+  const size_t smem = sizeof(Real) * (2 * TS_LINE + 4 * (FV3_WAVE + 1));
+  const bool area_form = epi && epi->area_form;
   Real *epi_out = epi ? epi->out : nullptr;
   const Real *epi_mult = epi ? epi->mult : nullptr;
   const bool wflux = epi ? epi->write_flux : true;
@@ -466,6 +467,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     Real *exp_ = lqi + TS_LINE;       // xfx * fx_in of the lane (read by lane - 1)
     Real *exx = exp_ + FV3_WAVE + 1;  // xfx
     Real *exf = exx + FV3_WAVE + 1;   // final fx of the lane's face (epilogue: read by lane - 1)
+    Real *exj = exf + FV3_WAVE + 1;   // xfx(i, r-3) (area-form epilogue)
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
     const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
@@ -486,6 +488,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT];
     Real mb[FV3_LPT];  // mass(i, r-3) = mass(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
+    Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
@@ -521,7 +524,8 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
-      if (lane == 0) exf[FV3_WAVE] = (Real)0;
+      if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
+      xjr[l] = ypp[l] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
@@ -602,6 +606,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           const Real ar3 = cur[l].ar3;
           const Real qi = (w2[l] * ar3 + p_prev[l] - pn) / (ar3 + y_prev[l] - yv);
           p_prev[l] = pn;
+          ypp[l] = y_prev[l];
           y_prev[l] = yv;
           lq[3 + lane] = qx;
           lqi[3 + lane] = qi;
@@ -639,6 +644,10 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
             if (epi_out) {
               fxk[l] = v;
               exf[lane] = v;
+              if (area_form) {
+                xjr[l] = xv3[l];
+                exj[lane] = xv3[l];
+              }
             }
           }
           fi3[l] = fi2[l];
@@ -692,8 +701,14 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
               if (fx_row && own_y[l]) {
                 const Real qc = w2[l];  // q(i, r-3)
                 const Real mu = epi_mult ? (epi_mult == mass ? mb[l] : emu[l]) : (Real)1;
-                const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
-                (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult ? mu * qc + dv_ : qc + dv_;
+                if (area_form) {
+                  const Real ar_ = cur[l].ar3;
+                  const Real ra_x = ar_ + xjr[l] - exj[lane + 1], ra_y = ar_ + ypp[l] - cur[l].yv;
+                  (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
+                } else {
+                  const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
+                  (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult ? mu * qc + dv_ : qc + dv_;
+                }
               }
               fyp[l] = v;
             }
@@ -725,6 +740,7 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     Real *out = epi->out;
     const Real *mult = epi->mult;
     Real *ax = epi->acc_x, *ay = epi->acc_y;
+    const bool aform = epi->area_form;
     Real *wu_ = epi->wind_u, *wv_ = epi->wind_v;
     const Real *wk_ = epi->wind_ke;
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -736,8 +752,15 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
         if (j <= g.ny) (wv_ + b)[p] = (wv_ + b)[p] * (g.dy + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i, j + 1)] - (fx + b)[p];
       }
       if (out && i <= g.nx && j <= g.ny) {
-        const Real dv_ = ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-        (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
+        const unsigned pe_ = IX(i + 1, j), pn = IX(i, j + 1);
+        if (aform) {
+          const Real ar = g.area[t * g.st2 + p];
+          const Real ra_x = ar + (xfx + b)[p] - (xfx + b)[pe_], ra_y = ar + (yfx + b)[p] - (yfx + b)[pn];
+          (out + b)[p] = ((q + b)[p] * ar + (fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) / (ra_x + ra_y - ar);
+        } else {
+          const Real dv_ = ((fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) * g.rarea[t * g.st2 + p];
+          (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
+        }
       }
       if (ax && j <= g.ny) (ax + b)[p] += (fx + b)[p];
       if (ay && i <= g.nx) (ay + b)[p] += (fy + b)[p];
