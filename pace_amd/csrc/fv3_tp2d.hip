@@ -423,7 +423,12 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 #define TS_PF 2  // rows fetched ahead of their use (1 or 2)
 #endif
 
-static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
+// FEAT: compile-time feature mask (TF_*): every call site gets a kernel that carries only the state,
+// pointers and branches it uses (the all-features kernel sat at 256 VGPRs with scratch and 131 spilled SGPRs).
+enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND = 32, TF_WFLUX = 64, TF_ACC = 128, TF_ALL = 255 };
+
+template <unsigned FEAT>
+static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
                         const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   const Geo g = c->g;
   Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
@@ -455,6 +460,16 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr area = g.area;
   launch_waves<TS_WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    // fold the features this instantiation does not have
+    constexpr bool C_MFX = FEAT & TF_MFX, C_DAMP = FEAT & TF_DAMP, C_MASS = FEAT & TF_MASS, C_EPI = FEAT & TF_EPI, C_AREA = FEAT & TF_AREA;
+    constexpr bool C_WIND = FEAT & TF_WIND, C_WFLUX = FEAT & TF_WFLUX, C_ACC = FEAT & TF_ACC;
+    const Real *const mfx_ = C_MFX ? mfx : nullptr, *const mfy_ = C_MFX ? mfy : nullptr, *const mass_ = C_MASS ? mass : nullptr;
+    Real *const epi_out_ = C_EPI ? epi_out : nullptr;
+    const Real *const epi_mult_ = C_EPI ? epi_mult : nullptr;
+    Real *const acc_x_ = C_ACC ? acc_x : nullptr, *const acc_y_ = C_ACC ? acc_y : nullptr;
+    Real *const wind_u_ = C_WIND ? wind_u : nullptr, *const wind_v_ = C_WIND ? wind_v : nullptr;
+    const Real *const wind_ke_ = C_WIND ? wind_ke : nullptr;
+    const bool wflux_ = C_WFLUX && wflux, area_form_ = C_AREA && area_form;
     const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
@@ -473,20 +488,20 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
     const bool S = fl & FV3_S, N = fl & FV3_N;
     const bool halo_cols = i0 - 3 < 1 || i0 + FV3_WAVE - 4 > nx;
-    const bool on = damped && deln_on(d, k);
+    const bool on = C_DAMP && damped && deln_on(d, k);
     const Real damp = on ? deln_damp(d, k) : (Real)0;
     const int r_end = jb + 3 < jed ? jb + 3 : jed;
-    const bool need_mc = mass && (on || (epi_out && epi_mult == mass));  // mass(i, r-2): damping weight and / or epilogue multiplier
+    const bool need_mc = mass_ && (on || (epi_out_ && epi_mult_ == mass_));  // mass_(i, r-2): damping weight and / or epilogue multiplier
 
     // per-lane marching state
     struct Row {  // the inputs of one step, fetched TS_PF steps ahead of their use
       Real qy, cx, xv, ar, cy, yv, ar3;
     };
-    // optional inputs consumed at the end of a step (mass fluxes, damping fluxes, mass(i-1, r-3), mass(i, r-2),
+    // optional inputs consumed at the end of a step (mass_ fluxes, damping fluxes, mass_(i-1, r-3), mass_(i, r-2),
     // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
     // (loads return in order) leaves the prefetched rows in flight
     Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT];
-    Real mb[FV3_LPT];  // mass(i, r-3) = mass(i, r-2) of the previous step
+    Real mb[FV3_LPT];  // mass_(i, r-3) = mass_(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
@@ -547,28 +562,28 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           {
             const int rf = r - 2 < jsd ? jsd : r - 2;
             const unsigned p3 = pcol[l] + (unsigned)(r3 * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
-            if (mfx) {
-              o_mx[l] = (mfx + b)[p3];
-              o_my[l] = (mfy + b)[pf];
+            if (mfx_) {
+              o_mx[l] = (mfx_ + b)[p3];
+              o_my[l] = (mfy_ + b)[pf];
             }
             if (on) {
               o_dx[l] = (dfx + b)[p3];
               o_dy[l] = (dfy + b)[pf];
-              if (mass) o_ma[l] = (mass + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
+              if (mass_) o_ma[l] = (mass_ + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
             }
-            if (need_mc) o_mc[l] = (mass + b)[pf];
-            if (epi_out) {
+            if (need_mc) o_mc[l] = (mass_ + b)[pf];
+            if (epi_out_) {
               era[l] = (rarea + m2)[p3];
-              if (epi_mult && epi_mult != mass) emu[l] = (epi_mult + b)[p3];
+              if (epi_mult_ && epi_mult_ != mass_) emu[l] = (epi_mult_ + b)[p3];
             }
-            if (wind_u) {
-              wu[l] = (wind_u + b)[pf];
+            if (wind_u_) {
+              wu[l] = (wind_u_ + b)[pf];
               wdx[l] = (gdx + m2)[pf];
-              wkf[l] = (wind_ke + b)[pf];      // ke(i, jf) -- also ke(i, jr + 1)
-              wke[l] = (wind_ke + b)[pf + 1];  // ke(i + 1, jf)
-              wv[l] = (wind_v + b)[p3];
+              wkf[l] = (wind_ke_ + b)[pf];      // ke(i, jf) -- also ke(i, jr + 1)
+              wke[l] = (wind_ke_ + b)[pf + 1];  // ke(i + 1, jf)
+              wv[l] = (wind_v_ + b)[p3];
               wdy[l] = (gdy + m2)[p3];
-              wkr[l] = (wind_ke + b)[p3];      // ke(i, jr)
+              wkr[l] = (wind_ke_ + b)[p3];      // ke(i, jr)
             }
           }
           cur[l] = nxt[l];
@@ -633,18 +648,18 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
             fxout = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord);
           }
           {
-            Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx ? o_mx[l] : xv3[l]);
-            if (on) v = mass ? v + (Real)0.5 * damp * (o_ma[l] + mb[l]) * o_dx[l] : v + o_dx[l];
-            if (wflux && fx_row && own_x[l]) {
+            Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx_ ? o_mx[l] : xv3[l]);
+            if (on) v = mass_ ? v + (Real)0.5 * damp * (o_ma[l] + mb[l]) * o_dx[l] : v + o_dx[l];
+            if (wflux_ && fx_row && own_x[l]) {
               const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
               (fx + b)[p] = v;
-              if (acc_x) (acc_x + b)[p] += v;
+              if (acc_x_) (acc_x_ + b)[p] += v;
             }
-            if (wind_v && fx_row && own_x[l]) (wind_v + b)[pcol[l] + (unsigned)(jr * sj32)] = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
-            if (epi_out) {
+            if (wind_v_ && fx_row && own_x[l]) (wind_v_ + b)[pcol[l] + (unsigned)(jr * sj32)] = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
+            if (epi_out_) {
               fxk[l] = v;
               exf[lane] = v;
-              if (area_form) {
+              if (area_form_) {
                 xjr[l] = xv3[l];
                 exj[lane] = xv3[l];
               }
@@ -688,26 +703,26 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
           const Real fyout = ppm_face(cv[l], co, cur[l].cy);
           cv[l] = co;
           {
-            Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy ? o_my[l] : cur[l].yv);
-            if (on) v = mass ? v + (Real)0.5 * damp * (mb[l] + o_mc[l]) * o_dy[l] : v + o_dy[l];
-            if (wflux && fy_row && own_y[l]) {
+            Real v = (Real)0.5 * (fyout + fyin[l]) * (mfy_ ? o_my[l] : cur[l].yv);
+            if (on) v = mass_ ? v + (Real)0.5 * damp * (mb[l] + o_mc[l]) * o_dy[l] : v + o_dy[l];
+            if (wflux_ && fy_row && own_y[l]) {
               const unsigned p = pcol[l] + (unsigned)(jf * sj32);
               (fy + b)[p] = v;
-              if (acc_y) (acc_y + b)[p] += v;
+              if (acc_y_) (acc_y_ + b)[p] += v;
             }
-            if (wind_u && fy_row && own_y[l]) (wind_u + b)[pcol[l] + (unsigned)(jf * sj32)] = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
-            if (epi_out) {
+            if (wind_u_ && fy_row && own_y[l]) (wind_u_ + b)[pcol[l] + (unsigned)(jf * sj32)] = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
+            if (epi_out_) {
               // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
               if (fx_row && own_y[l]) {
                 const Real qc = w2[l];  // q(i, r-3)
-                const Real mu = epi_mult ? (epi_mult == mass ? mb[l] : emu[l]) : (Real)1;
-                if (area_form) {
+                const Real mu = epi_mult_ ? (epi_mult_ == mass_ ? mb[l] : emu[l]) : (Real)1;
+                if (area_form_) {
                   const Real ar_ = cur[l].ar3;
                   const Real ra_x = ar_ + xjr[l] - exj[lane + 1], ra_y = ar_ + ypp[l] - cur[l].yv;
-                  (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
+                  (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
                 } else {
                   const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
-                  (epi_out + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult ? mu * qc + dv_ : qc + dv_;
+                  (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult_ ? mu * qc + dv_ : qc + dv_;
                 }
               }
               fyp[l] = v;
@@ -723,6 +738,38 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     else
       march(std::false_type{});
   });
+}
+
+static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
+                        const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
+  unsigned m = 0;
+  if (mfx) m |= TF_MFX;
+  if (dn) m |= TF_DAMP;
+  if (mass) m |= TF_MASS;
+  if (!epi || epi->write_flux) m |= TF_WFLUX;
+  if (epi) {
+    if (epi->out) m |= TF_EPI;
+    if (epi->area_form) m |= TF_AREA;
+    if (epi->wind_u) m |= TF_WIND;
+    if (epi->acc_x) m |= TF_ACC;
+  }
+#define TP_CASE(F)                                                                                          \
+  case (F):                                                                                                 \
+    tp2d_stream_t<(F)>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi); \
+    return;
+  switch (m) {
+    TP_CASE(TF_WFLUX)                                             // plain transport (C entry)
+    TP_CASE(TF_DAMP | TF_WFLUX)                                   // damped (C entry)
+    TP_CASE(TF_MFX | TF_MASS | TF_DAMP | TF_WFLUX)                // mass-flux weighted + damped (C entry)
+    TP_CASE(TF_DAMP | TF_EPI | TF_WFLUX | TF_ACC)                 // d_sw: delp
+    TP_CASE(TF_MFX | TF_EPI)                                      // d_sw: w
+    TP_CASE(TF_MFX | TF_MASS | TF_DAMP | TF_EPI)                  // d_sw: q_con, pt
+    TP_CASE(TF_WIND)                                              // d_sw: absolute vorticity + wind update
+    TP_CASE(TF_EPI | TF_AREA)                                     // update_dz_d: interface heights
+    default:
+      tp2d_stream_t<TF_ALL>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+  }
+#undef TP_CASE
 }
 
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
