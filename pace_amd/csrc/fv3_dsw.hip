@@ -658,7 +658,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
   {
     // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
-    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false};
+    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
     tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
   }
 
@@ -681,18 +681,18 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     });
   }
   {
-    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false};  // delp * w + div
+    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};  // delp * w + div
     tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
   // ---- condensate
   {
     Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
     tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
   }
   // ---- potential temperature, then the divisions by the new air mass
   {
-    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
     tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -890,7 +890,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
   //      transport kernel's epilogue (the vorticity fluxes are never stored)
   {
-    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false};
+    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr};
     tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
 

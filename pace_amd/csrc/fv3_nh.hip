@@ -416,6 +416,83 @@ extern "C" int fv3_edge_pe(fv3_ctx *c, const fv3_field *pe_, const fv3_field *de
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// edge_profile with the whole column in registers (level count known at compile time): the NZ layer
+// values are loaded up front (NZ independent loads in flight per lane), the forward elimination and the
+// back substitution run in place on the register array and the NZ+1 interface values are stored once --
+// one read and one write per field instead of the two column walks of the generic form below.
+// ---------------------------------------------------------------------------------------------
+template <int NZ>
+static void edge_profile_reg(fv3_ctx *c, fv3_stream_t s, const Real *crx, const Real *xfx, const Real *cry, const Real *yfx, Real *crx_a, Real *xfx_a, Real *cry_a,
+                             Real *yfx_a) {
+  const Geo g = c->g;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  const Real *gamd = g.ep_gam;
+  launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+    const long tb = t * g.st;
+    const unsigned pix = IX(i, j);
+    auto profile = [&](const Real *q, Real *qe) {
+      const Real *dp0 = g.dp_ref;
+      Real a[NZ + 1];
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) a[k] = K_(q, k);
+      const Real g0 = dp0[1] / dp0[0];
+      Real xt1 = (Real)2.0 * g0 * (g0 + (Real)1.0);
+      Real bet = g0 * (g0 + (Real)0.5);
+      Real q_m = a[0], q_mm = a[0];  // q[k-1], q[k-2] (original layer values)
+      a[0] = (xt1 * a[0] + a[1]) / bet;
+      Real gam_prev = ((Real)1.0 + g0 * (g0 + (Real)1.5)) / bet;
+      Real gk = g0;
+#pragma unroll
+      for (int k = 1; k < NZ; ++k) {
+        gk = dp0[k - 1] / dp0[k];
+        bet = (Real)2.0 + (Real)2.0 * gk - gam_prev;
+        const Real qk = a[k];
+        a[k] = ((Real)3.0 * (q_m + gk * qk) - a[k - 1]) / bet;
+        gam_prev = gk / bet;
+        q_mm = q_m;
+        q_m = qk;
+      }
+      const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
+      xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
+      const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
+      a[NZ] = (xt1 * q_m + q_mm - a_bot * a[NZ - 1]) / xt2;
+#pragma unroll
+      for (int k = NZ - 1; k >= 0; --k) a[k] = a[k] - gamd[k] * a[k + 1];
+#pragma unroll
+      for (int k = 0; k <= NZ; ++k) K_(qe, k) = a[k];
+    };
+    if (i >= 1 && i <= g.nx + 1) {
+      profile(crx, crx_a);
+      profile(xfx, xfx_a);
+    }
+    if (j >= 1 && j <= g.ny + 1) {
+      profile(cry, cry_a);
+      profile(yfx, yfx_a);
+    }
+  });
+}
+
+// returns false when the level count has no register-resident instantiation (the caller then runs the generic form)
+static bool edge_profile_columns(fv3_ctx *c, fv3_stream_t s, const Real *crx, const Real *xfx, const Real *cry, const Real *yfx, Real *crx_a, Real *xfx_a, Real *cry_a,
+                                 Real *yfx_a) {
+  static const bool generic = getenv("FV3_EDGE_PROFILE_GENERIC") != nullptr;  // A/B switch
+  if (generic) return false;
+  switch (c->g.nz) {
+    case 79:
+      edge_profile_reg<79>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    case 127:
+      edge_profile_reg<127>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    case 8:  // exercised by the parity tests
+      edge_profile_reg<8>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    default:
+      return false;
+  }
+}
+
 extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field *zh_, const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_,
                                const fv3_field *yfx_, const fv3_field *wsd_, double dtd, void *stream) {
   if (!c) return FV3_ERR_ARG;
@@ -429,90 +506,86 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   Real *fx = c->scratch[SC_E], *fy = c->scratch[SC_F], *fx2 = c->scratch[SC_G], *fy2 = c->scratch[SC_H], *d2 = c->scratch[SC_I];
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   // cubic-spline-like layer -> interface interpolation (FV3 edge_profile, limiter 0)
-  launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long tb = t * g.st;
-    const unsigned pix = IX(i, j);
-    const long p = tb + pix;
-    (void)p;
-    auto profile = [&](const Real *q, Real *qe) {
-      const Real *dp0 = g.dp_ref;
-      const Real g0 = dp0[1] / dp0[0];
-      Real xt1 = (Real)2.0 * g0 * (g0 + (Real)1.0);
-      Real bet = g0 * (g0 + (Real)0.5);
-      K_(qe, 0) = (xt1 * K_(q, 0) + K_(q, 1)) / bet;
-      Real gam_prev = ((Real)1.0 + g0 * (g0 + (Real)1.5)) / bet;
-      Real gk = g0;
-      // gam[k] is level-only: recomputed in the backward sweep from the same recurrence
-      for (int k = 1; k < nz; ++k) {
-        gk = dp0[k - 1] / dp0[k];
-        bet = (Real)2.0 + (Real)2.0 * gk - gam_prev;
-        K_(qe, k) = ((Real)3.0 * (K_(q, k - 1) + gk * K_(q, k)) - K_(qe, k - 1)) / bet;
-        gam_prev = gk / bet;
-      }
-      const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
-      xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
-      const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
-      K_(qe, nz) = (xt1 * K_(q, nz - 1) + K_(q, nz - 2) - a_bot * K_(qe, nz - 1)) / xt2;
-    };
-    const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
-    if (inx) {
-      profile(crx, crx_a);
-      profile(xfx, xfx_a);
-    }
-    if (iny) {
-      profile(cry, cry_a);
-      profile(yfx, yfx_a);
-    }
-  });
-  // backward sweep: gam[k] depends on dp_ref only (table built at context creation)
-  {
-    const Real *gamd = g.ep_gam;
+  if (!edge_profile_columns(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a)) {
     launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
       const long tb = t * g.st;
-    const unsigned pix = IX(i, j);
-    const long p = tb + pix;
-    (void)p;
+      const unsigned pix = IX(i, j);
+      const long p = tb + pix;
+      (void)p;
+      auto profile = [&](const Real *q, Real *qe) {
+        const Real *dp0 = g.dp_ref;
+        const Real g0 = dp0[1] / dp0[0];
+        Real xt1 = (Real)2.0 * g0 * (g0 + (Real)1.0);
+        Real bet = g0 * (g0 + (Real)0.5);
+        K_(qe, 0) = (xt1 * K_(q, 0) + K_(q, 1)) / bet;
+        Real gam_prev = ((Real)1.0 + g0 * (g0 + (Real)1.5)) / bet;
+        Real gk = g0;
+        // gam[k] is level-only: recomputed in the backward sweep from the same recurrence
+        for (int k = 1; k < nz; ++k) {
+          gk = dp0[k - 1] / dp0[k];
+          bet = (Real)2.0 + (Real)2.0 * gk - gam_prev;
+          K_(qe, k) = ((Real)3.0 * (K_(q, k - 1) + gk * K_(q, k)) - K_(qe, k - 1)) / bet;
+          gam_prev = gk / bet;
+        }
+        const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
+        xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
+        const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
+        K_(qe, nz) = (xt1 * K_(q, nz - 1) + K_(q, nz - 2) - a_bot * K_(qe, nz - 1)) / xt2;
+      };
       const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
-      for (int k = nz - 1; k >= 0; --k) {
-        const Real gm = gamd[k];
-        if (inx) {
-          K_(crx_a, k) = K_(crx_a, k) - gm * K_(crx_a, k + 1);
-          K_(xfx_a, k) = K_(xfx_a, k) - gm * K_(xfx_a, k + 1);
-        }
-        if (iny) {
-          K_(cry_a, k) = K_(cry_a, k) - gm * K_(cry_a, k + 1);
-          K_(yfx_a, k) = K_(yfx_a, k) - gm * K_(yfx_a, k + 1);
-        }
+      if (inx) {
+        profile(crx, crx_a);
+        profile(xfx, xfx_a);
+      }
+      if (iny) {
+        profile(cry, cry_a);
+        profile(yfx, yfx_a);
       }
     });
+    // backward sweep: gam[k] depends on dp_ref only (table built at context creation)
+    {
+      const Real *gamd = g.ep_gam;
+      launch2(c, s, Box{isd, ied, jsd, jed, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+        const long tb = t * g.st;
+      const unsigned pix = IX(i, j);
+      const long p = tb + pix;
+      (void)p;
+        const bool inx = i >= 1 && i <= g.nx + 1, iny = j >= 1 && j <= g.ny + 1;
+        for (int k = nz - 1; k >= 0; --k) {
+          const Real gm = gamd[k];
+          if (inx) {
+            K_(crx_a, k) = K_(crx_a, k) - gm * K_(crx_a, k + 1);
+            K_(xfx_a, k) = K_(xfx_a, k) - gm * K_(xfx_a, k + 1);
+          }
+          if (iny) {
+            K_(cry_a, k) = K_(cry_a, k) - gm * K_(cry_a, k + 1);
+            K_(yfx_a, k) = K_(yfx_a, k) - gm * K_(yfx_a, k + 1);
+          }
+        }
+      });
+    }
   }
-  // transport of every interface height: the advective-form update is the transport kernel's epilogue
-  // (zadv; the height fluxes are never stored), then the del-n damping term
-  Real *zadv = fx;
-  {
-    const TpEpi e{zadv, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true};
-    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz, &e);
-  }
+  // del-n damping fluxes of the interface heights, then their transport: the advective-form update and the
+  // damping term are the transport kernel's epilogue (znew; the height fluxes are never stored)
   int nord_max = 0;
   for (int k = 0; k <= nz; ++k) nord_max = std::max(nord_max, c->nord_v_h[k]);
   Deln dn{g.nord_v, g.damp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
   del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const unsigned p = IX(i, j);
-    Real z = (zadv + b)[p];
-    if (g.damp_vt[k] > (Real)1.0e-5) z = z + ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * (g.rarea + m2)[p];
-    (zh + b)[p] = z;
-  });
+  Real *znew = fx;
+  {
+    const TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt};
+    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz, &e);
+  }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
     const long p = tb + pix;
     (void)p;
-    Real below = K_(zh, nz);
+    Real below = K_(znew, nz);
+    K_(zh, nz) = below;
     wsd[t * g.st2 + IX(i, j)] = (zs[t * g.st2 + IX(i, j)] - below) / dt;
     for (int k = nz - 1; k >= 0; --k) {
-      const Real v = fv3_max(K_(zh, k), below + dz_min);
+      const Real v = fv3_max(K_(znew, k), below + dz_min);
       K_(zh, k) = v;
       below = v;
     }

@@ -65,6 +65,9 @@ struct TpEpi {
   // area_form: out = (q * area + fx - fx[i+1] + fy - fy[j+1]) / (ra_x + ra_y - area) with ra_x = area + xfx - xfx[i+1],
   // ra_y = area + yfx - yfx[j+1]  (update_dz_d's advective-form height update) instead of the flux form above
   bool area_form;
+  // area form only (optional): out += (zfx - zfx[i+1] + zfy - zfy[j+1]) * rarea on the levels with zon[k] > 1e-5
+  // (update_dz_d's del-n damping of the interface heights; zfx / zfy are del6_vt_flux outputs)
+  const Real *zfx, *zfy, *zon;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

@@ -445,6 +445,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nseg = (g.ny + seg - 1) / seg;
   const size_t smem = sizeof(Real) * (2 * TS_LINE + 4 * (FV3_WAVE + 1));
   const bool area_form = epi && epi->area_form;
+  const Real *zfx = epi ? epi->zfx : nullptr, *zfy = epi ? epi->zfy : nullptr, *zon = epi ? epi->zon : nullptr;
   Real *epi_out = epi ? epi->out : nullptr;
   const Real *epi_mult = epi ? epi->mult : nullptr;
   const bool wflux = epi ? epi->write_flux : true;
@@ -504,6 +505,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real mb[FV3_LPT];  // mass_(i, r-3) = mass_(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
+    Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
+    const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
@@ -540,7 +543,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
-      xjr[l] = ypp[l] = (Real)0;
+      xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
@@ -575,6 +578,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (epi_out_) {
               era[l] = (rarea + m2)[p3];
               if (epi_mult_ && epi_mult_ != mass_) emu[l] = (epi_mult_ + b)[p3];
+              if (zdamp) {
+                zx0[l] = (zfx + b)[p3];
+                zx1[l] = (zfx + b)[p3 + 1];
+                zy0[l] = (zfy + b)[p3];
+                zy1[l] = (zfy + b)[p3 + (unsigned)sj32];
+              }
             }
             if (wind_u_) {
               wu[l] = (wind_u_ + b)[pf];
@@ -719,7 +728,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 if (area_form_) {
                   const Real ar_ = cur[l].ar3;
                   const Real ra_x = ar_ + xjr[l] - exj[lane + 1], ra_y = ar_ + ypp[l] - cur[l].yv;
-                  (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
+                  Real z = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
+                  if (zdamp) z = z + (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
+                  (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = z;
                 } else {
                   const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
                   (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult_ ? mu * qc + dv_ : qc + dv_;
@@ -788,6 +799,7 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     const Real *mult = epi->mult;
     Real *ax = epi->acc_x, *ay = epi->acc_y;
     const bool aform = epi->area_form;
+    const Real *zfx_ = epi->zfx, *zfy_ = epi->zfy, *zon_ = epi->zon;
     Real *wu_ = epi->wind_u, *wv_ = epi->wind_v;
     const Real *wk_ = epi->wind_ke;
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -803,7 +815,9 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
         if (aform) {
           const Real ar = g.area[t * g.st2 + p];
           const Real ra_x = ar + (xfx + b)[p] - (xfx + b)[pe_], ra_y = ar + (yfx + b)[p] - (yfx + b)[pn];
-          (out + b)[p] = ((q + b)[p] * ar + (fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) / (ra_x + ra_y - ar);
+          Real z = ((q + b)[p] * ar + (fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) / (ra_x + ra_y - ar);
+          if (zfx_ && zon_[k] > (Real)1.0e-5) z = z + ((zfx_ + b)[p] - (zfx_ + b)[pe_] + (zfy_ + b)[p] - (zfy_ + b)[pn]) * g.rarea[t * g.st2 + p];
+          (out + b)[p] = z;
         } else {
           const Real dv_ = ((fx + b)[p] - (fx + b)[pe_] + (fy + b)[p] - (fy + b)[pn]) * g.rarea[t * g.st2 + p];
           (out + b)[p] = mult ? (mult + b)[p] * (q + b)[p] + dv_ : (q + b)[p] + dv_;
