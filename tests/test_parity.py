@@ -246,11 +246,13 @@ def test_full_acoustic_call_level_counts(backend, nz):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
-def test_full_acoustic_call_multi_tile(backend):
-    """C96: sub-domains span several LDS tiles (64 x 8 transport, 64 x 16 del-n), so interior,
-    tile-edge, cube-corner-window and partial tiles of the fused kernels are all exercised."""
+@pytest.mark.parametrize("n", [65, 96])
+def test_full_acoustic_call_multi_tile(backend, n):
+    """C96 / C65: sub-domains span several strips (58 / 61 columns) and row segments (64) of the marching
+    kernels -- interior waves, tile-edge waves, cube-corner patches, partial strips and a one-row last
+    segment are all exercised."""
     nz = 4
-    part, cfg, grids, ost, phis, odyn = oracle_cube(96, (1, 1), nz, dict(n_split=1))
+    part, cfg, grids, ost, phis, odyn = oracle_cube(n, (1, 1), nz, dict(n_split=1))
     init = [{k: v.copy() for k, v in s.items()} for s in ost]
     odyn(ost, 60.0, 1)
     got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
