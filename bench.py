@@ -171,6 +171,7 @@ def main():
                 "cells_global": h.cells_global,
             },
             "finite": ok,
+            "state_checksum": h.checksum(),
         }
         if "d_sw" in op_ms:
             alg = D_SW_PASSES * (8 if a.precision == 64 else 4) * h.cells_local

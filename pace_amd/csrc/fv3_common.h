@@ -117,6 +117,11 @@ struct fv3_ctx {
   double rf_dt = 0.0, rf_ptop = 0.0, rf_dm = 0.0;
   int rf_nd = 0, rf_nn = 0;
   std::string err;
+  // auxiliary stream: bandwidth-bound helper kernels (the del-n chains of d_sw) run there, one
+  // operator ahead of the issue-bound transport kernels on the caller's stream (fv3_aux_* below)
+  void *aux_stream = nullptr;
+  void *aux_events[8] = {nullptr};
+  int aux_on = 1;
   // per-operator profiling (fv3_step.hip)
   int profiling = 0;
   struct ProfEvent {
@@ -134,6 +139,15 @@ struct fv3_gather_plan {
   int64_t *src_off;
   signed char *sign;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Two-stream helpers.  fv3_aux(c, s): the stream helper kernels go to (the caller's stream itself when
+// the auxiliary stream is off or in the host emulation -- everything then runs in program order).
+// fv3_signal(c, from, e) / fv3_wait(c, to, e): event e recorded on `from`, later awaited by `to`.
+// ---------------------------------------------------------------------------------------------
+fv3_stream_t fv3_aux(fv3_ctx *c, fv3_stream_t s);
+void fv3_signal(fv3_ctx *c, fv3_stream_t from, int e);
+void fv3_wait(fv3_ctx *c, fv3_stream_t to, int e);
 
 // ---------------------------------------------------------------------------------------------
 // error helpers

@@ -287,12 +287,66 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     fv3_h2d(gd, &c->g, sizeof(Geo));
     c->g_dev = gd;
   }
+#ifndef FV3_HOST_EMU
+  {
+    // FV3_AUX_STREAM=1: run d_sw's del-n chains on a second stream, one transport ahead.  Off by default:
+    // measured on MI355X (C768) the two streams give bitwise identical states and the same time (d_sw
+    // 91.3-92.0 ms on, 91.8 ms off) -- the transport kernel holds 460 of the 512 VGPRs per SIMD lane, so
+    // the helper kernels find no room to run beside it.
+    const char *e = getenv("FV3_AUX_STREAM");
+    const char *m = getenv("FV3_TP2D_MODE");  // the staged A/B form recomputes the damping fluxes in shared scratch
+    c->aux_on = (e && e[0] == '1') && !(m && !strcmp(m, "staged"));
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) c->aux_stream = (void *)st;
+    for (auto &ev : c->aux_events) {
+      hipEvent_t h;
+      if (hipEventCreateWithFlags(&h, hipEventDisableTiming) == hipSuccess) ev = (void *)h;
+    }
+  }
+#endif
   *out = c;
   return FV3_OK;
 }
 
+extern "C++" {
+fv3_stream_t fv3_aux(fv3_ctx *c, fv3_stream_t s) {
+#ifdef FV3_HOST_EMU
+  (void)c;
+  return s;
+#else
+  return (c->aux_on && c->aux_stream) ? (fv3_stream_t)c->aux_stream : s;
+#endif
+}
+
+void fv3_signal(fv3_ctx *c, fv3_stream_t from, int e) {
+#ifdef FV3_HOST_EMU
+  (void)c;
+  (void)from;
+  (void)e;
+#else
+  if (c->aux_on && c->aux_stream) (void)hipEventRecord((hipEvent_t)c->aux_events[e], from);
+#endif
+}
+
+void fv3_wait(fv3_ctx *c, fv3_stream_t to, int e) {
+#ifdef FV3_HOST_EMU
+  (void)c;
+  (void)to;
+  (void)e;
+#else
+  if (c->aux_on && c->aux_stream) (void)hipStreamWaitEvent(to, (hipEvent_t)c->aux_events[e], 0);
+#endif
+}
+
+}  // extern "C++"
+
 int fv3_ctx_destroy(fv3_ctx *c) {
   if (!c) return FV3_OK;
+#ifndef FV3_HOST_EMU
+  for (void *e : c->aux_events)
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+  if (c->aux_stream) (void)hipStreamDestroy((hipStream_t)c->aux_stream);
+#endif
   for (void *p : c->owned) raw_free(p);
   delete c;
   return FV3_OK;

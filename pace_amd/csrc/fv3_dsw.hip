@@ -650,23 +650,42 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     nord_max = std::max(nord_max, c->nord_h[k]);
   }
 
+  // The del-n damping chains of delp / w / q_con / pt are bandwidth-bound and need only the field itself;
+  // the transports are issue-bound.  The chains therefore run on the auxiliary stream, one transport
+  // ahead (two pairs of flux arrays, A and B), and overlap with fxadv and the transports on the main stream.
+  //   events: 0 fork | 1..4 chain of delp, w, q_con, pt ready | 5 pair A consumed | 6 pair B consumed
+  fv3_stream_t s2 = fv3_aux(c, s);
+  Real *dA_x = c->scratch[SC_DN_FX], *dA_y = c->scratch[SC_DN_FY], *dB_x = c->scratch[SC_S], *dB_y = c->scratch[SC_T], *d2w = c->scratch[SC_DN_D2];
+  Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
+  Deln dn_w{g.nord_w, tab.d6_w, g.damp_w, 0, (Real)0, false, (Real)1.0e-5, nord_max_w};
+  Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
+  fv3_signal(c, s, 0);
+  fv3_wait(c, s2, 0);
+  del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
+  fv3_signal(c, s2, 1);
+  del6_vt_flux(c, s2, w, d2w, dB_x, dB_y, dn_w, false, 0, nz1);
+  fv3_signal(c, s2, 2);
+
   fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy);
 
   // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
   //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
   Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
-  Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
   {
     // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
-    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
+    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+    fv3_wait(c, s, 1);
     tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
+    fv3_signal(c, s, 5);
   }
+  fv3_wait(c, s2, 5);
+  del6_vt_flux(c, s2, q_con, d2w, dA_x, dA_y, dn_t, true, 0, nz1);
+  fv3_signal(c, s2, 3);
 
   // ---- vertical velocity: del-n damping + heat, then transport with the mass fluxes
   {
-    Deln dn_w{g.nord_w, tab.d6_w, g.damp_w, 0, (Real)0, false, (Real)1.0e-5, nord_max_w};
-    Real *fx2 = c->scratch[SC_DN_FX], *fy2 = c->scratch[SC_DN_FY];
-    del6_vt_flux(c, s, w, c->scratch[SC_DN_D2], fx2, fy2, dn_w, false, 0, nz1);
+    Real *fx2 = dB_x, *fy2 = dB_y;
+    fv3_wait(c, s, 2);
     launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
       const unsigned p = IX(i, j);
@@ -679,20 +698,25 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       (dw + b)[p] = dwv;
       (heat_s + b)[p] = hs;
     });
+    fv3_signal(c, s, 6);
   }
+  fv3_wait(c, s2, 6);
+  del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
+  fv3_signal(c, s2, 4);
   {
-    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};  // delp * w + div
+    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr};  // delp * w + div
     tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
   // ---- condensate
   {
-    Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
+    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+    fv3_wait(c, s, 3);
     tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
   }
   // ---- potential temperature, then the divisions by the new air mass
   {
-    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr};
+    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dB_x, dB_y};
+    fv3_wait(c, s, 4);  // (also the join: nothing is left on the auxiliary stream after this chain)
     tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
@@ -890,7 +914,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
   //      transport kernel's epilogue (the vorticity fluxes are never stored)
   {
-    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr};
+    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr};
     tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
   }
 

@@ -573,7 +573,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
   Real *znew = fx;
   {
-    const TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt};
+    const TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt, nullptr, nullptr};
     tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz, &e);
   }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {

@@ -29,7 +29,9 @@ enum {
   SC_P = 22,
   SC_Q = 23,
   SC_R = 24,  // d_sw absolute vorticity
-  SC_COUNT = 25
+  SC_S = 25,  // second pair of del-n damping fluxes (d_sw pipelines the chains one transport ahead)
+  SC_T = 26,
+  SC_COUNT = 27
 };
 
 // Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]
@@ -68,6 +70,9 @@ struct TpEpi {
   // area form only (optional): out += (zfx - zfx[i+1] + zfy - zfy[j+1]) * rarea on the levels with zon[k] > 1e-5
   // (update_dz_d's del-n damping of the interface heights; zfx / zfy are del6_vt_flux outputs)
   const Real *zfx, *zfy, *zon;
+  // damping fluxes of q already computed by the caller (del6_vt_flux into these arrays): fv_tp_2d then does
+  // not run the del-n chain itself (d_sw computes them one transport ahead on the auxiliary stream)
+  const Real *damp_fx, *damp_fy;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

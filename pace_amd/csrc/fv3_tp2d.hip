@@ -437,7 +437,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   memset(&d, 0, sizeof(d));
   if (damped) {
     d = *dn;
-    del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
+    if (epi && epi->damp_fx) {  // computed by the caller
+      dfx = const_cast<Real *>(epi->damp_fx);
+      dfy = const_cast<Real *>(epi->damp_fy);
+    } else {
+      del6_vt_flux(c, s, q, c->scratch[SC_DN_D2], dfx, dfy, d, mass != nullptr, k0, k1);
+    }
   }
   const int nk = k1 - k0 + 1;
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;

@@ -109,6 +109,14 @@ class DycoreHarness:
         if not self.sf.hostemu:
             torch.cuda.synchronize(self.sf.device)
 
+    def checksum(self):
+        """Order-fixed float64 sums of the prognostic fields (bitwise comparable between runs of one build)."""
+        out = {}
+        for n in ("delp", "pt", "u", "v", "w", "delz", "q_con"):
+            v = getattr(self.state, n).view[..., : self.cfg.npz].double()
+            out[n] = float(v.sum().item())
+        return out
+
     def sanity(self):
         """SafetyChecker-style bounds [REF driver/pace/driver/driver.py:557-560] on the local state."""
         out = {}
