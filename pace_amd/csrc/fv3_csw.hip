@@ -214,31 +214,70 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     if (W && N) { vaa[IX(0, npy)] = n_va[6]; vaa[IX(0, npy + 1)] = n_va[7]; }
   });
 
-  // (C) divergence on corners
+  // (C) divergence on corners.  Two levels per thread: the ten metric terms of a corner are read once and
+  // used for both levels (they are 2/3 of this kernel's bytes).
   if (nord > 0) {
-    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const int npair = (nz1 + 2) / 2;
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
       const int fl = g.flags[t];
-      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+      const long m2 = t * g.st2;
       const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
       const int npx = g.npx, npy = g.npy;
-      auto UF = [&](int ii, int jj) -> Real {
+      // metric factors of the four faces around the corner (exactly the sub-expressions of the one-level form)
+      struct Face {
+        Real cs, f;  // cos sum, dyc * 0.5 * sin sum  -- kept as separate factors: (.. * dyc) * 0.5 * (sin + sin)
+        Real d, ss;
+        bool edge;
+      };
+      auto UFm = [&](int ii, int jj) {
         const unsigned q = IX(ii, jj), qm = IX(ii, jj - 1);
-        if ((S && jj == 1) || (N && jj == npy)) return (u + b)[q] * (g.dyc + m2)[q] * (Real)0.5 * ((g.sin_sg4 + m2)[qm] + (g.sin_sg2 + m2)[q]);
-        return ((u + b)[q] - (Real)0.25 * ((va + b)[qm] + (va + b)[q]) * ((g.cos_sg4 + m2)[qm] + (g.cos_sg2 + m2)[q])) * (g.dyc + m2)[q] * (Real)0.5 *
-               ((g.sin_sg4 + m2)[qm] + (g.sin_sg2 + m2)[q]);
+        Face m;
+        m.edge = (S && jj == 1) || (N && jj == npy);
+        m.cs = (g.cos_sg4 + m2)[qm] + (g.cos_sg2 + m2)[q];
+        m.d = (g.dyc + m2)[q];
+        m.ss = (g.sin_sg4 + m2)[qm] + (g.sin_sg2 + m2)[q];
+        m.f = (Real)0;
+        return m;
       };
-      auto VF = [&](int ii, int jj) -> Real {
+      auto VFm = [&](int ii, int jj) {
         const unsigned q = IX(ii, jj), qm = IX(ii - 1, jj);
-        if ((W && ii == 1) || (E && ii == npx)) return (v + b)[q] * (g.dxc + m2)[q] * (Real)0.5 * ((g.sin_sg3 + m2)[qm] + (g.sin_sg1 + m2)[q]);
-        return ((v + b)[q] - (Real)0.25 * ((ua + b)[qm] + (ua + b)[q]) * ((g.cos_sg3 + m2)[qm] + (g.cos_sg1 + m2)[q])) * (g.dxc + m2)[q] * (Real)0.5 *
-               ((g.sin_sg3 + m2)[qm] + (g.sin_sg1 + m2)[q]);
+        Face m;
+        m.edge = (W && ii == 1) || (E && ii == npx);
+        m.cs = (g.cos_sg3 + m2)[qm] + (g.cos_sg1 + m2)[q];
+        m.d = (g.dxc + m2)[q];
+        m.ss = (g.sin_sg3 + m2)[qm] + (g.sin_sg1 + m2)[q];
+        m.f = (Real)0;
+        return m;
       };
-      Real dv = VF(i, j - 1) - VF(i, j) + UF(i - 1, j) - UF(i, j);
-      if (W && S && i == 1 && j == 1) dv -= VF(1, 0);
-      if (E && S && i == npx && j == 1) dv -= VF(npx, 0);
-      if (E && N && i == npx && j == npy) dv += VF(npx, npy);
-      if (W && N && i == 1 && j == npy) dv += VF(1, npy);
-      (divgd + b)[IX(i, j)] = (g.rarea_c + m2)[IX(i, j)] * dv;
+      const Face mu0 = UFm(i - 1, j), mu1 = UFm(i, j), mv0 = VFm(i, j - 1), mv1 = VFm(i, j);
+      const bool cSW = W && S && i == 1 && j == 1, cSE = E && S && i == npx && j == 1, cNE = E && N && i == npx && j == npy, cNW = W && N && i == 1 && j == npy;
+      Face mvc = mv0;
+      if (cSW) mvc = VFm(1, 0);
+      if (cSE) mvc = VFm(npx, 0);
+      if (cNE) mvc = VFm(npx, npy);
+      if (cNW) mvc = VFm(1, npy);
+      const Real rac = (g.rarea_c + m2)[IX(i, j)];
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2 * kp + kk;
+        if (k > nz1) break;
+        const long b = t * g.st + k * g.sk;
+        auto UF = [&](int ii, int jj, const Face &m) -> Real {
+          const unsigned q = IX(ii, jj), qm = IX(ii, jj - 1);
+          if (m.edge) return (u + b)[q] * m.d * (Real)0.5 * m.ss;
+          return ((u + b)[q] - (Real)0.25 * ((va + b)[qm] + (va + b)[q]) * m.cs) * m.d * (Real)0.5 * m.ss;
+        };
+        auto VF = [&](int ii, int jj, const Face &m) -> Real {
+          const unsigned q = IX(ii, jj), qm = IX(ii - 1, jj);
+          if (m.edge) return (v + b)[q] * m.d * (Real)0.5 * m.ss;
+          return ((v + b)[q] - (Real)0.25 * ((ua + b)[qm] + (ua + b)[q]) * m.cs) * m.d * (Real)0.5 * m.ss;
+        };
+        Real dv = VF(i, j - 1, mv0) - VF(i, j, mv1) + UF(i - 1, j, mu0) - UF(i, j, mu1);
+        if (cSW) dv -= VF(1, 0, mvc);
+        if (cSE) dv -= VF(npx, 0, mvc);
+        if (cNE) dv += VF(npx, npy, mvc);
+        if (cNW) dv += VF(1, npy, mvc);
+        (divgd + b)[IX(i, j)] = rac * dv;
+      }
     });
   }
 

@@ -142,18 +142,122 @@ struct FxAdv {
   }
 };
 
+// points where the final contravariant wind is the general interior expression (ut_final == ut_gen, vt_final == vt_gen)
+FV3_HD inline bool fxadv_int_u(const Geo &g, int fl, int i, int j) {
+  const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+  return i >= 0 && !((W && i == 1) || (E && i == g.npx)) && !((S && (j == 0 || j == 1)) || (N && (j == g.npy - 1 || j == g.npy)));
+}
+FV3_HD inline bool fxadv_int_v(const Geo &g, int fl, int i, int j) {
+  const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+  return j >= 0 && !((S && j == 1) || (N && j == g.npy)) && !((W && (i == 0 || i == 1)) || (E && (i == g.npx - 1 || i == g.npx)));
+}
+
 // cx / cy (optional): accumulated Courant numbers of the tracer sub-cycling, cx += crx, cy += cry on the
 // faces d_sw accumulates them (i in 1..nx+1 resp. j in 1..ny+1, all halo rows / columns)
 void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt, Real *cx,
            Real *cy) {
   const Geo g = c->g;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+  // Interior kernel, two levels per thread: away from the tile-edge rows / columns the contravariant wind is one
+  // expression in (uc, vc) and seven metric terms per component; those are read once and used for both
+  // levels (they are most of this kernel's bytes).  The tile-edge rows / columns (and the 16 cube-corner
+  // solves) are a separate thin launch of the general per-level forms: keeping them out of the level
+  // loop keeps its register footprint small.
+  const int npair = (g.nz + 1) / 2;
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
+    const long m2 = t * g.st2;
+    const bool int_u = fxadv_int_u(g, fl, i, j), int_v = fxadv_int_v(g, fl, i, j);
+    if (!int_u && !int_v) return;
+    const unsigned p = IX(i, j);
+    const bool out_x = int_u && i >= 1 && i <= g.nx + 1, out_y = int_v && j >= 1 && j <= g.ny + 1;
+    Real cu = 0, ru = 0, rdxa_m = 0, rdxa_0 = 0, dy_ = 0, s3 = 0, s1 = 0;
+    Real cv = 0, rv = 0, rdya_m = 0, rdya_0 = 0, dx_ = 0, s4 = 0, s2 = 0;
+    if (int_u) {
+      cu = (g.cosa_u + m2)[p];
+      ru = (g.rsin_u + m2)[p];
+    }
+    if (out_x) {
+      rdxa_m = (g.rdxa + m2)[IX(i - 1, j)];
+      rdxa_0 = (g.rdxa + m2)[p];
+      dy_ = (g.dy + m2)[p];
+      s3 = (g.sin_sg3 + m2)[IX(i - 1, j)];
+      s1 = (g.sin_sg1 + m2)[p];
+    }
+    if (int_v) {
+      cv = (g.cosa_v + m2)[p];
+      rv = (g.rsin_v + m2)[p];
+    }
+    if (out_y) {
+      rdya_m = (g.rdya + m2)[IX(i, j - 1)];
+      rdya_0 = (g.rdya + m2)[p];
+      dx_ = (g.dx + m2)[p];
+      s4 = (g.sin_sg4 + m2)[IX(i, j - 1)];
+      s2 = (g.sin_sg2 + m2)[p];
+    }
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2 * kp + kk;
+      if (k > g.nz - 1) break;
+      const long b = t * g.st + k * g.sk;
+      const Real *ucl = uc + b, *vcl = vc + b;
+      if (int_u) {
+        const Real utv = (ucl[p] - (Real)0.25 * cu * (vcl[IX(i - 1, j)] + vcl[p] + vcl[IX(i - 1, j + 1)] + vcl[IX(i, j + 1)])) * ru;
+        (ut + b)[p] = utv;
+        if (out_x) {
+          const Real x = dt * utv;
+          Real cr;
+          if (x > (Real)0) {
+            cr = x * rdxa_m;
+            (xfx + b)[p] = dy_ * x * s3;
+          } else {
+            cr = x * rdxa_0;
+            (xfx + b)[p] = dy_ * x * s1;
+          }
+          (crx + b)[p] = cr;
+          if (cx) (cx + b)[p] += cr;
+        }
+      }
+      if (int_v) {
+        const Real vtv = (vcl[p] - (Real)0.25 * cv * (ucl[IX(i, j - 1)] + ucl[IX(i + 1, j - 1)] + ucl[p] + ucl[IX(i + 1, j)])) * rv;
+        (vt + b)[p] = vtv;
+        if (out_y) {
+          const Real y = dt * vtv;
+          Real cr;
+          if (y > (Real)0) {
+            cr = y * rdya_m;
+            (yfx + b)[p] = dx_ * y * s4;
+          } else {
+            cr = y * rdya_0;
+            (yfx + b)[p] = dx_ * y * s2;
+          }
+          (cry + b)[p] = cr;
+          if (cy) (cy + b)[p] += cr;
+        }
+      }
+    }
+  });
+  // tile-edge frame: rows 0, 1, npy-1, npy and columns 0, 1, npx-1, npx of the sub-domains that have those edges
+  const int nfr = std::max(ied - isd + 1, jed - jsd + 1);
+  launch3(c, s, Box{0, nfr - 1, 1, 8, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int a, int side) {
+    const int fl = g.flags[t];
+    int i, j;
+    if (side <= 4) {  // rows
+      i = isd + a;
+      if (i > ied) return;
+      j = side <= 2 ? side - 1 : g.npy - 4 + side;
+      if (!(fl & (side <= 2 ? FV3_S : FV3_N))) return;
+    } else {  // columns (minus the points the row sides cover)
+      j = jsd + a;
+      if (j > jed) return;
+      i = side <= 6 ? side - 5 : g.npx - 8 + side;
+      if (!(fl & (side <= 6 ? FV3_W : FV3_E))) return;
+      if (((fl & FV3_S) && (j == 0 || j == 1)) || ((fl & FV3_N) && (j == g.npy - 1 || j == g.npy))) return;
+    }
+    const bool int_u = fxadv_int_u(g, fl, i, j), int_v = fxadv_int_v(g, fl, i, j);
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     FxAdv f{g, uc + b, vc + b, m2, dt, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
     const unsigned p = IX(i, j);
-    if (i >= 0) {  // ut on is-1..ie+3, jsd..jed
+    if (i >= 0 && !int_u) {  // ut on is-1..ie+3, jsd..jed
       const Real utv = f.ut_final(i, j);
       (ut + b)[p] = utv;
       if (i >= 1 && i <= g.nx + 1) {
@@ -170,7 +274,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
         if (cx) (cx + b)[p] += cr;
       }
     }
-    if (j >= 0) {  // vt on isd..ied, js-1..je+3
+    if (j >= 0 && !int_v) {  // vt on isd..ied, js-1..je+3
       const Real vtv = f.vt_final(i, j);
       (vt + b)[p] = vtv;
       if (j >= 1 && j <= g.ny + 1) {
