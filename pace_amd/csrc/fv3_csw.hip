@@ -341,24 +341,32 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
   });
 
-  // (E) time-centred C-grid winds
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+  // (E) time-centred C-grid winds (two levels per thread: the six metric terms are read once)
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
     const unsigned p = IX(i, j);
-    if (j <= g.ny) {
-      const Real ucv = (uc + b)[p];
-      Real fy1 = ((W && i == 1) || (E && i == npx)) ? dt2 * (v + b)[p] : dt2 * ((v + b)[p] - ucv * (g.cosa_u + m2)[p]) / (g.sina_u + m2)[p];
-      const Real fyv = fy1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i, j + 1)];
-      (uc + b)[p] = ucv + fy1 * fyv + (g.rdxc + m2)[p] * ((ke + b)[IX(i - 1, j)] - (ke + b)[p]);
-    }
-    if (i <= g.nx) {
-      const Real vcv = (vc + b)[p];
-      Real fx1 = ((S && j == 1) || (N && j == npy)) ? dt2 * (u + b)[p] : dt2 * ((u + b)[p] - vcv * (g.cosa_v + m2)[p]) / (g.sina_v + m2)[p];
-      const Real fxv = fx1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i + 1, j)];
-      (vc + b)[p] = vcv - fx1 * fxv + (g.rdyc + m2)[p] * ((ke + b)[IX(i, j - 1)] - (ke + b)[p]);
+    const bool edge_u = (W && i == 1) || (E && i == npx), edge_v = (S && j == 1) || (N && j == npy);
+    const Real cau = (g.cosa_u + m2)[p], sau = (g.sina_u + m2)[p], rdxc = (g.rdxc + m2)[p];
+    const Real cav = (g.cosa_v + m2)[p], sav = (g.sina_v + m2)[p], rdyc = (g.rdyc + m2)[p];
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2 * kp + kk;
+      if (k > nz1) break;
+      const long b = t * g.st + k * g.sk;
+      if (j <= g.ny) {
+        const Real ucv = (uc + b)[p];
+        const Real fy1 = edge_u ? dt2 * (v + b)[p] : dt2 * ((v + b)[p] - ucv * cau) / sau;
+        const Real fyv = fy1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i, j + 1)];
+        (uc + b)[p] = ucv + fy1 * fyv + rdxc * ((ke + b)[IX(i - 1, j)] - (ke + b)[p]);
+      }
+      if (i <= g.nx) {
+        const Real vcv = (vc + b)[p];
+        const Real fx1 = edge_v ? dt2 * (u + b)[p] : dt2 * ((u + b)[p] - vcv * cav) / sav;
+        const Real fxv = fx1 > (Real)0 ? (vort + b)[p] : (vort + b)[IX(i + 1, j)];
+        (vc + b)[p] = vcv - fx1 * fxv + rdyc * ((ke + b)[IX(i, j - 1)] - (ke + b)[p]);
+      }
     }
   });
   return fv3_post(c, s, "c_sw");

@@ -842,16 +842,21 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   bool keep_uv_dx = false;
   for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
   Real *ut2 = c->scratch[SC_E], *vt2 = c->scratch[SC_F];  // = the utd / vtd slots below (damping fluxes overwrite them on damped levels)
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const unsigned p = IX(i, j);
-    {
+  // (two levels per thread: the six metric terms are read once)
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+    const long m2 = t * g.st2;
+    const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j);
+    const Real dx0 = (g.dx + m2)[p], dx1 = (g.dx + m2)[pn], dy0 = (g.dy + m2)[p], dy1 = (g.dy + m2)[pe_], ra = (g.rarea + m2)[p], f0v = (g.f0 + m2)[p];
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2 * kp + kk;
+      if (k > nz1) break;
+      const long b = t * g.st + k * g.sk;
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
-      const Real a = (u + b)[p] * (g.dx + m2)[p], a1 = (u + b)[IX(i, j + 1)] * (g.dx + m2)[IX(i, j + 1)];
-      const Real e = (v + b)[p] * (g.dy + m2)[p], e1 = (v + b)[IX(i + 1, j)] * (g.dy + m2)[IX(i + 1, j)];
-      const Real wkv = (g.rarea + m2)[p] * (a - a1 - e + e1);
+      const Real a = (u + b)[p] * dx0, a1 = (u + b)[pn] * dx1;
+      const Real e = (v + b)[p] * dy0, e1 = (v + b)[pe_] * dy1;
+      const Real wkv = ra * (a - a1 - e + e1);
       (wk + b)[p] = wkv;
-      (vabs + b)[p] = wkv + (g.f0 + m2)[p];  // absolute vorticity for the transport below
+      (vabs + b)[p] = wkv + f0v;  // absolute vorticity for the transport below
       if (keep_uv_dx) {
         (vt2 + b)[p] = a;
         (ut2 + b)[p] = e;
@@ -1029,34 +1034,33 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, nz1);
   }
   const bool heat_on = cf.d_con > 1.0e-5;
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    const unsigned p = IX(i, j);
-    Real hs = (heat_s + b)[p];
-    const Real dcon = g.d_con[k];
-    if (dcon > (Real)1.0e-5) {
-      const bool dv = g.damp_vt[k] > (Real)1.0e-5;
-      // ub on (i, j), (i, j+1): (vort - vort[i+1] + vt) * rdx ; vb on (i, j), (i+1, j): (vort - vort[j+1] - ut) * rdy
-      auto UB = [&](int ii, int jj) {
-        const unsigned q = IX(ii, jj);
-        const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii + 1, jj)];
-        return (d0 + (vtd + b)[q]) * (g.rdx + m2)[q];  // vtd: damping flux, or the kept u*dx on undamped levels
-      };
-      auto VB = [&](int ii, int jj) {
-        const unsigned q = IX(ii, jj);
-        const Real d0 = (vdamp + b)[q] - (vdamp + b)[IX(ii, jj + 1)];
-        return (d0 - (utd + b)[q]) * (g.rdy + m2)[q];
-      };
-      const Real ub0 = UB(i, j), ub1 = UB(i, j + 1), vb0 = VB(i, j), vb1 = VB(i + 1, j);
-      const Real fy0 = (u + b)[p] * (g.rdx + m2)[p], fy1 = (u + b)[IX(i, j + 1)] * (g.rdx + m2)[IX(i, j + 1)];
-      const Real fx0 = (v + b)[p] * (g.rdy + m2)[p], fx1 = (v + b)[IX(i + 1, j)] * (g.rdy + m2)[IX(i + 1, j)];
-      const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
-      const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
-      hs = (delp + b)[p] * (hs - (Real)0.25 * dcon * (g.rsin2 + m2)[p] *
-                                   ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) -
-                                    (g.cosa_s + m2)[p] * (u2 * dv2 + v2 * du2 + du2 * dv2)));
+  // (two levels per thread: the six metric terms are read once)
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+    const long m2 = t * g.st2;
+    const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j), pne = IX(i + 1, j + 1);
+    const Real rdx0 = (g.rdx + m2)[p], rdx1 = (g.rdx + m2)[pn], rdy0 = (g.rdy + m2)[p], rdy1 = (g.rdy + m2)[pe_];
+    const Real rs2 = (g.rsin2 + m2)[p], cs = (g.cosa_s + m2)[p];
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2 * kp + kk;
+      if (k > nz1) break;
+      const long b = t * g.st + k * g.sk;
+      Real hs = (heat_s + b)[p];
+      const Real dcon = g.d_con[k];
+      if (dcon > (Real)1.0e-5) {
+        // ub on (i, j), (i, j+1): (vort - vort[i+1] + vt) * rdx ; vb on (i, j), (i+1, j): (vort - vort[j+1] - ut) * rdy
+        // (vtd / utd: damping fluxes, or the kept u*dx / v*dy on undamped levels)
+        const Real vd00 = (vdamp + b)[p], vd10 = (vdamp + b)[pe_], vd01 = (vdamp + b)[pn], vd11 = (vdamp + b)[pne];
+        const Real ub0 = (vd00 - vd10 + (vtd + b)[p]) * rdx0, ub1 = (vd01 - vd11 + (vtd + b)[pn]) * rdx1;
+        const Real vb0 = (vd00 - vd01 - (utd + b)[p]) * rdy0, vb1 = (vd10 - vd11 - (utd + b)[pe_]) * rdy1;
+        const Real fy0 = (u + b)[p] * rdx0, fy1 = (u + b)[pn] * rdx1;
+        const Real fx0 = (v + b)[p] * rdy0, fx1 = (v + b)[pe_] * rdy1;
+        const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
+        const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
+        hs = (delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
+                                     ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2)));
+      }
+      if (heat_on) (heat_source + b)[p] += hs;
     }
-    if (heat_on) (heat_source + b)[p] += hs;
   });
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     if (!(g.damp_vt[k] > (Real)1.0e-5)) return;
