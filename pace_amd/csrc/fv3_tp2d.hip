@@ -171,44 +171,59 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
   const Geo g = c->g;
   const Deln d = dn;
   const int nk = k1 - k0 + 1;
+  const int npair = (nk + 1) / 2;  // a wave walks TWO levels at once: the three metric rows (half of the bytes) are loaded once
   const int nstrip = (g.nx + 1 + D6_OUT - 1) / D6_OUT;
-  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 4);
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * npair, 3);
   const int nseg = (g.ny + seg - 1) / seg;
-  const size_t smem = sizeof(Real) * 2 * (D6_NMAX + 1) * (FV3_WAVE + 2);
+  const int LW = FV3_WAVE + 2;
+  const size_t smem = sizeof(Real) * 2 * 2 * (D6_NMAX + 1) * LW;
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr del6_u = g.del6_u, del6_v = g.del6_v, rarea = g.rarea;
-  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
-    if (!deln_on(d, k)) return;
-    const int nord = deln_nord(d, k);
-    const Real damp = deln_damp(d, k);
-    const long b = t * st + k * sk, m2 = t * st2;
+  launch_waves<3>(c, s, nstrip, nseg, g.nsub * npair, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const int t = blk.bz / npair, ka = k0 + 2 * (blk.bz - t * npair);
+    // per-level controls (the two levels of a pair may differ in order / switch: sponge boundary)
+    bool act[2];
+    int nord[2];
+    Real damp[2];
+    long b[2];
+    int nmax = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = ka + e;
+      act[e] = k <= k1 && deln_on(d, k);
+      nord[e] = act[e] ? deln_nord(d, k) : 0;
+      damp[e] = act[e] ? deln_damp(d, k) : (Real)0;
+      b[e] = t * st + (k <= k1 ? k : k1) * sk;
+      if (act[e] && nord[e] > nmax) nmax = nord[e];
+    }
+    if (!act[0] && !act[1]) return;
+    const long m2 = t * st2;
     const int i0 = 1 + blk.bx * D6_OUT;
     const int ja = 1 + blk.by * seg;
     const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
-    Real *ld = (Real *)smem_ + 1;                         // ld[s * LW + lane]: d2_s of the lane's cell (read by lane + 1)
-    Real *lf = ld + (D6_NMAX + 1) * (FV3_WAVE + 2);       // lf[s * LW + lane]: fx_s of the lane's west face (read by lane - 1)
-    const int LW = FV3_WAVE + 2;
-    const Real *qq = q + b;
+    Real *ld = (Real *)smem_ + 1;                // ld[(e * (NMAX+1) + s) * LW + lane]: d2_s of the lane's cell (read by lane + 1)
+    Real *lf = ld + 2 * (D6_NMAX + 1) * LW;      // lf[...]: fx_s of the lane's west face (read by lane - 1)
+    const Real *qq0 = q + b[0], *qq1 = q + b[1];
     const MPtr dub = del6_u + m2, dvb = del6_v + m2, rab = rarea + m2;
     struct Row {
-      Real q, du, dv, ra;
+      Real q0, q1, du, dv, ra;
     };
     Row pf[D6_PF][FV3_LPT];
     Real du[D6_NMAX + 1][FV3_LPT], dv[D6_NMAX + 1][FV3_LPT], ra[D6_NMAX + 1][FV3_LPT];  // metrics of row r - s
-    Real d2p[D6_NMAX + 1][FV3_LPT], fxp[D6_NMAX + 1][FV3_LPT], fxe[D6_NMAX + 1][FV3_LPT], fyp[D6_NMAX + 1][FV3_LPT];
-    Real d2c[D6_NMAX + 1][FV3_LPT], fxc[D6_NMAX + 1][FV3_LPT], fyc[D6_NMAX + 1][FV3_LPT];
+    Real d2p[2][D6_NMAX + 1][FV3_LPT], fxp[2][D6_NMAX + 1][FV3_LPT], fxe[2][D6_NMAX + 1][FV3_LPT], fyp[2][D6_NMAX + 1][FV3_LPT];
+    Real d2c[2][D6_NMAX + 1][FV3_LPT], fxc[2][D6_NMAX + 1][FV3_LPT], fyc[2][D6_NMAX + 1][FV3_LPT];
     unsigned pcol[FV3_LPT];
     bool own_x[FV3_LPT], own_y[FV3_LPT];
-    int r_beg = ja - 1 - nord, r_end = jb + nord;
+    int r_beg = ja - 1 - nmax, r_end = jb + nmax;
     if (r_beg < jsd) r_beg = jsd;
     if (r_end > jed) r_end = jed;
     auto load_row = [&](int r, int l) -> Row {
       const unsigned p0 = pcol[l] + (unsigned)(r * sj32);
       Row w;
-      w.q = qq[p0];
+      w.q0 = qq0[p0];
+      w.q1 = qq1[p0];
       w.du = dub[p0];
       w.dv = dvb[p0];
       w.ra = rab[p0];
@@ -221,11 +236,14 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
       own_y[l] = i >= i0 && i < i0 + D6_OUT && i <= nx;
 #pragma unroll
       for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
-        du[s_][l] = dv[s_][l] = ra[s_][l] = d2p[s_][l] = fxp[s_][l] = fxe[s_][l] = fyp[s_][l] = (Real)0;
-        d2c[s_][l] = fxc[s_][l] = fyc[s_][l] = (Real)0;
-        if (lane == 0) {
-          ld[s_ * LW - 1] = (Real)0;
-          lf[s_ * LW + FV3_WAVE] = (Real)0;
+        du[s_][l] = dv[s_][l] = ra[s_][l] = (Real)0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          d2p[e][s_][l] = fxp[e][s_][l] = fxe[e][s_][l] = fyp[e][s_][l] = d2c[e][s_][l] = fxc[e][s_][l] = fyc[e][s_][l] = (Real)0;
+          if (lane == 0) {
+            ld[(e * (D6_NMAX + 1) + s_) * LW - 1] = (Real)0;
+            lf[(e * (D6_NMAX + 1) + s_) * LW + FV3_WAVE] = (Real)0;
+          }
         }
       }
 #pragma unroll
@@ -248,56 +266,69 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
         du[0][l] = cu.du;
         dv[0][l] = cu.dv;
         ra[0][l] = cu.ra;
-        d2c[0][l] = q_raw ? cu.q : damp * cu.q;
-        fyc[0][l] = du[0][l] * (d2p[0][l] - d2c[0][l]);
-        ld[lane] = d2c[0][l];
 #pragma unroll
-        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
-          if (s_ <= nord) {
-            d2c[s_][l] = (fxp[s_ - 1][l] - fxe[s_ - 1][l] + fyp[s_ - 1][l] - fyc[s_ - 1][l]) * ra[s_][l];
-            fyc[s_][l] = du[s_][l] * (d2c[s_][l] - d2p[s_][l]);
-            ld[s_ * LW + lane] = d2c[s_][l];
+        for (int e = 0; e < 2; ++e) {
+          if (!act[e]) continue;
+          const Real qv = e == 0 ? cu.q0 : cu.q1;
+          d2c[e][0][l] = q_raw ? qv : damp[e] * qv;
+          fyc[e][0][l] = du[0][l] * (d2p[e][0][l] - d2c[e][0][l]);
+          ld[e * (D6_NMAX + 1) * LW + lane] = d2c[e][0][l];
+#pragma unroll
+          for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+            if (s_ <= nord[e]) {
+              d2c[e][s_][l] = (fxp[e][s_ - 1][l] - fxe[e][s_ - 1][l] + fyp[e][s_ - 1][l] - fyc[e][s_ - 1][l]) * ra[s_][l];
+              fyc[e][s_][l] = du[s_][l] * (d2c[e][s_][l] - d2p[e][s_][l]);
+              ld[(e * (D6_NMAX + 1) + s_) * LW + lane] = d2c[e][s_][l];
+            }
           }
         }
       }
       blk.wave_sync();
       // ---- phase B: x-fluxes from the west neighbour's d2
       FV3_LANES(blk, lane, l) {
-        fxc[0][l] = dv[0][l] * (ld[lane - 1] - d2c[0][l]);
-        lf[lane] = fxc[0][l];
 #pragma unroll
-        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
-          if (s_ <= nord) {
-            fxc[s_][l] = dv[s_][l] * (d2c[s_][l] - ld[s_ * LW + lane - 1]);
-            lf[s_ * LW + lane] = fxc[s_][l];
+        for (int e = 0; e < 2; ++e) {
+          if (!act[e]) continue;
+          fxc[e][0][l] = dv[0][l] * (ld[e * (D6_NMAX + 1) * LW + lane - 1] - d2c[e][0][l]);
+          lf[e * (D6_NMAX + 1) * LW + lane] = fxc[e][0][l];
+#pragma unroll
+          for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+            if (s_ <= nord[e]) {
+              fxc[e][s_][l] = dv[s_][l] * (d2c[e][s_][l] - ld[(e * (D6_NMAX + 1) + s_) * LW + lane - 1]);
+              lf[(e * (D6_NMAX + 1) + s_) * LW + lane] = fxc[e][s_][l];
+            }
           }
         }
       }
       blk.wave_sync();
       // ---- phase C: east neighbour's x-flux for the next step; final fluxes of the last iteration
-      const int jo = r - nord;
-      const bool fx_row = jo >= ja && jo <= jb && jo <= ny, fy_row = jo >= ja && jo <= jb;
       FV3_LANES(blk, lane, l) {
 #pragma unroll
-        for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
-          if (s_ <= nord) {
-            fxe[s_][l] = lf[s_ * LW + lane + 1];
-            fxp[s_][l] = fxc[s_][l];
-            fyp[s_][l] = fyc[s_][l];
-            d2p[s_][l] = d2c[s_][l];
-          }
-        }
-        const unsigned p = pcol[l] + (unsigned)(jo * sj32);
-        Real ox = fxc[0][l], oy = fyc[0][l];
+        for (int e = 0; e < 2; ++e) {
+          if (!act[e]) continue;
 #pragma unroll
-        for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
-          if (s_ == nord) {
-            ox = fxc[s_][l];
-            oy = fyc[s_][l];
+          for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
+            if (s_ <= nord[e]) {
+              fxe[e][s_][l] = lf[(e * (D6_NMAX + 1) + s_) * LW + lane + 1];
+              fxp[e][s_][l] = fxc[e][s_][l];
+              fyp[e][s_][l] = fyc[e][s_][l];
+              d2p[e][s_][l] = d2c[e][s_][l];
+            }
           }
+          const int jo = r - nord[e];
+          const bool fx_row = jo >= ja && jo <= jb && jo <= ny, fy_row = jo >= ja && jo <= jb;
+          const unsigned p = pcol[l] + (unsigned)(jo * sj32);
+          Real ox = fxc[e][0][l], oy = fyc[e][0][l];
+#pragma unroll
+          for (int s_ = 1; s_ <= D6_NMAX; ++s_) {
+            if (s_ == nord[e]) {
+              ox = fxc[e][s_][l];
+              oy = fyc[e][s_][l];
+            }
+          }
+          if (fx_row && own_x[l]) (fx2 + b[e])[p] = ox;
+          if (fy_row && own_y[l]) (fy2 + b[e])[p] = oy;
         }
-        if (fx_row && own_x[l]) (fx2 + b)[p] = ox;
-        if (fy_row && own_y[l]) (fy2 + b)[p] = oy;
       }
       blk.wave_sync();
     }
