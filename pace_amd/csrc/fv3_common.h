@@ -460,6 +460,13 @@ inline void launch_waves(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int g
   (void)c;
   dim3 grid;
   const GridMap m = fv3_grid(gx, gy, gz, &grid);
+  if (smem_bytes > 64 * 1024) {  // opt in to the large-LDS allocation (up to 160 KB per workgroup on gfx950)
+    static size_t granted = 0;   // per kernel instantiation
+    if (smem_bytes > granted) {
+      (void)hipFuncSetAttribute((const void *)fv3_kw<WPE, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+      granted = smem_bytes;
+    }
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kw<WPE, F>), grid, dim3(FV3_WAVE, 1, 1), smem_bytes, s, m, f);
 #endif
 }

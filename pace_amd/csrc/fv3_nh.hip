@@ -130,6 +130,272 @@ struct Sim1 {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// SIM1 as a wave kernel.  The column solver above moves ~45 full-field passes through HBM per call
+// (every tridiagonal temporary is a context scratch field); here a lane owns one column, the
+// PP -> W2 -> PE chain of temporaries lives in ONE LDS line per lane (slot k of a column's line
+// holds PP(k+1), then W2(k), then PE(k+1): each value dies exactly where its successor is born),
+// only the two gam arrays and PM still go through memory, and the old thickness is recomputed from
+// the interface heights instead of being stored.  nz * 512 B of LDS per wave = 4 waves / CU at L79,
+// so memory-level parallelism comes from explicit register prefetch: k_walk() keeps U levels of
+// every input in flight while the U levels loaded before are being computed.
+// Operation order per value is the one of Sim1::run (bitwise the same results).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct KRec {
+  Real v[N];
+};
+
+template <int N, int U, bool UP, class Load, class Body>
+FV3_HD inline void k_walk(int nz, Load load, Body body) {
+  KRec<N> buf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int kk = u < nz ? u : nz - 1;
+    buf[u] = load(UP ? kk : nz - 1 - kk);
+  }
+  for (int c = 0; c < nz; c += U) {
+    KRec<N> nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int kk = c + U + u;
+      kk = kk < nz ? kk : nz - 1;
+      nxt[u] = load(UP ? kk : nz - 1 - kk);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (c + u < nz) body(UP ? c + u : nz - 1 - (c + u), buf[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = nxt[u];
+  }
+}
+
+#define KW_(arr, k) ((arr) + tb + (long)(k)*sk)[pix]
+#ifndef FV3_RIEM_U
+#define FV3_RIEM_U 4   // levels in flight in the sweeps with 4-5 inputs
+#endif
+#ifndef FV3_RIEM_U1
+#define FV3_RIEM_U1 8  // ... in the sweeps with 1-2 inputs
+#endif
+
+struct Sim1W {
+  long sk;
+  int nz;
+  Real rgas, rgrav, p_fac, ptop;
+  // cl.pm(k, delp_k, qcon_k): layer-mean pressure of level k (called once per level, increasing k);
+  // cl.out_pe(k1, pe, delp_k): new pressure perturbation at interface k1 = k + 1 (increasing k);
+  // cl.finish(k, dz): new thickness of level k (decreasing k).
+  // A = this lane's LDS line (stride FV3_WAVE); zint = interface heights (nz + 1 levels) the old
+  // thickness comes from; wout (optional, may alias w1) receives the new w.
+  // GL: the gam arrays live in a second LDS line B (2 waves / CU at L79) instead of the scratch field GAM.
+  template <bool GL, class C>
+  FV3_HD void run(Real *A, Real *B, long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *qcon, const Real *zint, const Real *w1,
+                  Real ws, Real *PM, Real *GAM, Real *wout, C &cl) const {
+    const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
+    constexpr int U = FV3_RIEM_U, U1 = FV3_RIEM_U1;
+    Real pp_nz;
+    // ---- sweep 1 (up): layer pressures, forward elimination for pp.  PP(k+1) -> slot k
+    {
+      Real g_prev = (Real)0, dm_k = (Real)0, pe_k = (Real)0, bet = (Real)0, pp_k = (Real)0;  // g_prev = dm(k-1) / dm(k) = the previous step's g_rat
+      Real z_top = KW_(zint, 0);
+      k_walk<5, U, true>(
+          nz,
+          [&](int k) {
+            KRec<5> r;
+            r.v[0] = KW_(delp, k);
+            r.v[1] = KW_(cappa, k);
+            r.v[2] = KW_(pt, k);
+            r.v[3] = KW_(qcon, k);
+            r.v[4] = KW_(zint, k + 1);
+            return r;
+          },
+          [&](int m, const KRec<5> &r) {
+            const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
+            KW_(PM, m) = pm_n;
+            const Real dz_n = r.v[4] - z_top;
+            z_top = r.v[4];
+            const Real dm_n = r.v[0] * rgrav;
+            const Real pe_n = exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
+            if (m >= 1) {
+              const int k = m - 1;
+              const Real g_rat = dm_k / dm_n;
+              const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
+              const Real dd = (Real)3.0 * (pe_k + g_rat * pe_n);
+              if (k == 0) {
+                bet = bb;
+                pp_k = dd / bet;
+              } else {
+                const Real gam = g_prev / bet;
+                if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
+                bet = bb - gam;
+                pp_k = (dd - pp_k) / bet;
+              }
+              A[k * FV3_WAVE] = pp_k;
+              g_prev = g_rat;
+            }
+            dm_k = dm_n;
+            pe_k = pe_n;
+          });
+      {
+        const int k = nz - 1;
+        const Real bb = (Real)2.0, dd = (Real)3.0 * pe_k;
+        const Real gam = g_prev / bet;
+        if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
+        bet = bb - gam;
+        pp_k = (dd - pp_k) / bet;
+        A[k * FV3_WAVE] = pp_k;
+      }
+      pp_nz = pp_k;
+    }
+    // ---- sweep 2 (down): back substitution, PP(k) = PP(k) - gam(k) PP(k+1), k = nz-1 .. 1
+    {
+      Real pp_next = pp_nz;
+      k_walk<1, U1, false>(
+          nz,
+          [&](int k) {
+            KRec<1> r;
+            r.v[0] = GL ? (Real)0 : KW_(GAM, k > 0 ? k : 1);
+            return r;
+          },
+          [&](int k, const KRec<1> &r) {
+            if (k >= 1) {
+              const Real ppv = A[(k - 1) * FV3_WAVE] - (GL ? B[k * FV3_WAVE] : r.v[0]) * pp_next;
+              A[(k - 1) * FV3_WAVE] = ppv;
+              pp_next = ppv;
+            }
+          });
+    }
+    // ---- sweep 3 (up): forward elimination for w.  W2(k) -> slot k (PP(k+1) has been taken out one level earlier)
+    {
+      Real pem = ptop, gm_p = (Real)0, dz_p = (Real)0, aa_k = (Real)0, dmp = (Real)0, w1p = (Real)0, pp_lo = (Real)0, pp_lo2 = (Real)0, bet = (Real)0,
+           w2_prev = (Real)0;
+      Real z_top = KW_(zint, 0);
+      k_walk<4, U, true>(
+          nz,
+          [&](int k) {
+            KRec<4> r;
+            r.v[0] = KW_(delp, k);
+            r.v[1] = KW_(cappa, k);
+            r.v[2] = KW_(zint, k + 1);
+            r.v[3] = KW_(w1, k);
+            return r;
+          },
+          [&](int m, const KRec<4> &r) {
+            const Real gm_n = (Real)1.0 / ((Real)1.0 - r.v[1]);
+            const Real dz_n = r.v[2] - z_top;
+            z_top = r.v[2];
+            const Real pp_hi = A[m * FV3_WAVE];  // PP(m+1)
+            if (m >= 1) {
+              const Real aa_n = t1g * (Real)0.5 * (gm_p + gm_n) / (dz_p + dz_n) * (pem + pp_lo);
+              const int k = m - 1;
+              if (k == 0) {
+                bet = dmp - aa_n;
+                w2_prev = (dmp * w1p + dt * pp_lo) / bet;
+              } else {
+                const Real gam = aa_k / bet;
+                if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
+                bet = dmp - (aa_k + aa_n + aa_k * gam);
+                w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev) / bet;
+              }
+              A[k * FV3_WAVE] = w2_prev;
+              aa_k = aa_n;
+            }
+            pem = pem + r.v[0];
+            gm_p = gm_n;
+            dz_p = dz_n;
+            dmp = r.v[0] * rgrav;
+            w1p = r.v[3];
+            pp_lo2 = pp_lo;
+            pp_lo = pp_hi;
+          });
+      {
+        const Real p1 = t1g * gm_p / dz_p * (pem + pp_lo);
+        const Real gam = aa_k / bet;
+        if (GL) B[(nz - 1) * FV3_WAVE] = gam; else KW_(GAM, nz - 1) = gam;
+        bet = dmp - (aa_k + p1 + aa_k * gam);
+        w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - p1 * ws - aa_k * w2_prev) / bet;
+        A[(nz - 1) * FV3_WAVE] = w2_prev;
+      }
+      // ---- sweep 4 (down): back substitution, W2(k) = W2(k) - gam(k+1) W2(k+1), k = nz-2 .. 0
+      Real w2_next = w2_prev;
+      k_walk<1, U1, false>(
+          nz,
+          [&](int k) {
+            KRec<1> r;
+            r.v[0] = GL ? (Real)0 : KW_(GAM, k > 0 ? k : 1);
+            return r;
+          },
+          [&](int kk, const KRec<1> &r) {
+            if (kk >= 1) {
+              const Real wv = A[(kk - 1) * FV3_WAVE] - (GL ? B[kk * FV3_WAVE] : r.v[0]) * w2_next;
+              A[(kk - 1) * FV3_WAVE] = wv;
+              w2_next = wv;
+            }
+          });
+    }
+    // ---- sweep 5 (up): new pressure perturbation.  PE(k+1) -> slot k; the new w leaves through wout
+    {
+      Real pe_run = (Real)0;
+      k_walk<2, U1, true>(
+          nz,
+          [&](int k) {
+            KRec<2> r;
+            r.v[0] = KW_(delp, k);
+            r.v[1] = KW_(w1, k);
+            return r;
+          },
+          [&](int k, const KRec<2> &r) {
+            const Real w2k = A[k * FV3_WAVE];
+            pe_run = pe_run + r.v[0] * rgrav * (w2k - r.v[1]) * rdt;
+            A[k * FV3_WAVE] = pe_run;
+            if (wout) KW_(wout, k) = w2k;
+            cl.out_pe(k + 1, pe_run, r.v[0]);
+          });
+    }
+    // ---- sweep 6 (down): new layer thickness, handed to the caller's finish
+    {
+      Real p1 = (Real)0, dm_below = (Real)0, pe1 = A[(nz - 1) * FV3_WAVE], pe2 = (Real)0;
+      k_walk<4, U, false>(
+          nz,
+          [&](int k) {
+            KRec<4> r;
+            r.v[0] = KW_(delp, k);
+            r.v[1] = KW_(pt, k);
+            r.v[2] = KW_(cappa, k);
+            r.v[3] = KW_(PM, k);
+            return r;
+          },
+          [&](int k, const KRec<4> &r) {
+            const Real dm = r.v[0] * rgrav;
+            const Real pe_k = k >= 1 ? A[(k - 1) * FV3_WAVE] : (Real)0;
+            if (k == nz - 1) {
+              p1 = (pe_k + (Real)2.0 * pe1) * r3;
+            } else {
+              const Real g_rat = dm / dm_below;
+              const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
+              p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
+            }
+            const Real dzn = -dm * rgas * r.v[1] * exp((r.v[2] - (Real)1.0) * log(fv3_max(p_fac * r.v[3], p1 + r.v[3])));
+            cl.finish(k, dzn);
+            pe2 = pe1;
+            pe1 = pe_k;
+            dm_below = dm;
+          });
+    }
+  }
+};
+
+#ifndef FV3_RIEM_GL
+#define FV3_RIEM_GL 0  // 1: gam arrays in a second LDS line (experiment; halves the resident waves)
+#endif
+// LDS line budget of the wave solver; above it (very deep columns) the callers fall back to the column kernels
+inline bool riem_wave_ok(const Geo &g) {
+  static const char *e = getenv("FV3_RIEM_MODE");
+  if (e && !strcmp(e, "columns")) return false;
+  return (size_t)g.nz * FV3_WAVE * sizeof(Real) * (FV3_RIEM_GL ? 2 : 1) <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
+}
+inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
+
 // interface interpolation weights of update_dz_c
 struct DzcW {
   Real top_ratio, bot_ratio;
@@ -202,6 +468,49 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
   Sim1 sim{g, (Real)c->cst.rdgas, (Real)1.0 / (Real)c->cst.grav, (Real)c->cfg.p_fac, ptop};
   Real *PM = c->scratch[SC_A], *DZ = c->scratch[SC_B], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
   const int nz = g.nz;
+  if (riem_wave_ok(g)) {
+    const Sim1W sw{g.sk, nz, sim.rgas, sim.rgrav, sim.p_fac, ptop};
+    const int i0 = 0, j0 = 0, ni = g.nx + 2, ncol = ni * (g.ny + 2);
+    const long st = g.st, st2 = g.st2, sk = g.sk;
+    const int sj32 = g.sj32, go = g.o;
+    const bool gl = riem_gam_lds(g);
+    launch_waves<1>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
+      const int t = blk.bz;
+      const long tb = t * st;
+      FV3_LANES(blk, lane, l) {
+        const int cidx = blk.bx * FV3_WAVE + lane;
+        if (cidx >= ncol) continue;
+        const int jr = cidx / ni;
+        const unsigned pix = (unsigned)((j0 + jr + go) * sj32 + (i0 + cidx - jr * ni) + go);
+        struct Cl {
+          long tb, sk;
+          unsigned pix;
+          Real peg, pem, z, grav;
+          Real *pef, *gz;
+          FV3_HD Real pm(int, Real dm, Real qc) {
+            const Real peg_n = peg + dm * ((Real)1.0 - qc);
+            const Real v = (peg_n - peg) / log(peg_n / peg);
+            peg = peg_n;
+            return v;
+          }
+          FV3_HD void out_pe(int k1, Real pe, Real dm) {
+            pem = pem + dm;
+            KW_(pef, k1) = pe + pem;
+          }
+          FV3_HD void finish(int k, Real dz) {
+            z = z - dz * grav;
+            KW_(gz, k) = z;
+          }
+        };
+        const Real z_bot = phis[t * st2 + pix];
+        Cl cl{tb, sk, pix, ptop, ptop, z_bot, grav, pef, gz};
+        KW_(pef, 0) = ptop;
+        sw.run<FV3_RIEM_GL != 0>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt2, delpc, cappa, ptc, q_con, gz, w3, ws[t * st2 + pix], PM, GAM, (Real *)nullptr, cl);
+        KW_(gz, nz) = z_bot;
+      }
+    });
+    return fv3_post(c, s, "riem_solver_c");
+  }
   launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
@@ -254,6 +563,65 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
   Real *PM = c->scratch[SC_A], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
   const int nz = g.nz;
   const bool last = last_call != 0;
+  if (riem_wave_ok(g)) {
+    const Sim1W sw{g.sk, nz, sim.rgas, sim.rgrav, sim.p_fac, ptop};
+    const int i0 = 1, j0 = 1, ni = g.nx, ncol = ni * g.ny;
+    const long st = g.st, st2 = g.st2, sk = g.sk;
+    const int sj32 = g.sj32, go = g.o;
+    const bool gl = riem_gam_lds(g);
+    launch_waves<1>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
+      const int t = blk.bz;
+      const long tb = t * st;
+      FV3_LANES(blk, lane, l) {
+        const int cidx = blk.bx * FV3_WAVE + lane;
+        if (cidx >= ncol) continue;
+        const int jr = cidx / ni;
+        const unsigned pix = (unsigned)((j0 + jr + go) * sj32 + (i0 + cidx - jr * ni) + go);
+        struct Cl {
+          long tb, sk;
+          unsigned pix;
+          Real pem, peg, pelng_k, z, akap;
+          bool last;
+          Real *pk3, *peln, *pk, *pe, *ppe, *zh, *delz;
+          FV3_HD Real pm(int k, Real dm, Real qc) {
+            pem = pem + dm;
+            const Real peg_n = peg + dm * ((Real)1.0 - qc);
+            const Real peln_n = log(pem), pelng_n = log(peg_n);
+            const Real pk3v = exp(akap * peln_n);
+            KW_(pk3, k + 1) = pk3v;
+            if (last) {
+              KW_(peln, k + 1) = peln_n;
+              KW_(pk, k + 1) = pk3v;
+              KW_(pe, k + 1) = pem;
+            }
+            const Real v = (peg_n - peg) / (pelng_n - pelng_k);
+            peg = peg_n;
+            pelng_k = pelng_n;
+            return v;
+          }
+          FV3_HD void out_pe(int k1, Real pev, Real) { KW_(ppe, k1) = pev; }
+          FV3_HD void finish(int k, Real dz) {
+            z = z - dz;
+            KW_(zh, k) = z;
+            KW_(delz, k) = dz;
+          }
+        };
+        const Real z_bot = zs[t * st2 + pix];
+        const Real peln0 = log(ptop);
+        Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, last, pk3, peln, pk, pe, ppe, zh, delz};
+        KW_(pk3, 0) = exp(akap * peln0);
+        if (last) {
+          KW_(peln, 0) = peln0;
+          KW_(pk, 0) = KW_(pk3, 0);
+          KW_(pe, 0) = ptop;
+        }
+        KW_(ppe, 0) = (Real)0;
+        sw.run<FV3_RIEM_GL != 0>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt, delp, cappa, pt, q_con, zh, w, wsd[t * st2 + pix], PM, GAM, w, cl);
+        KW_(zh, nz) = z_bot;
+      }
+    });
+    return fv3_post(c, s, "riem_solver3");
+  }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
