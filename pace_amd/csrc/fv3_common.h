@@ -73,6 +73,7 @@ struct Geo {
   const Real *corner_extrap;  // [nsub][4][3]
   const Real *dp_ref, *pfull; // [nz]
   const Real *ep_gam;         // [nz+1] edge_profile back-substitution factors (function of dp_ref)
+  const Real *ep_gk, *ep_bet; // [nz+1] edge_profile forward-elimination ratios dp(k-1)/dp(k) and pivots (level-only)
   // per-level parameters (get_column_namelist), device arrays [nz+1]
   const int *nord, *nord_v, *nord_w, *nord_t;
   const Real *damp_vt, *damp_w, *damp_t, *d2_divg, *d_con, *ke_bg;

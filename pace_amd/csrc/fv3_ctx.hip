@@ -227,16 +227,22 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   {
     // FV3 edge_profile: gam[k] of the layer -> interface spline (update_dz_d)
     const std::vector<double> &dp0 = c->dp_ref_h;
-    std::vector<double> gd(nz + 1, 0.0);
+    std::vector<double> gd(nz + 1, 0.0), gkv(nz + 1, 0.0), betv(nz + 1, 0.0);
     const double g0 = dp0[1] / dp0[0];
     double bet = g0 * (g0 + 0.5);
     gd[0] = (1.0 + g0 * (g0 + 1.5)) / bet;
+    gkv[0] = g0;
+    betv[0] = bet;
     for (int k = 1; k < nz; ++k) {
       const double gk = dp0[k - 1] / dp0[k];
       bet = 2.0 + 2.0 * gk - gd[k - 1];
       gd[k] = gk / bet;
+      gkv[k] = gk;
+      betv[k] = bet;
     }
     g.ep_gam = upload(c, toReal(gd));
+    g.ep_gk = upload(c, toReal(gkv));
+    g.ep_bet = upload(c, toReal(betv));
   }
   g.nord = upload(c, c->nord_h);
   g.nord_v = upload(c, c->nord_v_h);

@@ -841,11 +841,132 @@ static void edge_profile_reg(fv3_ctx *c, fv3_stream_t s, const Real *crx, const 
   });
 }
 
+// Wave forms of edge_profile: a wave owns 64 columns of ONE of the four fields (flattened column index: no
+// idle lanes on the face-field boxes).  The pivots / ratios are level-only tables built at context
+// creation, so a level costs one division.
+//   NZ > 0: the column lives in registers, all NZ loads in flight at once, code = one unrolled profile
+//           (the older edge_profile_reg inlines four profiles with three divisions per level: ~130 KB of
+//           code, 2.5 TB/s);
+//   NZ = 0: any level count -- rolled loops, the forward-eliminated values sit in the lane's LDS line,
+//           inputs prefetched 16 levels ahead (LDS-limited to 4 waves / CU at L79: latency-bound, 3.3 TB/s).
+template <int NZ>
+static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *qe, bool xf);
+template <int NZ>
+static void edge_profile_wave(fv3_ctx *c, fv3_stream_t s, const Real *crx, const Real *xfx, const Real *cry, const Real *yfx, Real *crx_a, Real *xfx_a, Real *cry_a,
+                              Real *yfx_a) {
+  // one launch per field: the field pointers stay kernel arguments (selecting among them inside the kernel
+  // turns every access into a flat load through a scratch copy of the argument block)
+  edge_profile_wave1<NZ>(c, s, crx, crx_a, true);
+  edge_profile_wave1<NZ>(c, s, xfx, xfx_a, true);
+  edge_profile_wave1<NZ>(c, s, cry, cry_a, false);
+  edge_profile_wave1<NZ>(c, s, yfx, yfx_a, false);
+}
+template <int NZ>
+static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *qe, bool xf) {
+  const Geo g = c->g;
+  const int nz = g.nz;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  const int nix = g.nx + 1, ncx = nix * (jed - jsd + 1);  // x-face fields: i in [1, nx+1], every j
+  const int niy = ied - isd + 1, ncy = niy * (g.ny + 1);  // y-face fields: every i, j in [1, ny+1]
+  const int ni = xf ? nix : niy, ncol = xf ? ncx : ncy, i0 = xf ? 1 : isd, j0 = xf ? jsd : 1;
+  const long st = g.st, sk = g.sk;
+  const int sj32 = g.sj32, go = g.o;
+  const Real *gkt = g.ep_gk, *bett = g.ep_bet, *gamd = g.ep_gam;
+  constexpr int WPE = NZ == 0 ? 1 : (NZ > 100 ? 1 : 2);
+  launch_waves<WPE>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, NZ == 0 ? sizeof(Real) * nz * FV3_WAVE : 0, [=] FV3_HD(const Blk &blk, char *smem_) {
+    const long tb = blk.bz * st;
+    FV3_LANES(blk, lane, l) {
+      const int cidx = blk.bx * FV3_WAVE + lane;
+      if (cidx >= ncol) continue;
+      const int jr = cidx / ni;
+      const unsigned pix = (unsigned)((j0 + jr + go) * sj32 + (i0 + cidx - jr * ni) + go);
+      if constexpr (NZ > 0) {
+        (void)smem_;
+        Real a[NZ + 1];
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) a[k] = KW_(q, k);
+        const Real g0 = gkt[0];
+        Real q_m = a[0], q_mm = a[0];
+        a[0] = ((Real)2.0 * g0 * (g0 + (Real)1.0) * a[0] + a[1]) / bett[0];
+#pragma unroll
+        for (int k = 1; k < NZ; ++k) {
+          const Real qk = a[k];
+          a[k] = ((Real)3.0 * (q_m + gkt[k] * qk) - a[k - 1]) / bett[k];
+          q_mm = q_m;
+          q_m = qk;
+        }
+        const Real gk = gkt[NZ - 1], gam_prev = gamd[NZ - 1];
+        const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
+        const Real xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
+        const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
+        a[NZ] = (xt1 * q_m + q_mm - a_bot * a[NZ - 1]) / xt2;
+#pragma unroll
+        for (int k = NZ - 1; k >= 0; --k) a[k] = a[k] - gamd[k] * a[k + 1];
+#pragma unroll
+        for (int k = 0; k <= NZ; ++k) KW_(qe, k) = a[k];
+      } else {
+        Real *A = (Real *)smem_ + lane;
+        Real q_m = (Real)0, q_mm = (Real)0, a_prev = (Real)0;
+        k_walk<1, 16, true>(
+            nz,
+            [&](int k) {
+              KRec<1> r;
+              r.v[0] = KW_(q, k);
+              return r;
+            },
+            [&](int k, const KRec<1> &r) {
+              const Real qk = r.v[0];
+              if (k == 0) {
+                q_m = q_mm = qk;
+                return;
+              }
+              if (k == 1) {
+                const Real g0 = gkt[0];
+                a_prev = ((Real)2.0 * g0 * (g0 + (Real)1.0) * q_m + qk) / bett[0];
+                A[0] = a_prev;
+              }
+              const Real gk = gkt[k];
+              a_prev = ((Real)3.0 * (q_m + gk * qk) - a_prev) / bett[k];
+              A[k * FV3_WAVE] = a_prev;
+              q_mm = q_m;
+              q_m = qk;
+            });
+        const Real gk = gkt[nz - 1], gam_prev = gamd[nz - 1];
+        const Real a_bot = (Real)1.0 + gk * (gk + (Real)1.5);
+        const Real xt1 = (Real)2.0 * gk * (gk + (Real)1.0);
+        const Real xt2 = gk * (gk + (Real)0.5) - a_bot * gam_prev;
+        Real a_next = (xt1 * q_m + q_mm - a_bot * a_prev) / xt2;
+        KW_(qe, nz) = a_next;
+        for (int k = nz - 1; k >= 0; --k) {
+          a_next = A[k * FV3_WAVE] - gamd[k] * a_next;
+          KW_(qe, k) = a_next;
+        }
+      }
+    }
+  });
+}
+
 // returns false when the level count has no register-resident instantiation (the caller then runs the generic form)
 static bool edge_profile_columns(fv3_ctx *c, fv3_stream_t s, const Real *crx, const Real *xfx, const Real *cry, const Real *yfx, Real *crx_a, Real *xfx_a, Real *cry_a,
                                  Real *yfx_a) {
-  static const bool generic = getenv("FV3_EDGE_PROFILE_GENERIC") != nullptr;  // A/B switch
+  static const bool generic = getenv("FV3_EDGE_PROFILE_GENERIC") != nullptr;  // A/B switches
+  static const bool regs = getenv("FV3_EDGE_PROFILE_REG") != nullptr;
   if (generic) return false;
+  if (!regs && c->g.nz >= 2) {
+    static const bool lds = getenv("FV3_EDGE_PROFILE_LDS") != nullptr;
+    if (c->g.nz == 79 && !lds) {
+      edge_profile_wave<79>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    }
+    if (c->g.nz == 127 && !lds) {
+      edge_profile_wave<127>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    }
+    if (sizeof(Real) * c->g.nz * FV3_WAVE <= 64 * 1024) {
+      edge_profile_wave<0>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
+      return true;
+    }
+  }
   switch (c->g.nz) {
     case 79:
       edge_profile_reg<79>(c, s, crx, xfx, cry, yfx, crx_a, xfx_a, cry_a, yfx_a);
