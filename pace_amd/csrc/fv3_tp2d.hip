@@ -590,7 +590,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
     auto march = [&](auto xe_tag) {
       constexpr bool XE = decltype(xe_tag)::value;
-      for (int r = ja - 3; r <= r_end; ++r) {
+      auto step = [&](int r) {
         const int r3 = r - 3 < jsd ? jsd : r - 3;
         const int rn = r + TS_PF < r_end ? r + TS_PF : r_end;
         const int sy = r - 1;  // cell whose low edge value the y-windows complete at this step
@@ -641,8 +641,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           Real qy = cur[l].qy, qx = qy;
           if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
             const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
-            qy = cc<2>(qq, *gp, fl, ic, r);
-            qx = cc<1>(qq, *gp, fl, ic, r);
+            const int rc = r < jed ? r : jed;  // (trailing steps of the unrolled march)
+            qy = cc<2>(qq, *gp, fl, ic, rc);
+            qx = cc<1>(qq, *gp, fl, ic, rc);
             cur[l].qy = qy;
           }
           w2[l] = w3[l];
@@ -778,6 +779,23 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           mb[l] = o_mc[l];
         }
         blk.wave_sync();
+      };
+      // The prefetched rows rotate through TS_PF + 1 register sets (cur <- nxt <- nx2).  Rolled, the rotation is
+      // register copies at the loop head, and a copy of a row still in flight is a full vmcnt(0) drain every
+      // step; unrolled by the rotation period the copies become renames (interior strips only: code size).
+      // Measured on MI355X: 1.5 % -- with every load of the march redirected to one cached row the kernel is
+      // still 6 of its 8.3 ms, i.e. the march is bound by its own issue + LDS-exchange latency at 2 waves / SIMD,
+      // not by HBM latency (prefetching the optional inputs as well, at one or two steps, changed nothing).
+      if constexpr (XE) {
+        for (int r = ja - 3; r <= r_end; ++r) step(r);
+      } else {
+        // (trailing steps past r_end: their loads are clamped to r_end and every store is masked by the
+        // owned-row tests, so they only keep the trip count a multiple of the period)
+        for (int r = ja - 3; r <= r_end; r += TS_PF + 1) {
+          step(r);
+          step(r + 1);
+          if (TS_PF == 2) step(r + 2);
+        }
       }
     };
     if (W || E)
