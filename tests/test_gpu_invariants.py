@@ -110,3 +110,28 @@ def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, wo
         check=True, env=env, timeout=600,
     )
     subprocess.run([sys.executable, tool, "--compare", w1, w2], check=True, timeout=60)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize(
+    "toggle",
+    ["FV3_RIEM_MODE=columns", "FV3_EDGE_PROFILE_LDS=1", "FV3_EDGE_PROFILE_REG=1", "FV3_EDGE_PROFILE_GENERIC=1", "FV3_TP2D_MODE=staged", "FV3_DEL6_MODE=staged"],
+)
+def test_alternative_kernel_forms_agree(tmp_path, toggle):
+    """Every operator that has two device implementations (wave Riemann solver vs thread-per-column, the
+    three edge_profile forms, marching vs staged transport / del-n fluxes) must give the same step: per
+    sub-domain sums and maxima of the prognostic fields after two C48 L79 steps agree to 1e-11 (the forms
+    differ only in FMA association of a few sums; most are bitwise equal).  This is the check that caught a
+    mis-compiled edge_profile variant (in-kernel selection among field pointers)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "multi_gpu_check.py")
+    base, alt = str(tmp_path / "base.json"), str(tmp_path / "alt.json")
+    size = ["--nx", "48", "--nz", "79"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
+    subprocess.run([sys.executable, tool, "--out", base] + size, check=True, env=env, timeout=600)
+    name, val = toggle.split("=")
+    subprocess.run([sys.executable, tool, "--out", alt] + size, check=True, env=dict(env, **{name: val}), timeout=600)
+    subprocess.run([sys.executable, tool, "--compare", base, alt, "--rtol", "1e-11"], check=True, timeout=60)
