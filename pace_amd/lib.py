@@ -148,6 +148,12 @@ def load(precision: int = 64, hostemu: bool = False) -> C.CDLL:
     if not os.path.exists(path):
         what = "tests/_hostemu (python -m pace_amd.build --hostemu)" if hostemu else "python -m pace_amd.build (or __graft_entry__.build())"
         raise Fv3Error(f"{path} is missing; build it with {what}. The MI355X path has no CPU fallback.")
+    if not hostemu:
+        # The device buffers are torch tensors, so this process will hold torch's HIP runtime (the wheel bundles its
+        # own libamdhip64).  Load it FIRST: if this library pulled in /opt/rocm's copy before torch, the process would
+        # carry two runtimes and fv3_ctx_create fails with "hipSetDevice failed" (seen on the MI355X box when build()
+        # and smoke() ran in one process).
+        import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         try:
