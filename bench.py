@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c768", help="c768 (headline) | c384 | c192 | c48 | c12")
+    ap.add_argument("--config", default="c768", help="c768 (headline) | c384 | c272 | c192 | c48 | c12")
     ap.add_argument("--nz", type=int, default=None)
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -442,14 +442,16 @@ __global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(W
 }
 #endif
 
-// Rows a marching wave owns (FV3_SEG overrides for experiments).  Shorter segments were tried to
-// shorten the tail of small launches (C384 / C192 per-GPU loads): 16 or 32 rows were 1-7 % slower
-// than 64 at every size measured on MI355X, so 64 stays.
+// Rows a marching wave owns (FV3_SEG overrides for experiments).  A segment costs 6 warm-up steps, so longer
+// is cheaper per row as long as the launch still fills the chip many times over: 96 rows when that leaves
+// >= 8 waves per resident slot (C768 on one GPU: 1 % faster than 64, measured), 64 otherwise (the per-GPU loads
+// of the 4- and 8-GPU runs, where the tail of the launch matters more).  16 / 32-row segments were 1-7 %
+// slower than 64 at every size measured on MI355X, 128 equal to 64.
 inline int fv3_pick_seg(long waves_at_64, int wpe) {
   static const char *e = getenv("FV3_SEG");
-  (void)waves_at_64;
-  (void)wpe;
-  return e ? atoi(e) : 64;
+  if (e) return atoi(e);
+  const long slots = 256L * 4 * wpe;
+  return waves_at_64 * 2 / 3 >= 8 * slots ? 96 : 64;
 }
 
 template <int WPE = 3, class F>

@@ -30,6 +30,8 @@ CONFIGS = {
     "c192": dict(nx_tile=192, nz=79, layout=(1, 1), dt_atmos=200.0, k_split=7, n_split=8),
     # not a reference config: 6 sub-domains of 384^2 = the per-GPU share of the C768 run on 4 GPUs (scaling studies on one GPU)
     "c384": dict(nx_tile=384, nz=79, layout=(1, 1), dt_atmos=225.0, k_split=2, n_split=6),
+    # likewise 6 sub-domains of 272^2 ~ 3 of 384^2 = the per-GPU cell count of the C768 run on 8 GPUs
+    "c272": dict(nx_tile=272, nz=79, layout=(1, 1), dt_atmos=225.0, k_split=2, n_split=6),
     "c768": dict(nx_tile=768, nz=79, layout=(2, 2), dt_atmos=225.0, k_split=2, n_split=6),
 }
 
