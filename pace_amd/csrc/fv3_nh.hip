@@ -389,10 +389,14 @@ struct Sim1W {
 #define FV3_RIEM_GL 0  // 1: gam arrays in a second LDS line (experiment; halves the resident waves)
 #endif
 // LDS line budget of the wave solver; above it (very deep columns) the callers fall back to the column kernels
-inline bool riem_wave_ok(const Geo &g) {
+inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
   static const char *e = getenv("FV3_RIEM_MODE");
   if (e && !strcmp(e, "columns")) return false;
-  return (size_t)g.nz * FV3_WAVE * sizeof(Real) * (FV3_RIEM_GL ? 2 : 1) <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
+  const size_t line = (size_t)g.nz * FV3_WAVE * sizeof(Real) * (FV3_RIEM_GL ? 2 : 1);
+  // heavy = riem_solver3 (7 exp/log per level): below 4 waves per CU (line > 40 KB: 127 levels in fp64) the
+  // bandwidth-bound column form is faster (25.7 vs 29.1 ms at C768 L127 fp64); riem_solver_c still gains (24.7 vs 29.2)
+  if (heavy && !(e && !strcmp(e, "wave")) && line > 40 * 1024) return false;
+  return line <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
 
@@ -563,7 +567,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
   Real *PM = c->scratch[SC_A], *W2 = c->scratch[SC_C], *PP = c->scratch[SC_D], *GAM = c->scratch[SC_E];
   const int nz = g.nz;
   const bool last = last_call != 0;
-  if (riem_wave_ok(g)) {
+  if (riem_wave_ok(g, true)) {
     const Sim1W sw{g.sk, nz, sim.rgas, sim.rgrav, sim.p_fac, ptop};
     const int i0 = 1, j0 = 1, ni = g.nx, ncol = ni * g.ny;
     const long st = g.st, st2 = g.st2, sk = g.sk;
