@@ -23,7 +23,8 @@ struct A2B {
   MPtr dya;
   bool W, E, S, N;
 
-  FV3_HD Real Q(int i, int j) const { return q[IX(i, j)]; }
+  Real sc;          // input scale (1, or g for the interface heights of nh_p_grad: gz = g * zh is never stored)
+  FV3_HD Real Q(int i, int j) const { return sc * q[IX(i, j)]; }
 
   FV3_HD Real qx_int(int i, int j) const { return A2B_B2 * (Q(i - 2, j) + Q(i + 1, j)) + A2B_B1 * (Q(i - 1, j) + Q(i, j)); }
   FV3_HD Real qy_int(int i, int j) const { return A2B_B2 * (Q(i, j - 2) + Q(i, j + 1)) + A2B_B1 * (Q(i, j - 1) + Q(i, j)); }
@@ -100,11 +101,12 @@ struct A2B {
 FV3_HD inline Real extrap(Real fac, Real q1, Real q2) { return q1 + fac * (q1 - q2); }
 
 // one output corner, any position: tile-edge formulas included
-FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j) {
+FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j, Real scale = (Real)1) {
   const int fl = g.flags[t];
   A2B a;
   a.g = g;
   a.q = qlev;
+  a.sc = scale;
   a.dxa = g.dxa + t * g.st2;
   a.dya = g.dya + t * g.st2;
   a.W = fl & FV3_W;
@@ -178,7 +180,7 @@ FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j
 // its i-neighbours through two LDS lines and stores one corner.  Corners within two points of a
 // cube-tile edge use other formulas: the marching kernel skips them and a thin frame launch
 // evaluates a2b_point there.
-void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace) {
+void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace, Real scale) {
   const Geo g = c->g;
   Real *out = replace ? c->scratch[SC_K] : qout;
   const int kshift = replace ? 0 : (kout0 - kin0);
@@ -231,7 +233,7 @@ void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int k
     for (int r = r_beg; r <= r_end; ++r) {
       const int rn = r + AB_PF < r_end ? r + AB_PF : r_end;
       FV3_LANES(blk, lane, l) {
-        const Real qn = pf[0][l];
+        const Real qn = scale * pf[0][l];
 #pragma unroll
         for (int n = 0; n + 1 < AB_PF; ++n) pf[n][l] = pf[n + 1][l];
         pf[AB_PF - 1][l] = q[pcol[l] + (unsigned)(rn * sj32)];
@@ -277,7 +279,7 @@ void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int k
       if (((fl & FV3_W) && i <= 2) || ((fl & FV3_E) && i >= g.npx - 1)) return;
     }
     const Real *q = qin + t * g.st + k * g.sk;
-    (out + t * g.st + (k + kshift) * g.sk)[IX(i, j)] = a2b_point(g, q, t, i, j);
+    (out + t * g.st + (k + kshift) * g.sk)[IX(i, j)] = a2b_point(g, q, t, i, j, scale);
   });
   if (replace) {
     launch3<4>(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kin0, kin0 + nk - 1}, [=] FV3_HD(int t, int k, int i, int j) {

@@ -410,8 +410,16 @@ struct DzcW {
 // ---------------------------------------------------------------------------------------------
 extern "C" int fv3_update_dz_c(fv3_ctx *c, const fv3_field *zs_, const fv3_field *ut_, const fv3_field *vt_, const fv3_field *gz_, const fv3_field *ws_,
                                double dtd, void *stream) {
+  return fv3_update_dz_c_from(c, zs_, ut_, vt_, gz_, gz_, ws_, dtd, stream);
+}
+
+// gz_in -> gz: the sequencer passes zh as gz_in on the sub-steps where the reference first copies zh into gz
+// (dyn_core: "gz = zh" before update_dz_c), which saves that full-field copy; only cells 0..n+1 of gz are written,
+// and nothing downstream (riem_solver_c, p_grad_c) reads gz beyond them.
+int fv3_update_dz_c_from(fv3_ctx *c, const fv3_field *zs_, const fv3_field *ut_, const fv3_field *vt_, const fv3_field *gzin_, const fv3_field *gz_,
+                         const fv3_field *ws_, double dtd, void *stream) {
   if (!c) return FV3_ERR_ARG;
-  FV3_FIELD2D(zs, zs_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_) FV3_FIELD(gz, gz_) FV3_FIELD2D(ws, ws_)
+  FV3_FIELD2D(zs, zs_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_) FV3_FIELD(gz, gz_) FV3_FIELD(gzin, gzin_) FV3_FIELD2D(ws, ws_)
   const Geo g = c->g;
   fv3_stream_t s = (fv3_stream_t)stream;
   const Real dt = (Real)dtd;
@@ -432,7 +440,7 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, const fv3_field *zs_, const fv3_field
       const Real int_ratio = (Real)1.0 / (g.dp_ref[k - 1] + g.dp_ref[k]);
       return (g.dp_ref[k] * (f + (k - 1) * g.sk)[q] + g.dp_ref[k - 1] * (f + k * g.sk)[q]) * int_ratio;
     };
-    const Real *gg = gz + b;
+    const Real *gg = gzin + b;
     const Real x0 = XI(ut, i, j), x1 = XI(ut, i + 1, j), y0 = XI(vt, i, j), y1 = XI(vt, i, j + 1);
     const Real fx0 = x0 * (x0 > (Real)0 ? gg[f4_index<1>(g, fl, i - 1, j)] : gg[f4_index<1>(g, fl, i, j)]);
     const Real fx1 = x1 * (x1 > (Real)0 ? gg[f4_index<1>(g, fl, i, j)] : gg[f4_index<1>(g, fl, i + 1, j)]);
@@ -699,6 +707,13 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, const fv3_field *uc_, const fv3_field *v
 
 extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, const fv3_field *pp_, const fv3_field *gz_, const fv3_field *pk3_,
                              const fv3_field *delp_, double dtd, double ptop, double akap, void *stream) {
+  return fv3_nh_p_grad_scaled(c, u_, v_, pp_, gz_, pk3_, delp_, dtd, ptop, akap, 1.0, stream);
+}
+
+// gz_scale: the sequencer passes the interface heights zh with gz_scale = g instead of first storing
+// gz = g * zh (compute_geopotential): the product is formed where a2b_ord4 reads its input (same bits).
+int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, const fv3_field *pp_, const fv3_field *gz_, const fv3_field *pk3_,
+                         const fv3_field *delp_, double dtd, double ptop, double akap, double gz_scale, void *stream) {
   if (!c) return FV3_ERR_ARG;
   FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(pp, pp_) FV3_FIELD(gz, gz_) FV3_FIELD(pk3, pk3_) FV3_FIELD(delp, delp_)
   const Geo g = c->g;
@@ -717,7 +732,7 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, const fv3_field *u_, const fv3_field *v
   });
   a2b_ord4(c, s, pp, ppb, 1, 1, nz, false);
   a2b_ord4(c, s, pk3, pk3b, 1, 1, nz, false);
-  a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false);
+  a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false, (Real)gz_scale);
   a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;

@@ -83,5 +83,9 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 
 // a2b_ord4: qout levels kout0.. from qin levels kin0.. (nk levels); replace writes back into qin
-void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace);
+void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace, Real scale = (Real)1);
+int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u, const fv3_field *v, const fv3_field *pp, const fv3_field *gz, const fv3_field *pk3, const fv3_field *delp,
+                         double dt, double ptop, double akap, double gz_scale, void *stream);
+int fv3_update_dz_c_from(fv3_ctx *c, const fv3_field *zs, const fv3_field *ut, const fv3_field *vt, const fv3_field *gz_in, const fv3_field *gz, const fv3_field *ws,
+                         double dt, void *stream);
 

@@ -137,10 +137,11 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     if (it == 0) {
       HALO(FV3_HALO_GZ, 1);
       RUN(FV3_OP_GLUE, fv3_copy(c, &ws->gz, &ws->zh, stream));
+      RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c(c, &ws->zs, &ws->ut, &ws->vt, &ws->gz, &ws->ws3, dt2, stream));
     } else {
-      RUN(FV3_OP_GLUE, fv3_copy(c, &ws->zh, &ws->gz, stream));
+      // (the reference copies zh into gz first; update_dz_c reads zh directly instead)
+      RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c_from(c, &ws->zs, &ws->ut, &ws->vt, &ws->zh, &ws->gz, &ws->ws3, dt2, stream));
     }
-    RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c(c, &ws->zs, &ws->ut, &ws->vt, &ws->gz, &ws->ws3, dt2, stream));
     RUN(FV3_OP_RIEM_SOLVER_C,
         fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &st->q_con, &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
     RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
@@ -159,9 +160,9 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &st->delp, ptop, stream));
     RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &st->delp, ptop, akap, stream));
     HALO(FV3_HALO_ZH, 1);
-    RUN(FV3_OP_GLUE, fv3_compute_geopotential(c, &ws->zh, &ws->gz, stream));
     HALO(FV3_HALO_PKC, 1);
-    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad(c, &st->u, &st->v, &ws->pkc, &ws->gz, &ws->pk3, &st->delp, dt, ptop, akap, stream));
+    // (the reference stores gz = g * zh first -- compute_geopotential; here the corner interpolation reads zh and scales it)
+    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &st->delp, dt, ptop, akap, c->cst.grav, stream));
     if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &st->w, dt, ptop, stream));
     if (it != n_split - 1) {
       HALO(FV3_HALO_U__V, 0);
