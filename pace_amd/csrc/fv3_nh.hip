@@ -400,6 +400,10 @@ inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
 
+#ifndef PG_KC
+#define PG_KC 16  // levels one thread of the pressure-gradient kernels walks
+#endif
+
 // interface interpolation weights of update_dz_c
 struct DzcW {
   Real top_ratio, bot_ratio;
@@ -688,18 +692,34 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, const fv3_field *uc_, const fv3_field *v
   FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_) FV3_FIELD(delpc, delpc_) FV3_FIELD(pkc, pkc_) FV3_FIELD(gz, gz_)
   const Geo g = c->g;
   const Real dt2 = (Real)dt2d;
-  launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
-    const unsigned p = IX(i, j);
-    if (j <= g.ny) {
-      const unsigned pm = IX(i - 1, j);
-      (uc + b)[p] = (uc + b)[p] + dt2 * (g.rdxc + m2)[p] / ((delpc + b)[pm] + (delpc + b)[p]) *
-                                  (((gz + b1)[pm] - (gz + b)[p]) * ((pkc + b1)[p] - (pkc + b)[pm]) + ((gz + b)[pm] - (gz + b1)[p]) * ((pkc + b1)[pm] - (pkc + b)[p]));
-    }
-    if (i <= g.nx) {
-      const unsigned pm = IX(i, j - 1);
-      (vc + b)[p] = (vc + b)[p] + dt2 * (g.rdyc + m2)[p] / ((delpc + b)[pm] + (delpc + b)[p]) *
-                                  (((gz + b1)[pm] - (gz + b)[p]) * ((pkc + b1)[p] - (pkc + b)[pm]) + ((gz + b)[pm] - (gz + b1)[p]) * ((pkc + b1)[pm] - (pkc + b)[p]));
+  // A thread walks PG_KC levels keeping the lower-interface values (gz, pkc at k+1, three points each) in
+  // registers for the next level: every interface plane is read once instead of twice (9 -> 7 field passes).
+  // (rolled loop: an unrolled level loop lets the compiler hoist every level's loads at once)
+  const int nz = g.nz, nchunk = (nz + PG_KC - 1) / PG_KC;
+  launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, [=] FV3_HD(int t, int kc, int i, int j) {
+    const long m2 = t * g.st2;
+    const unsigned p = IX(i, j), px = IX(i - 1, j), py = IX(i, j - 1);
+    const bool do_u = j <= g.ny, do_v = i <= g.nx;
+    const Real rx = (g.rdxc + m2)[p], ry = (g.rdyc + m2)[p];
+    const int ka = kc * PG_KC, kb = ka + PG_KC < nz ? ka + PG_KC : nz;
+    long b = t * g.st + ka * g.sk;
+    Real g0 = (gz + b)[p], gx0 = (gz + b)[px], gy0 = (gz + b)[py];
+    Real k0 = (pkc + b)[p], kx0 = (pkc + b)[px], ky0 = (pkc + b)[py];
+#pragma unroll 1
+    for (int k = ka; k < kb; ++k) {
+      const long b1 = b + g.sk;
+      const Real g1 = (gz + b1)[p], gx1 = (gz + b1)[px], gy1 = (gz + b1)[py];
+      const Real k1 = (pkc + b1)[p], kx1 = (pkc + b1)[px], ky1 = (pkc + b1)[py];
+      const Real dpc = (delpc + b)[p];
+      if (do_u) (uc + b)[p] = (uc + b)[p] + dt2 * rx / ((delpc + b)[px] + dpc) * ((gx1 - g0) * (k1 - kx0) + (gx0 - g1) * (kx1 - k0));
+      if (do_v) (vc + b)[p] = (vc + b)[p] + dt2 * ry / ((delpc + b)[py] + dpc) * ((gy1 - g0) * (k1 - ky0) + (gy0 - g1) * (ky1 - k0));
+      g0 = g1;
+      gx0 = gx1;
+      gy0 = gy1;
+      k0 = k1;
+      kx0 = kx1;
+      ky0 = ky1;
+      b = b1;
     }
   });
   return fv3_post(c, (fv3_stream_t)stream, "p_grad_c");
@@ -734,27 +754,44 @@ int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, c
   a2b_ord4(c, s, pk3, pk3b, 1, 1, nz, false);
   a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false, (Real)gz_scale);
   a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2, b1 = b + g.sk;
-    const unsigned p = IX(i, j);
-    auto WK = [&](unsigned q) { return (pk3b + b1)[q] - (pk3b + b)[q]; };
-    if (i <= g.nx) {
-      const unsigned pe_ = IX(i + 1, j);
-      const Real du = dt / (WK(p) + WK(pe_)) *
-                      (((gzb + b1)[p] - (gzb + b)[pe_]) * ((pk3b + b1)[pe_] - (pk3b + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pe_]) * ((pk3b + b1)[p] - (pk3b + b)[pe_]));
-      (u + b)[p] = ((u + b)[p] + du +
-                  dt / ((wk1 + b)[p] + (wk1 + b)[pe_]) *
-                      (((gzb + b1)[p] - (gzb + b)[pe_]) * ((ppb + b1)[pe_] - (ppb + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pe_]) * ((ppb + b1)[p] - (ppb + b)[pe_]))) *
-                 (g.rdx + m2)[p];
-    }
-    if (j <= g.ny) {
-      const unsigned pn = IX(i, j + 1);
-      const Real dv = dt / (WK(p) + WK(pn)) *
-                      (((gzb + b1)[p] - (gzb + b)[pn]) * ((pk3b + b1)[pn] - (pk3b + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pn]) * ((pk3b + b1)[p] - (pk3b + b)[pn]));
-      (v + b)[p] = ((v + b)[p] + dv +
-                  dt / ((wk1 + b)[p] + (wk1 + b)[pn]) *
-                      (((gzb + b1)[p] - (gzb + b)[pn]) * ((ppb + b1)[pn] - (ppb + b)[p]) + ((gzb + b)[p] - (gzb + b1)[pn]) * ((ppb + b1)[p] - (ppb + b)[pn]))) *
-                 (g.rdy + m2)[p];
+  // A thread walks PG_KC levels keeping the lower-interface corner values (pk3, gz, pp at k+1, three corners each)
+  // in registers for the next level: every interface plane is read once instead of twice (11 -> 8 field passes).
+  const int nchunk = (nz + PG_KC - 1) / PG_KC;
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, [=] FV3_HD(int t, int kc, int i, int j) {
+    const long m2 = t * g.st2;
+    const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
+    const bool do_u = i <= g.nx, do_v = j <= g.ny;
+    const Real rx = (g.rdx + m2)[p], ry = (g.rdy + m2)[p];
+    const int ka = kc * PG_KC, kb = ka + PG_KC < nz ? ka + PG_KC : nz;
+    long b = t * g.st + ka * g.sk;
+    Real k0 = (pk3b + b)[p], ke0 = (pk3b + b)[pe_], kn0 = (pk3b + b)[pn];
+    Real g0 = (gzb + b)[p], ge0 = (gzb + b)[pe_], gn0 = (gzb + b)[pn];
+    Real q0 = (ppb + b)[p], qe0 = (ppb + b)[pe_], qn0 = (ppb + b)[pn];
+#pragma unroll 1
+    for (int k = ka; k < kb; ++k) {
+      const long b1 = b + g.sk;
+      const Real k1 = (pk3b + b1)[p], ke1 = (pk3b + b1)[pe_], kn1 = (pk3b + b1)[pn];
+      const Real g1 = (gzb + b1)[p], ge1 = (gzb + b1)[pe_], gn1 = (gzb + b1)[pn];
+      const Real q1 = (ppb + b1)[p], qe1 = (ppb + b1)[pe_], qn1 = (ppb + b1)[pn];
+      const Real wkp = k1 - k0, w1p = (wk1 + b)[p];
+      if (do_u) {
+        const Real du = dt / (wkp + (ke1 - ke0)) * ((g1 - ge0) * (ke1 - k0) + (g0 - ge1) * (k1 - ke0));
+        (u + b)[p] = ((u + b)[p] + du + dt / (w1p + (wk1 + b)[pe_]) * ((g1 - ge0) * (qe1 - q0) + (g0 - ge1) * (q1 - qe0))) * rx;
+      }
+      if (do_v) {
+        const Real dv = dt / (wkp + (kn1 - kn0)) * ((g1 - gn0) * (kn1 - k0) + (g0 - gn1) * (k1 - kn0));
+        (v + b)[p] = ((v + b)[p] + dv + dt / (w1p + (wk1 + b)[pn]) * ((g1 - gn0) * (qn1 - q0) + (g0 - gn1) * (q1 - qn0))) * ry;
+      }
+      k0 = k1;
+      ke0 = ke1;
+      kn0 = kn1;
+      g0 = g1;
+      ge0 = ge1;
+      gn0 = gn1;
+      q0 = q1;
+      qe0 = qe1;
+      qn0 = qn1;
+      b = b1;
     }
   });
   return fv3_post(c, s, "nh_p_grad");
