@@ -247,6 +247,19 @@ inline GridMap fv3_grid(int gx, int gy, int nplanes, dim3 *grid) {
 }
 #endif
 
+// Levels one thread of a metric-heavy stage kernel walks: the 2-D metric terms of the point are loaded once,
+// by hand, ahead of a ROLLED level loop (unrolled, the compiler hoists every level's loads at once).
+// FV3_LAUNDER(i): inside such a level loop the point indices are passed through an empty asm so that the index /
+// predicate arithmetic derived from them is recomputed per level instead of being hoisted out of the loop as
+// hundreds of live registers (c_sw stage B went to 255 VGPRs, 1 wave / SIMD, without it).
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define FV3_LAUNDER(x) asm volatile("" : "+v"(x))
+#else
+#define FV3_LAUNDER(x) ((void)0)
+#endif
+#ifndef FV3_KC
+#define FV3_KC 8  // measured at C768: 2 -> 105.6, 4 -> 107.5, 8 -> 108.0, 16 -> 108.4 SDPD (8 keeps more workgroups for the multi-GPU loads)
+#endif
 #ifndef FV3_KCH_DEFAULT
 #define FV3_KCH_DEFAULT 1
 #endif

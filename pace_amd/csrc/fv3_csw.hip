@@ -81,23 +81,46 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   Real *ke = c->scratch[SC_A], *vort = c->scratch[SC_B];
 
   // (A) contravariant A-grid winds on is-2..ie+2
-  launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+  const int nkc = (nz1 + FV3_KC) / FV3_KC;  // level chunks of the kernels that walk FV3_KC levels per thread
+  launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-    D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
-    const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
+    const long m2 = t * g.st2;
     const unsigned p = IX(i, j);
-    (ua + b)[p] = (ut_ - vt_ * (g.cosa_s + m2)[p]) * (g.rsin2 + m2)[p];
-    (va + b)[p] = (vt_ - ut_ * (g.cosa_s + m2)[p]) * (g.rsin2 + m2)[p];
+    const Real cs = (g.cosa_s + m2)[p], rs2 = (g.rsin2 + m2)[p];
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
+      if (k > nz1) break;
+      const long b = t * g.st + k * g.sk;
+      D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
+      const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
+      (ua + b)[p] = (ut_ - vt_ * cs) * rs2;
+      (va + b)[p] = (vt_ - ut_ * cs) * rs2;
+    }
   });
 
   // (B) C-grid winds + contravariant ut, vt (already scaled: dt2 * ut * dy * sin_sg)
-  launch3(c, s, Box{0, g.nx + 2, 0, g.ny + 2, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+  launch3(c, s, Box{0, g.nx + 2, 0, g.ny + 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int j_) {
     const int fl = g.flags[t];
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-    D2A d{g, u + b, v + b, W, E, S, N};
     const int npx = g.npx, npy = g.npy;
+    int i = i_, j = j_;
+    unsigned p = IX(i, j);
+    // the metric terms of the point, shared by the levels of the chunk (tile-edge clauses read their own)
+    const Real m_cosa_u = (g.cosa_u + m2)[p], m_rsin_u = (g.rsin_u + m2)[p], m_dy = (g.dy + m2)[p], m_s3w = (g.sin_sg3 + m2)[IX(i - 1, j)], m_s1 = (g.sin_sg1 + m2)[p];
+    const Real m_cosa_v = (g.cosa_v + m2)[p], m_rsin_v = (g.rsin_v + m2)[p], m_dx = (g.dx + m2)[p], m_s4s = (g.sin_sg4 + m2)[IX(i, j - 1)], m_s2 = (g.sin_sg2 + m2)[p];
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+    const int k = FV3_KC * kp + kk;
+    if (k > nz1) break;
+    i = i_;
+    j = j_;
+    FV3_LAUNDER(i);
+    FV3_LAUNDER(j);
+    p = IX(i, j);
+    const long b = t * g.st + k * g.sk;
+    D2A d{g, u + b, v + b, W, E, S, N};
     const Real *uaa = ua + b, *vaa = va + b;
     // ua / va with the corner fixes the edge interpolation reads
     auto UA = [&](int ii, int jj) -> Real {
@@ -130,7 +153,6 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       }
       return vaa[IX(ii, jj)];
     };
-    const unsigned p = IX(i, j);
     if (j <= g.ny + 1) {  // uc, ut on i = is-1..ie+2, j = js-1..je+1
       Real ucv = (Real)0, utv;
       bool edge = false;
@@ -150,13 +172,13 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       if (edge && (i == 1 || i == npx)) {
         utv = edge_interp4(UA(i - 2, j), UA(i - 1, j), UA(i, j), UA(i + 1, j), (g.dxa + m2)[IX(i - 2, j)], (g.dxa + m2)[IX(i - 1, j)], (g.dxa + m2)[IX(i, j)],
                            (g.dxa + m2)[IX(i + 1, j)]);
-        ucv = utv > (Real)0 ? utv * (g.sin_sg3 + m2)[IX(i - 1, j)] : utv * (g.sin_sg1 + m2)[p];
+        ucv = utv > (Real)0 ? utv * m_s3w : utv * m_s1;
       } else {
         if (!edge) ucv = CSW_A2 * (d.utmp_x(i - 2, j) + d.utmp_x(i + 1, j)) + CSW_A1 * (d.utmp_x(i - 1, j) + d.utmp_x(i, j));
-        utv = (ucv - (v + b)[p] * (g.cosa_u + m2)[p]) * (g.rsin_u + m2)[p];
+        utv = (ucv - (v + b)[p] * m_cosa_u) * m_rsin_u;
       }
       (uc + b)[p] = ucv;
-      (ut + b)[p] = utv > (Real)0 ? dt2 * utv * (g.dy + m2)[p] * (g.sin_sg3 + m2)[IX(i - 1, j)] : dt2 * utv * (g.dy + m2)[p] * (g.sin_sg1 + m2)[p];
+      (ut + b)[p] = utv > (Real)0 ? dt2 * utv * m_dy * m_s3w : dt2 * utv * m_dy * m_s1;
     }
     if (i <= g.nx + 1) {  // vc, vt on i = is-1..ie+1, j = js-1..je+2
       Real vcv = (Real)0, vtv;
@@ -177,13 +199,14 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       if (edge && (j == 1 || j == npy)) {
         vtv = edge_interp4(VA(i, j - 2), VA(i, j - 1), VA(i, j), VA(i, j + 1), (g.dya + m2)[IX(i, j - 2)], (g.dya + m2)[IX(i, j - 1)], (g.dya + m2)[IX(i, j)],
                            (g.dya + m2)[IX(i, j + 1)]);
-        vcv = vtv > (Real)0 ? vtv * (g.sin_sg4 + m2)[IX(i, j - 1)] : vtv * (g.sin_sg2 + m2)[p];
+        vcv = vtv > (Real)0 ? vtv * m_s4s : vtv * m_s2;
       } else {
         if (!edge) vcv = CSW_A2 * (d.vtmp_y(i, j - 2) + d.vtmp_y(i, j + 1)) + CSW_A1 * (d.vtmp_y(i, j - 1) + d.vtmp_y(i, j));
-        vtv = (vcv - (u + b)[p] * (g.cosa_v + m2)[p]) * (g.rsin_v + m2)[p];
+        vtv = (vcv - (u + b)[p] * m_cosa_v) * m_rsin_v;
       }
       (vc + b)[p] = vcv;
-      (vt + b)[p] = vtv > (Real)0 ? dt2 * vtv * (g.dx + m2)[p] * (g.sin_sg4 + m2)[IX(i, j - 1)] : dt2 * vtv * (g.dx + m2)[p] * (g.sin_sg2 + m2)[p];
+      (vt + b)[p] = vtv > (Real)0 ? dt2 * vtv * m_dx * m_s4s : dt2 * vtv * m_dx * m_s2;
+    }
     }
   });
 
@@ -217,7 +240,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // (C) divergence on corners.  Two levels per thread: the ten metric terms of a corner are read once and
   // used for both levels (they are 2/3 of this kernel's bytes).
   if (nord > 0) {
-    const int npair = (nz1 + 2) / 2;
+    const int npair = (nz1 + FV3_KC) / FV3_KC;
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
       const int fl = g.flags[t];
       const long m2 = t * g.st2;
@@ -257,8 +280,9 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       if (cNE) mvc = VFm(npx, npy);
       if (cNW) mvc = VFm(1, npy);
       const Real rac = (g.rarea_c + m2)[IX(i, j)];
-      for (int kk = 0; kk < 2; ++kk) {
-        const int k = 2 * kp + kk;
+#pragma unroll 1
+      for (int kk = 0; kk < FV3_KC; ++kk) {
+        const int k = FV3_KC * kp + kk;
         if (k > nz1) break;
         const long b = t * g.st + k * g.sk;
         auto UF = [&](int ii, int jj, const Face &m) -> Real {
@@ -282,12 +306,29 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   }
 
   // (D) upwind transport (delpc, ptc, wc), kinetic energy, absolute vorticity
-  launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+  launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int j_) {
     const int fl = g.flags[t];
-    const long b = t * g.st + k * g.sk, m2 = t * g.st2;
+    const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
-    const unsigned p = IX(i, j);
+    int i = i_, j = j_;
+    unsigned p = IX(i, j);
+    // metric terms of the point, shared by the levels of the chunk (tile-edge clauses read their own)
+    const bool corner_pt = i >= 1 && j >= 1;
+    const Real ra = (g.rarea + m2)[p];
+    const Real m_dxc_s = corner_pt ? (g.dxc + m2)[IX(i, j - 1)] : (Real)0, m_dxc = (g.dxc + m2)[p];
+    const Real m_dyc_w = corner_pt ? (g.dyc + m2)[IX(i - 1, j)] : (Real)0, m_dyc = (g.dyc + m2)[p];
+    const Real m_fc = (g.fC + m2)[p], m_rac = (g.rarea_c + m2)[p];
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+    const int k = FV3_KC * kp + kk;
+    if (k > nz1) break;
+    i = i_;
+    j = j_;
+    FV3_LAUNDER(i);
+    FV3_LAUNDER(j);
+    p = IX(i, j);
+    const long b = t * g.st + k * g.sk;
     {
       // x fluxes at faces i and i+1 (fill_4corners x), y fluxes at j and j+1 (fill_4corners y)
       Real fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
@@ -305,7 +346,6 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         fy[a] = fy1[a] * (pt + b)[srcy];
         fy2[a] = fy1[a] * (w + b)[srcy];
       }
-      const Real ra = (g.rarea + m2)[p];
       const Real dpc = (delp + b)[p] + (fx1[0] - fx1[1] + fy1[0] - fy1[1]) * ra;
       (delpc + b)[p] = dpc;
       (ptc + b)[p] = ((pt + b)[p] * (delp + b)[p] + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
@@ -329,20 +369,20 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       }
       (ke + b)[p] = (Real)0.5 * dt2 * (uav * kev + vav * vov);
     }
-    if (i >= 1 && j >= 1) {  // absolute vorticity on corners is..ie+1, js..je+1
-      auto FX = [&](int ii, int jj) { return (uc + b)[IX(ii, jj)] * (g.dxc + m2)[IX(ii, jj)]; };
+    if (corner_pt) {  // absolute vorticity on corners is..ie+1, js..je+1
       auto FY = [&](int ii, int jj) { return (vc + b)[IX(ii, jj)] * (g.dyc + m2)[IX(ii, jj)]; };
-      Real vo = FX(i, j - 1) - FX(i, j) - FY(i - 1, j) + FY(i, j);
+      Real vo = (uc + b)[IX(i, j - 1)] * m_dxc_s - (uc + b)[p] * m_dxc - (vc + b)[IX(i - 1, j)] * m_dyc_w + (vc + b)[p] * m_dyc;
       if (W && S && i == 1 && j == 1) vo += FY(0, 1);
       if (E && S && i == npx && j == 1) vo -= FY(npx, 1);
       if (E && N && i == npx && j == npy) vo -= FY(npx, npy);
       if (W && N && i == 1 && j == npy) vo += FY(0, npy);
-      (vort + b)[p] = (g.fC + m2)[p] + (g.rarea_c + m2)[p] * vo;
+      (vort + b)[p] = m_fc + m_rac * vo;
+    }
     }
   });
 
   // (E) time-centred C-grid winds (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
     const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
@@ -351,8 +391,9 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const bool edge_u = (W && i == 1) || (E && i == npx), edge_v = (S && j == 1) || (N && j == npy);
     const Real cau = (g.cosa_u + m2)[p], sau = (g.sina_u + m2)[p], rdxc = (g.rdxc + m2)[p];
     const Real cav = (g.cosa_v + m2)[p], sav = (g.sina_v + m2)[p], rdyc = (g.rdyc + m2)[p];
-    for (int kk = 0; kk < 2; ++kk) {
-      const int k = 2 * kp + kk;
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
       if (k > nz1) break;
       const long b = t * g.st + k * g.sk;
       if (j <= g.ny) {

@@ -163,7 +163,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
   // levels (they are most of this kernel's bytes).  The tile-edge rows / columns (and the 16 cube-corner
   // solves) are a separate thin launch of the general per-level forms: keeping them out of the level
   // loop keeps its register footprint small.
-  const int npair = (g.nz + 1) / 2;
+  const int npair = (g.nz + FV3_KC - 1) / FV3_KC;
   launch3(c, s, Box{isd, ied, jsd, jed, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
     const long m2 = t * g.st2;
@@ -195,8 +195,9 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       s4 = (g.sin_sg4 + m2)[IX(i, j - 1)];
       s2 = (g.sin_sg2 + m2)[p];
     }
-    for (int kk = 0; kk < 2; ++kk) {
-      const int k = 2 * kp + kk;
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
       if (k > g.nz - 1) break;
       const long b = t * g.st + k * g.sk;
       const Real *ucl = uc + b, *vcl = vc + b;
@@ -843,12 +844,13 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
   Real *ut2 = c->scratch[SC_E], *vt2 = c->scratch[SC_F];  // = the utd / vtd slots below (damping fluxes overwrite them on damped levels)
   // (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  launch3(c, s, Box{isd, ied, jsd, jed, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j);
     const Real dx0 = (g.dx + m2)[p], dx1 = (g.dx + m2)[pn], dy0 = (g.dy + m2)[p], dy1 = (g.dy + m2)[pe_], ra = (g.rarea + m2)[p], f0v = (g.f0 + m2)[p];
-    for (int kk = 0; kk < 2; ++kk) {
-      const int k = 2 * kp + kk;
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
       if (k > nz1) break;
       const long b = t * g.st + k * g.sk;
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
@@ -1035,13 +1037,14 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   }
   const bool heat_on = cf.d_con > 1.0e-5;
   // (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (nz1 + 2) / 2 - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j), pne = IX(i + 1, j + 1);
     const Real rdx0 = (g.rdx + m2)[p], rdx1 = (g.rdx + m2)[pn], rdy0 = (g.rdy + m2)[p], rdy1 = (g.rdy + m2)[pe_];
     const Real rs2 = (g.rsin2 + m2)[p], cs = (g.cosa_s + m2)[p];
-    for (int kk = 0; kk < 2; ++kk) {
-      const int k = 2 * kp + kk;
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
       if (k > nz1) break;
       const long b = t * g.st + k * g.sk;
       Real hs = (heat_s + b)[p];
