@@ -532,7 +532,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
 
     // per-lane marching state
     struct Row {  // the inputs of one step, fetched TS_PF steps ahead of their use
-      Real qy, cx, xv, ar, cy, yv, ar3;
+      Real qy, cx, xv, ar, cy, yv;
     };
     // optional inputs consumed at the end of a step (mass_ fluxes, damping fluxes, mass_(i-1, r-3), mass_(i, r-2),
     // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
@@ -545,6 +545,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
+    Real a1[FV3_LPT], a2[FV3_LPT], a3[FV3_LPT];  // area of rows r-1, r-2, r-3 (a delay line instead of a second load of the metric)
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
     Real v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], v5[FV3_LPT], al_v[FV3_LPT];  // q_j likewise
     PpmCell cq[FV3_LPT], cv[FV3_LPT];                                        // reconstructed cell r-3 of q / q_j
@@ -557,7 +558,6 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
 
     auto load_row = [&](int r, int l) -> Row {
       const int rf = r - 2 < jsd ? jsd : r - 2;  // face / row of the y-sweeps (clamped while the windows fill)
-      const int r3 = r - 3 < jsd ? jsd : r - 3;  // row of q_i and of the outer x-sweep
       const unsigned p0 = pcol[l] + (unsigned)(r * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
       Row w;
       w.qy = qq[p0];
@@ -566,7 +566,6 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       w.ar = areab[p0];
       w.cy = cryb[pf];
       w.yv = yfxb[pf];
-      w.ar3 = areab[pcol[l] + (unsigned)(r3 * sj32)];
       return w;
     };
     FV3_LANES(blk, lane, l) {
@@ -575,6 +574,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       own_x[l] = i >= i0 && i < i0 + TS_OUT && i <= nx + 1;
       own_y[l] = i >= i0 && i < i0 + TS_OUT && i <= nx;
       w2[l] = w3[l] = w4[l] = w5[l] = al_q[l] = v2[l] = v3[l] = v4[l] = v5[l] = al_v[l] = (Real)0;
+      a1[l] = a2[l] = a3[l] = (Real)1;  // (warm-up steps: outputs masked, keep the divisions finite)
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
@@ -664,7 +664,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           cq[l] = co;
           const Real yv = cur[l].yv;
           const Real pn = yv * fyin[l];
-          const Real ar3 = cur[l].ar3;
+          const Real ar3 = a3[l];  // area(i, r-3): the row loaded three steps ago
           const Real qi = (w2[l] * ar3 + p_prev[l] - pn) / (ar3 + y_prev[l] - yv);
           p_prev[l] = pn;
           ypp[l] = y_prev[l];
@@ -763,7 +763,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 const Real qc = w2[l];  // q(i, r-3)
                 const Real mu = epi_mult_ ? (epi_mult_ == mass_ ? mb[l] : emu[l]) : (Real)1;
                 if (area_form_) {
-                  const Real ar_ = cur[l].ar3;
+                  const Real ar_ = a3[l];
                   const Real ra_x = ar_ + xjr[l] - exj[lane + 1], ra_y = ar_ + ypp[l] - cur[l].yv;
                   Real z = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
                   if (zdamp) z = z + (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
@@ -777,6 +777,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
           }
           mb[l] = o_mc[l];
+          a3[l] = a2[l];
+          a2[l] = a1[l];
+          a1[l] = cur[l].ar;
         }
         blk.wave_sync();
       };
