@@ -537,7 +537,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     // optional inputs consumed at the end of a step (mass_ fluxes, damping fluxes, mass_(i-1, r-3), mass_(i, r-2),
     // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
     // (loads return in order) leaves the prefetched rows in flight
-    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT];
+    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT], o_ax[FV3_LPT], o_ay[FV3_LPT];
     Real mb[FV3_LPT];  // mass_(i, r-3) = mass_(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
@@ -577,7 +577,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       a1[l] = a2[l] = a3[l] = (Real)1;  // (warm-up steps: outputs masked, keep the divisions finite)
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
-      fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = (Real)0;
+      fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
@@ -604,6 +604,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (mfx_) {
               o_mx[l] = (mfx_ + b)[p3];
               o_my[l] = (mfy_ + b)[pf];
+            }
+            if (acc_x_) {  // accumulated fluxes: fetched here, not at the += (a load consumed at once stalls the step for a full memory latency)
+              o_ax[l] = (acc_x_ + b)[p3];
+              o_ay[l] = (acc_y_ + b)[pf];
             }
             if (on) {
               o_dx[l] = (dfx + b)[p3];
@@ -699,7 +703,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (wflux_ && fx_row && own_x[l]) {
               const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
               (fx + b)[p] = v;
-              if (acc_x_) (acc_x_ + b)[p] += v;
+              if (acc_x_) (acc_x_ + b)[p] = o_ax[l] + v;
             }
             if (wind_v_ && fx_row && own_x[l]) (wind_v_ + b)[pcol[l] + (unsigned)(jr * sj32)] = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
             if (epi_out_) {
@@ -754,7 +758,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (wflux_ && fy_row && own_y[l]) {
               const unsigned p = pcol[l] + (unsigned)(jf * sj32);
               (fy + b)[p] = v;
-              if (acc_y_) (acc_y_ + b)[p] += v;
+              if (acc_y_) (acc_y_ + b)[p] = o_ay[l] + v;
             }
             if (wind_u_ && fy_row && own_y[l]) (wind_u_ + b)[pcol[l] + (unsigned)(jf * sj32)] = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
             if (epi_out_) {
