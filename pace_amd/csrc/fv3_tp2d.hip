@@ -479,7 +479,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
   const int nseg = (g.ny + seg - 1) / seg;
-  const size_t smem = sizeof(Real) * (2 * TS_LINE + 4 * (FV3_WAVE + 1));
+  const size_t smem = sizeof(Real) * (2 * TS_LINE + 4 * (FV3_WAVE + 1) + 32);
   const bool area_form = epi && epi->area_form;
   const Real *zfx = epi ? epi->zfx : nullptr, *zfy = epi ? epi->zfy : nullptr, *zon = epi ? epi->zon : nullptr;
   Real *epi_out = epi ? epi->out : nullptr;
@@ -495,7 +495,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const Geo *gp = c->g_dev;
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
-  const MPtr area = g.area;
+  const MPtr area = g.area, gdxa = g.dxa;
   launch_waves<TS_WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     // fold the features this instantiation does not have
     constexpr bool C_MFX = FEAT & TF_MFX, C_DAMP = FEAT & TF_DAMP, C_MASS = FEAT & TF_MASS, C_EPI = FEAT & TF_EPI, C_AREA = FEAT & TF_AREA;
@@ -520,6 +520,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real *exx = exp_ + FV3_WAVE + 1;  // xfx
     Real *exf = exx + FV3_WAVE + 1;   // final fx of the lane's face (epilogue: read by lane - 1)
     Real *exj = exf + FV3_WAVE + 1;   // xfx(i, r-3) (area-form epilogue)
+    Real *emr = exj + FV3_WAVE + 1;   // tile-edge strips: dxa of the 4 + 4 cells around the W / E edge, rows r..r-3 (ring of 4 x 8)
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
     const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
@@ -533,6 +534,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     // per-lane marching state
     struct Row {  // the inputs of one step, fetched TS_PF steps ahead of their use
       Real qy, cx, xv, ar, cy, yv;
+      Real em;  // tile-edge strips, lanes 0..7: dxa(edge cell, r) for the one-sided formulas (prefetched with the row: a load inside the step stalls it)
     };
     // optional inputs consumed at the end of a step (mass_ fluxes, damping fluxes, mass_(i-1, r-3), mass_(i, r-2),
     // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
@@ -556,7 +558,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     unsigned pcol[FV3_LPT];  // in-plane offset of (ic, 0)
     bool own_x[FV3_LPT], own_y[FV3_LPT];
 
-    auto load_row = [&](int r, int l) -> Row {
+    const MPtr dxab0 = gdxa + m2;
+    auto load_row = [&](int r, int l, int lane) -> Row {
       const int rf = r - 2 < jsd ? jsd : r - 2;  // face / row of the y-sweeps (clamped while the windows fill)
       const unsigned p0 = pcol[l] + (unsigned)(r * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
       Row w;
@@ -566,6 +569,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       w.ar = areab[p0];
       w.cy = cryb[pf];
       w.yv = yfxb[pf];
+      w.em = (Real)1;
+      if ((W || E) && lane < 8) {
+        const bool have = lane < 4 ? W : E;
+        const int sc = lane < 4 ? lane - 1 : npx - 2 + (lane - 4);  // columns -1..2 (W) / npx-2..npx+1 (E)
+        if (have) w.em = dxab0[(unsigned)((r + go) * sj32 + sc + go)];
+      }
       return w;
     };
     FV3_LANES(blk, lane, l) {
@@ -583,8 +592,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
-      nxt[l] = load_row(ja - 3, l);
-      if (TS_PF == 2) nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l);
+      nxt[l] = load_row(ja - 3, l, lane);
+      if (TS_PF == 2) nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l, lane);
+      if (lane < 32) emr[lane] = (Real)1;
     }
 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
@@ -638,10 +648,11 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           cur[l] = nxt[l];
           if (TS_PF == 2) {
             nxt[l] = nx2[l];
-            nx2[l] = load_row(rn, l);
+            nx2[l] = load_row(rn, l, lane);
           } else {
-            nxt[l] = load_row(rn, l);
+            nxt[l] = load_row(rn, l, lane);
           }
+          if (XE && lane < 8) emr[(r & 3) * 8 + lane] = cur[l].em;
           Real qy = cur[l].qy, qx = qy;
           if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
             const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
@@ -685,12 +696,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           Real fxin, fxout;
           if (XE) {
             const int i = i0 - 3 + lane;
-            const MPtr dxab = gp->dxa + m2;
+            auto EI = [&](int s_) { return s_ <= 2 ? s_ + 1 : s_ - (npx - 2) + 4; };  // ring column of an edge cell
             auto Qx = [&](int s_) { return lq[s_ - i0 + 6]; };
-            auto Mx = [&](int s_) { return dxab[(unsigned)((r + go) * sj32 + s_ + go)]; };
+            auto Mx = [&](int s_) { return emr[(r & 3) * 8 + EI(s_)]; };
             fxin = ppm_flux(Qx, Mx, cx, i, W, E, npx, hord);
             auto Qi = [&](int s_) { return lqi[s_ - i0 + 6]; };
-            auto Mx3 = [&](int s_) { return dxab[(unsigned)((r3 + go) * sj32 + s_ + go)]; };
+            auto Mx3 = [&](int s_) { return emr[((r - 3) & 3) * 8 + EI(s_)]; };
             fxout = ppm_flux(Qi, Mx3, cx3[l], i, W, E, npx, hord);
           } else {
             const Real *a = lq + lane, *bq = lqi + lane;
