@@ -1210,13 +1210,24 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
   const Real cd = (Real)cdd;
   const int ntimes = nmax < 3 ? nmax : 3;
   const int nz1 = g.nz - 1;
-  Real *fx = c->scratch[SC_A], *fy = c->scratch[SC_B];
+  // One launch per iteration, out of place (q -> B -> A -> q for three iterations): the x / y fluxes of a cell's four
+  // faces are formed in registers from the five neighbouring values instead of being stored and read back (7 -> 2
+  // field passes per iteration), FV3_KC levels per thread with the five metric terms loaded once.  Every launch
+  // covers the whole padded plane -- cells outside the iteration's update box are copied -- so each buffer is
+  // complete, as the in-place reference field is.
+  Real *bufA = c->scratch[SC_A], *bufB = c->scratch[SC_B];
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  const int nkc = (nz1 + FV3_KC) / FV3_KC;
+  Real *in = q;
   for (int n = 1; n <= ntimes; ++n) {
     const int nt = ntimes - n;
+    Real *out = nt == 0 ? (ntimes == 1 ? bufA : q) : (nt % 2 ? bufA : bufB);
+    if (out == in) out = out == bufA ? bufB : bufA;
+    Real *qin = in;
     launch3(c, s, Box{1, 1, 1, 1, 0, nz1}, [=] FV3_HD(int t, int k, int, int) {
       const int fl = g.flags[t];
       const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-      Real *qq = q + t * g.st + k * g.sk;
+      Real *qq = qin + t * g.st + k * g.sk;
       const int npx = g.npx, npy = g.npy, ie = g.nx, je = g.ny;
       const Real r3 = (Real)(1.0 / 3.0);
       if (W && S) {
@@ -1236,26 +1247,60 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
         qq[IX(1, je)] = a; qq[IX(0, je)] = a; qq[IX(1, npy)] = a;
       }
     });
-    launch3(c, s, Box{1 - nt, g.nx + 1 + nt, 1 - nt, g.ny + 1 + nt, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    launch3(c, s, Box{isd, ied, jsd, jed, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int j_) {
       const int fl = g.flags[t];
-      const long b = t * g.st + k * g.sk, m2 = t * g.st2;
-      const Real *qq = q + b;
-      const unsigned p = IX(i, j);
-      if (j <= g.ny + nt) {
-        const Real a = nt > 0 ? cc<1>(qq, g, fl, i - 1, j) : qq[IX(i - 1, j)];
-        const Real e = nt > 0 ? cc<1>(qq, g, fl, i, j) : qq[p];
-        (fx + b)[p] = (g.del6_v + m2)[p] * (a - e);
+      const long m2 = t * g.st2;
+      int i = i_, j = j_;
+      const bool upd = i >= 1 - nt && i <= g.nx + nt && j >= 1 - nt && j <= g.ny + nt;
+      const unsigned p0 = IX(i, j);
+      Real mvx0 = (Real)0, mvx1 = (Real)0, muy0 = (Real)0, muy1 = (Real)0, cra = (Real)0;
+      if (upd) {
+        mvx0 = (g.del6_v + m2)[p0];
+        mvx1 = (g.del6_v + m2)[IX(i + 1, j)];
+        muy0 = (g.del6_u + m2)[p0];
+        muy1 = (g.del6_u + m2)[IX(i, j + 1)];
+        cra = cd * (g.rarea + m2)[p0];
       }
-      if (i <= g.nx + nt) {
-        const Real a = nt > 0 ? cc<2>(qq, g, fl, i, j - 1) : qq[IX(i, j - 1)];
-        const Real e = nt > 0 ? cc<2>(qq, g, fl, i, j) : qq[p];
-        (fy + b)[p] = (g.del6_u + m2)[p] * (a - e);
+#pragma unroll 1
+      for (int kk = 0; kk < FV3_KC; ++kk) {
+        const int k = FV3_KC * kp + kk;
+        if (k > nz1) break;
+        i = i_;
+        j = j_;
+        FV3_LAUNDER(i);
+        FV3_LAUNDER(j);
+        const long b = t * g.st + k * g.sk;
+        const Real *qq = qin + b;
+        const unsigned p = IX(i, j);
+        Real v = qq[p];
+        if (upd) {
+          Real xw, xc, xe, ys, yc, yn;
+          if (nt > 0) {
+            xw = cc<1>(qq, g, fl, i - 1, j);
+            xc = cc<1>(qq, g, fl, i, j);
+            xe = cc<1>(qq, g, fl, i + 1, j);
+            ys = cc<2>(qq, g, fl, i, j - 1);
+            yc = cc<2>(qq, g, fl, i, j);
+            yn = cc<2>(qq, g, fl, i, j + 1);
+          } else {
+            xw = qq[IX(i - 1, j)];
+            xe = qq[IX(i + 1, j)];
+            ys = qq[IX(i, j - 1)];
+            yn = qq[IX(i, j + 1)];
+            xc = yc = v;
+          }
+          v = v + cra * (mvx0 * (xw - xc) - mvx1 * (xc - xe) + muy0 * (ys - yc) - muy1 * (yc - yn));
+        }
+        (out + b)[p] = v;
       }
     });
-    launch3(c, s, Box{1 - nt, g.nx + nt, 1 - nt, g.ny + nt, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-      const long b = t * g.st + k * g.sk;
-      const unsigned p = IX(i, j);
-      (q + b)[p] = (q + b)[p] + cd * g.rarea[t * g.st2 + p] * ((fx + b)[p] - (fx + b)[IX(i + 1, j)] + (fy + b)[p] - (fy + b)[IX(i, j + 1)]);
+    in = out;
+  }
+  if (in != q) {
+    Real *src = in;
+    launch3<4>(c, s, Box{isd, ied, jsd, jed, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      q[p] = src[p];
     });
   }
   return fv3_post(c, s, "del2_cubed");
