@@ -433,6 +433,93 @@ int fv3_update_dz_c_from(fv3_ctx *c, const fv3_field *zs_, const fv3_field *ut_,
   const Real top_ratio = (Real)(dp[0] / (dp[0] + dp[1]));
   const Real bot_ratio = (Real)(dp[nz - 1] / (dp[nz - 2] + dp[nz - 1]));
   Real *gzn = c->scratch[SC_A];
+  if (gzin != gz && nz >= 3) {
+    // Out of place (the sequencer's zh -> gz form): ONE column kernel walks the interfaces upward from the surface,
+    // forms the advected height of interface k in registers and applies the monotonicity scan at once -- the
+    // intermediate field is never stored (2 field passes less) and each wind layer is read once (it serves the
+    // interface above and the one below).  In place (gz -> gz) the two-kernel form below is required: neighbours'
+    // heights are read while columns are rewritten.
+    launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+      const int fl = g.flags[t];
+      const long tb = t * g.st, m2 = t * g.st2;
+      const unsigned pix = IX(i, j), qx1 = IX(i + 1, j), qy1 = IX(i, j + 1);
+      const unsigned gw = f4_index<1>(g, fl, i - 1, j), gc1 = f4_index<1>(g, fl, i, j), ge = f4_index<1>(g, fl, i + 1, j);
+      const unsigned gs = f4_index<2>(g, fl, i, j - 1), gc2 = f4_index<2>(g, fl, i, j), gn = f4_index<2>(g, fl, i, j + 1);
+      const Real ar = (g.area + m2)[pix];
+      // layer values at the four faces: a* = layer k-1 (above the interface), c* = layer k (below), p* = layer k+1
+      Real ax0, ax1, ay0, ay1, cx0 = (Real)0, cx1 = (Real)0, cy0 = (Real)0, cy1 = (Real)0, px0 = (Real)0, px1 = (Real)0, py0 = (Real)0, py1 = (Real)0;
+      {
+        const Real *u1 = ut + tb + (long)(nz - 1) * g.sk, *v1 = vt + tb + (long)(nz - 1) * g.sk;
+        ax0 = u1[pix];
+        ax1 = u1[qx1];
+        ay0 = v1[pix];
+        ay1 = v1[qy1];
+      }
+      Real below = (Real)0;
+#pragma unroll 1
+      for (int k = nz; k >= 0; --k) {
+        // layer k-2 (becomes "above" for the next interface); at the bottom it also enters the extrapolation
+        Real nx0 = (Real)0, nx1 = (Real)0, ny0 = (Real)0, ny1 = (Real)0;
+        if (k >= 2) {
+          const Real *u2 = ut + tb + (long)(k - 2) * g.sk, *v2 = vt + tb + (long)(k - 2) * g.sk;
+          nx0 = u2[pix];
+          nx1 = u2[qx1];
+          ny0 = v2[pix];
+          ny1 = v2[qy1];
+        }
+        Real x0, x1, y0, y1;
+        if (k == nz) {
+          x0 = ax0 + (ax0 - nx0) * bot_ratio;
+          x1 = ax1 + (ax1 - nx1) * bot_ratio;
+          y0 = ay0 + (ay0 - ny0) * bot_ratio;
+          y1 = ay1 + (ay1 - ny1) * bot_ratio;
+        } else if (k == 0) {
+          x0 = cx0 + (cx0 - px0) * top_ratio;
+          x1 = cx1 + (cx1 - px1) * top_ratio;
+          y0 = cy0 + (cy0 - py0) * top_ratio;
+          y1 = cy1 + (cy1 - py1) * top_ratio;
+        } else {
+          const Real d1 = g.dp_ref[k], d0 = g.dp_ref[k - 1];
+          const Real int_ratio = (Real)1.0 / (d0 + d1);
+          x0 = (d1 * ax0 + d0 * cx0) * int_ratio;
+          x1 = (d1 * ax1 + d0 * cx1) * int_ratio;
+          y0 = (d1 * ay0 + d0 * cy0) * int_ratio;
+          y1 = (d1 * ay1 + d0 * cy1) * int_ratio;
+        }
+        const Real *gg = gzin + tb + (long)k * g.sk;
+        const Real fx0 = x0 * (x0 > (Real)0 ? gg[gw] : gg[gc1]);
+        const Real fx1 = x1 * (x1 > (Real)0 ? gg[gc1] : gg[ge]);
+        const Real fy0 = y0 * (y0 > (Real)0 ? gg[gs] : gg[gc2]);
+        const Real fy1 = y1 * (y1 > (Real)0 ? gg[gc2] : gg[gn]);
+        const Real zn = (gg[pix] * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+        Real v = zn;
+        if (k == nz) {
+          ws[t * g.st2 + pix] = (zs[t * g.st2 + pix] - zn) / dt;
+        } else {
+          v = fv3_max(zn, below + dz_min);
+        }
+        (gz + tb + (long)k * g.sk)[pix] = v;
+        below = v;
+        // shift: the interface above sees this one's "above" layer as its "below" layer
+        px0 = cx0;
+        px1 = cx1;
+        py0 = cy0;
+        py1 = cy1;
+        cx0 = ax0;
+        cx1 = ax1;
+        cy0 = ay0;
+        cy1 = ay1;
+        if (k == nz) {
+          // (interface nz-1 keeps layer nz-1 below it and gets layer nz-2 above it)
+        }
+        ax0 = nx0;
+        ax1 = nx1;
+        ay0 = ny0;
+        ay1 = ny1;
+      }
+    });
+    return fv3_post(c, s, "update_dz_c");
+  }
   launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nz}, [=] FV3_HD(int t, int k, int i, int j) {
     const int fl = g.flags[t];
     const long bt = t * g.st, b = bt + k * g.sk, m2 = t * g.st2;
