@@ -94,3 +94,24 @@ def test_field_validation(hostemu):
 
     with pytest.raises(lib.Fv3Error, match="shape"):
         cs.sf.call("copy", good.fref, Quantity(other, ("x", "y", "z")).fref)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fv3_mi355x.h is the boundary a non-Python host binds (cgo / JNI / Fortran ISO_C_BINDING ...): it must
+    compile as plain C99, and a C translation unit that references every declared entry point must link against the
+    built library (no C++ or torch types in the signatures)."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "fv3_mi355x.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    text = open(hdr).read()
+    names = sorted(set(re.findall(r"\b(fv3_[a-z0-9_]+)\s*\(", text)) - {"fv3_halo_fn"})
+    names = [n for n in names if re.search(r"^\s*(?:const\s+)?[a-z_0-9 ]+\**\s*\b%s\s*\(" % n, text, re.M)]
+    assert len(names) >= 20
+    src = tmp_path / "use_all.c"
+    body = "\n".join(f"  p[{i}] = (void *)&{n};" for i, n in enumerate(names))
+    src.write_text(f'#include "fv3_mi355x.h"\n#include <stdio.h>\nint main(void) {{\n  void *p[{len(names)}];\n{body}\n  printf("%d %p\\n", {len(names)}, p[0]);\n  return 0;\n}}\n')
+    obj = tmp_path / "use_all.o"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o", str(obj)], check=True)
