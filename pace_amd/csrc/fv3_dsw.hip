@@ -746,7 +746,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   const int nz1 = g.nz - 1;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   Real *ut = c->scratch[SC_A], *vt = c->scratch[SC_B], *fx = c->scratch[SC_C], *fy = c->scratch[SC_D], *gx = c->scratch[SC_E], *gy = c->scratch[SC_F];
-  Real *dw = c->scratch[SC_G], *heat_s = c->scratch[SC_H], *ke = c->scratch[SC_I], *wk = c->scratch[SC_J];
+  Real *heat_s = c->scratch[SC_H], *ke = c->scratch[SC_I], *wk = c->scratch[SC_J];
   int nord_max_v = 0, nord_max_w = 0, nord_max_t = 0, nord_max = 0;
   for (int k = 0; k < g.nz; ++k) {
     nord_max_v = std::max(nord_max_v, c->nord_v_h[k]);
@@ -768,7 +768,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   fv3_wait(c, s2, 0);
   del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
   fv3_signal(c, s2, 1);
-  del6_vt_flux(c, s2, w, d2w, dB_x, dB_y, dn_w, false, 0, nz1);
+  // (w's damping fluxes get their own pair: the kernel that applies them runs after the transports)
+  Real *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
+  del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
   fv3_signal(c, s2, 2);
 
   fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy);
@@ -787,24 +789,11 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   del6_vt_flux(c, s2, q_con, d2w, dA_x, dA_y, dn_t, true, 0, nz1);
   fv3_signal(c, s2, 3);
 
-  // ---- vertical velocity: del-n damping + heat, then transport with the mass fluxes
-  {
-    Real *fx2 = dB_x, *fy2 = dB_y;
-    fv3_wait(c, s, 2);
-    launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-      const long b = t * g.st + k * g.sk;
-      const unsigned p = IX(i, j);
-      Real hs = (Real)0, dwv = (Real)0;
-      if (g.damp_w[k] > (Real)1.0e-5) {
-        const Real dd8 = g.ke_bg[k] * fabs(dt);
-        dwv = ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-        hs = dd8 - dwv * ((w + b)[p] + (Real)0.5 * dwv);
-      }
-      (dw + b)[p] = dwv;
-      (heat_s + b)[p] = hs;
-    });
-    fv3_signal(c, s, 6);
-  }
+  // ---- vertical velocity: transport with the mass fluxes; its del-n damping increment dw and the heat it
+  //      dissipates are formed by the post-transport kernel below straight from the damping fluxes (the old w is
+  //      still in place there), so neither a dw field nor a separate pass over the fluxes exists
+  fv3_wait(c, s, 2);
+  fv3_signal(c, s, 6);
   fv3_wait(c, s2, 6);
   del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
   fv3_signal(c, s2, 4);
@@ -825,13 +814,21 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
   }
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long p = t * g.st + k * g.sk + IX(i, j);
+    const long b = t * g.st + k * g.sk;
+    const unsigned q = IX(i, j);
+    const long p = b + q;
     const Real dpnv = dpn[p];
     delp[p] = dpnv;
     pt[p] = pt_dp[p] / dpnv;
-    Real wn = w_dp[p] / dpnv;
-    if (g.damp_w[k] > (Real)1.0e-5) wn = wn + dw[p];
+    Real wn = w_dp[p] / dpnv, hs = (Real)0;
+    if (g.damp_w[k] > (Real)1.0e-5) {
+      const Real dd8 = g.ke_bg[k] * fabs(dt);
+      const Real dwv = ((dC_x + b)[q] - (dC_x + b)[IX(i + 1, j)] + (dC_y + b)[q] - (dC_y + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + q];
+      hs = dd8 - dwv * (w[p] + (Real)0.5 * dwv);  // (w[p]: still the pre-transport value)
+      wn = wn + dwv;
+    }
     w[p] = wn;
+    heat_s[p] = hs;
     q_con[p] = qc_dp[p] / dpnv;
   });
 

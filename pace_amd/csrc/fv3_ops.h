@@ -31,7 +31,8 @@ enum {
   SC_R = 24,  // d_sw absolute vorticity
   SC_S = 25,  // second pair of del-n damping fluxes (d_sw pipelines the chains one transport ahead)
   SC_T = 26,
-  SC_COUNT = 27
+  SC_U = 27,  // d_sw: y damping flux of w (kept until the post-transport kernel forms dw and its heat)
+  SC_COUNT = 28
 };
 
 // Per-level del-n control.  Level k uses order nord_k[k] (or nord_u), coefficient damp_k[k]

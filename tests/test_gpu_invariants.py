@@ -61,12 +61,18 @@ def test_stateless_deterministic_and_no_allocation(gpu_backend):
     h1.synchronize()
     for n in ("delp", "pt", "u", "v", "w", "delz"):
         assert torch.equal(getattr(h1.state, n).storage, getattr(h2.state, n).storage), n
-    # second call: no device allocation (scratch is owned by the context, buffers are cached)
+    # second call: no device allocation (scratch is owned by the context, buffers are cached).
+    # (objects of earlier tests may be collected DURING the call and lower memory_allocated(): collect them first
+    # and compare the allocation COUNT, which only ever grows)
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
     stats0 = torch.cuda.memory_stats()["allocation.all.allocated"]
     h1.step()
     h1.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.memory_allocated() <= before
     assert torch.cuda.memory_stats()["allocation.all.allocated"] == stats0
 
 
