@@ -479,7 +479,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
   const int nseg = (g.ny + seg - 1) / seg;
-  const size_t smem = sizeof(Real) * (2 * TS_LINE + 4 * (FV3_WAVE + 1) + 32);
+  const size_t smem = sizeof(Real) * (2 * TS_LINE + 5 * (FV3_WAVE + 1) + 32);
   const bool area_form = epi && epi->area_form;
   const Real *zfx = epi ? epi->zfx : nullptr, *zfy = epi ? epi->zfy : nullptr, *zon = epi ? epi->zon : nullptr;
   Real *epi_out = epi ? epi->out : nullptr;
@@ -520,7 +520,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real *exx = exp_ + FV3_WAVE + 1;  // xfx
     Real *exf = exx + FV3_WAVE + 1;   // final fx of the lane's face (epilogue: read by lane - 1)
     Real *exj = exf + FV3_WAVE + 1;   // xfx(i, r-3) (area-form epilogue)
-    Real *emr = exj + FV3_WAVE + 1;   // tile-edge strips: dxa of the 4 + 4 cells around the W / E edge, rows r..r-3 (ring of 4 x 8)
+    Real *exm = exj + FV3_WAVE + 1;   // mass(i, r-3) of the lane (read by lane + 1: the west cell of its face)
+    Real *emr = exm + FV3_WAVE + 1;   // tile-edge strips: dxa of the 4 + 4 cells around the W / E edge, rows r..r-3 (ring of 4 x 8)
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
     const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
@@ -539,7 +540,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     // optional inputs consumed at the end of a step (mass_ fluxes, damping fluxes, mass_(i-1, r-3), mass_(i, r-2),
     // epilogue terms): loaded at the top of the same step, AHEAD of the prefetch, so that waiting for them
     // (loads return in order) leaves the prefetched rows in flight
-    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_ma[FV3_LPT], o_mc[FV3_LPT], o_ax[FV3_LPT], o_ay[FV3_LPT];
+    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_dx[FV3_LPT], o_dy[FV3_LPT], o_mc[FV3_LPT], o_ax[FV3_LPT], o_ay[FV3_LPT];
     Real mb[FV3_LPT];  // mass_(i, r-3) = mass_(i, r-2) of the previous step
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
@@ -586,7 +587,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       a1[l] = a2[l] = a3[l] = (Real)1;  // (warm-up steps: outputs masked, keep the divisions finite)
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
-      fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_ma[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
+      fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
@@ -595,6 +596,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       nxt[l] = load_row(ja - 3, l, lane);
       if (TS_PF == 2) nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l, lane);
       if (lane < 32) emr[lane] = (Real)1;
+      exm[lane] = (Real)0;
     }
 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
@@ -622,7 +624,6 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (on) {
               o_dx[l] = (dfx + b)[p3];
               o_dy[l] = (dfy + b)[pf];
-              if (mass_) o_ma[l] = (mass_ + b)[p3 - (p3 != 0u)];  // (first halo cell of the plane: value unused)
             }
             if (need_mc) o_mc[l] = (mass_ + b)[pf];
             if (epi_out_) {
@@ -710,7 +711,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           }
           {
             Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx_ ? o_mx[l] : xv3[l]);
-            if (on) v = mass_ ? v + (Real)0.5 * damp * (o_ma[l] + mb[l]) * o_dx[l] : v + o_dx[l];
+            // (mass of the west cell = the neighbouring lane's mb, through an LDS line instead of a second load of the field)
+            if (on) v = mass_ ? v + (Real)0.5 * damp * ((lane > 0 ? exm[lane - 1] : (Real)0) + mb[l]) * o_dx[l] : v + o_dx[l];
             if (wflux_ && fx_row && own_x[l]) {
               const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
               (fx + b)[p] = v;
@@ -792,6 +794,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
           }
           mb[l] = o_mc[l];
+          if (on && mass_) exm[lane] = mb[l];
           a3[l] = a2[l];
           a2[l] = a1[l];
           a1[l] = cur[l].ar;
