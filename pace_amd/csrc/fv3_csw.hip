@@ -306,8 +306,10 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const Box nat{0, g.nx + 2, 0, g.ny + 2, 0, nkc - 1};
     if (b_split) {
       // (one right-sized launch per window: launch3w sizes every window's grid for the largest one)
-      launch3(c, s, Box{0, 5, 0, g.ny + 2, 0, nkc - 1}, stage_b);
-      launch3(c, s, Box{g.nx - 3, g.nx + 2, 0, g.ny + 2, 0, nkc - 1}, stage_b);
+      // (the 6-column W / E windows run transposed -- lanes along j -- so that a wave has 64 busy lanes instead of 6)
+      const int e0 = g.nx - 3;
+      launch3(c, s, Box{0, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_b(t, kp, b_, a); });
+      launch3(c, s, Box{0, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_b(t, kp, e0 + b_, a); });
       launch3(c, s, Box{6, g.nx - 4, 0, 5, 0, nkc - 1}, stage_b);
       launch3(c, s, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, nkc - 1}, stage_b);
     } else {
