@@ -6,6 +6,7 @@
 // Per-level parameters (nord, damp, d_con of the sponge layers) come from device tables indexed
 // by k = blockIdx.z, so one launch serves all levels (the reference builds one stencil per
 // k-range through restrict_vertical).
+#include "fv3_a2b.h"
 #include "fv3_ops.h"
 #include "fv3_ppm.h"
 
@@ -1001,23 +1002,26 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     }
   }
   // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
-  Real *wkb = c->scratch[SC_DN_FX];
-  a2b_ord4(c, s, wk, wkb, 0, 0, g.nz, false);
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const int nord = g.nord[k];
-    if (nord == 0) return;
-    const long b = t * g.st + k * g.sk;
-    const unsigned p = IX(i, j);
-    const Real dpc = (delpc + b)[p];
-    Real vo = (Real)0;
-    if ((Real)cf.dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + (wkb + b)[p] * (wkb + b)[p]);
-    const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, (Real)cf.dddmp * vo));
-    const Real dn_ = (dnew + b)[p];
-    (divgd + b)[p] = dn_;  // (no-op for the in-place staged form)
-    const Real vd = damp2 * dpc + tab.dd8[k] * dn_;
-    (vdamp + b)[p] = vd;
-    (ke + b)[p] += vd;
-  });
+  // (wkb, the corner vorticity, is no longer a field: see the a2b epilogue below)
+  // Corner vorticity (a2b_ord4 of wk) is consumed once, pointwise, by the Smagorinsky-type damping below: that
+  // kernel runs as the epilogue of the corner interpolation and the corner field is never stored.
+  {
+    const Real dddmp = (Real)cf.dddmp;
+    a2b_ord4_t<8>(c, s, wk, 0, 0, g.nz, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
+      const int nord = g.nord[k];
+      if (nord == 0) return;
+      const long b = t * g.st + k * g.sk;
+      const Real dpc = (delpc + b)[p];
+      Real vo = (Real)0;
+      if (dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkbv * wkbv);
+      const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, dddmp * vo));
+      const Real dn_ = (dnew + b)[p];
+      (divgd + b)[p] = dn_;  // (no-op for the in-place staged form)
+      const Real vd = damp2 * dpc + tab.dd8[k] * dn_;
+      (vdamp + b)[p] = vd;
+      (ke + b)[p] += vd;
+    });
+  }
 
   // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
   //      transport kernel's epilogue (the vorticity fluxes are never stored)
