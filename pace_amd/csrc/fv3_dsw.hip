@@ -155,9 +155,13 @@ FV3_HD inline bool fxadv_int_v(const Geo &g, int fl, int i, int j) {
 
 // cx / cy (optional): accumulated Courant numbers of the tracer sub-cycling, cx += crx, cy += cry on the
 // faces d_sw accumulates them (i in 1..nx+1 resp. j in 1..ny+1, all halo rows / columns)
+// thin_ut: store ut / vt only within 4 cells of a cube-tile edge -- all d_sw reads of them afterwards are the tile-edge
+// forms of the corner kinetic energy (the standalone operator stores them everywhere, as the reference does)
 void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt, Real *cx,
-           Real *cy) {
+           Real *cy, bool thin_ut) {
   const Geo g = c->g;
+  static const bool full_ut = getenv("FV3_FXADV_FULL_UT") != nullptr;  // A/B switch
+  if (full_ut) thin_ut = false;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   // Interior kernel, two levels per thread: away from the tile-edge rows / columns the contravariant wind is one
   // expression in (uc, vc) and seven metric terms per component; those are read once and used for both
@@ -168,10 +172,13 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
   launch3(c, s, Box{isd, ied, jsd, jed, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
     const long m2 = t * g.st2;
-    const bool int_u = fxadv_int_u(g, fl, i, j), int_v = fxadv_int_v(g, fl, i, j);
-    if (!int_u && !int_v) return;
+    bool int_u = fxadv_int_u(g, fl, i, j), int_v = fxadv_int_v(g, fl, i, j);
     const unsigned p = IX(i, j);
     const bool out_x = int_u && i >= 1 && i <= g.nx + 1, out_y = int_v && j >= 1 && j <= g.ny + 1;
+    const bool st_ut = !thin_ut || ((fl & FV3_W) && i <= 4) || ((fl & FV3_E) && i >= g.npx - 3) || ((fl & FV3_S) && j <= 4) || ((fl & FV3_N) && j >= g.npy - 3);
+    int_u = int_u && (out_x || st_ut);  // (nothing to do where neither the Courant number nor ut itself is wanted)
+    int_v = int_v && (out_y || st_ut);
+    if (!int_u && !int_v) return;
     Real cu = 0, ru = 0, rdxa_m = 0, rdxa_0 = 0, dy_ = 0, s3 = 0, s1 = 0;
     Real cv = 0, rv = 0, rdya_m = 0, rdya_0 = 0, dx_ = 0, s4 = 0, s2 = 0;
     if (int_u) {
@@ -204,7 +211,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       const Real *ucl = uc + b, *vcl = vc + b;
       if (int_u) {
         const Real utv = (ucl[p] - (Real)0.25 * cu * (vcl[IX(i - 1, j)] + vcl[p] + vcl[IX(i - 1, j + 1)] + vcl[IX(i, j + 1)])) * ru;
-        (ut + b)[p] = utv;
+        if (st_ut) (ut + b)[p] = utv;
         if (out_x) {
           const Real x = dt * utv;
           Real cr;
@@ -221,7 +228,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       }
       if (int_v) {
         const Real vtv = (vcl[p] - (Real)0.25 * cv * (ucl[IX(i, j - 1)] + ucl[IX(i + 1, j - 1)] + ucl[p] + ucl[IX(i + 1, j)])) * rv;
-        (vt + b)[p] = vtv;
+        if (st_ut) (vt + b)[p] = vtv;
         if (out_y) {
           const Real y = dt * vtv;
           Real cr;
@@ -351,7 +358,7 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
                          const fv3_field *yfx_, const fv3_field *ut_, const fv3_field *vt_, double dt, void *stream) {
   if (!c) return FV3_ERR_ARG;
   FV3_FIELD(uc, uc_) FV3_FIELD(vc, vc_) FV3_FIELD(crx, crx_) FV3_FIELD(cry, cry_) FV3_FIELD(xfx, xfx_) FV3_FIELD(yfx, yfx_) FV3_FIELD(ut, ut_) FV3_FIELD(vt, vt_)
-  fxadv(c, (fv3_stream_t)stream, uc, vc, crx, cry, xfx, yfx, ut, vt, (Real)dt, nullptr, nullptr);
+  fxadv(c, (fv3_stream_t)stream, uc, vc, crx, cry, xfx, yfx, ut, vt, (Real)dt, nullptr, nullptr, false);
   return fv3_post(c, (fv3_stream_t)stream, "fxadv");
 }
 
@@ -774,7 +781,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
   fv3_signal(c, s2, 2);
 
-  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy);
+  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
 
   // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
   //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
