@@ -963,6 +963,10 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   //      the work arrays of the iteration exactly as in the reference (their C-grid values are dead).
   Real *vdamp = c->scratch[SC_DN_D2];  // damping field "vort" on corners (free: del-n chains are done)
   // nord == 0 levels: divergence of the D-grid wind on the fly; nord > 0 levels: delpc = divgd
+  static const bool staged_dd = getenv("FV3_DIVDAMP_STAGED") != nullptr;  // A/B switch for profiling
+  // the marching iteration writes its result beside divgd, so the un-iterated divergence stays readable there and
+  // the nord > 0 levels need no copy of it into delpc
+  const bool dd_sep = !(staged_dd || nord_max > DD_NMAX);
   launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
     const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
@@ -970,7 +974,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     const int npx = g.npx, npy = g.npy;
     const unsigned p = IX(i, j);
     if (g.nord[k] != 0) {
-      (delpc + b)[p] = (divgd + b)[p];
+      if (!dd_sep) (delpc + b)[p] = (divgd + b)[p];
       return;
     }
     auto PTC = [&](int ii, int jj) -> Real {
@@ -1000,8 +1004,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   // divergence-damping iteration: divgd -> dnew (levels with nord > 0)
   Real *dnew = divgd;
   {
-    static const bool staged_dd = getenv("FV3_DIVDAMP_STAGED") != nullptr;  // A/B switch for profiling
-    if (staged_dd || nord_max > DD_NMAX) {
+    if (!dd_sep) {
       divdamp_staged(c, s, divgd, uc, vc, nord_max, 0, nz1, nullptr);
     } else if (nord_max > 0) {
       dnew = c->scratch[SC_L];
@@ -1018,7 +1021,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       const int nord = g.nord[k];
       if (nord == 0) return;
       const long b = t * g.st + k * g.sk;
-      const Real dpc = (delpc + b)[p];
+      const Real dpc = dd_sep ? (divgd + b)[p] : (delpc + b)[p];  // the un-iterated divergence
       Real vo = (Real)0;
       if (dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkbv * wkbv);
       const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, dddmp * vo));
