@@ -890,18 +890,23 @@ extern "C" int fv3_pk3_halo(fv3_ctx *c, const fv3_field *pk3_, const fv3_field *
   FV3_FIELD(pk3, pk3_) FV3_FIELD(delp, delp_)
   const Geo g = c->g;
   const Real ptop = (Real)ptopd, akap = (Real)akapd;
-  launch2(c, (fv3_stream_t)stream, Box{-1, g.nx + 2, -1, g.ny + 2, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    if (i >= 1 && i <= g.nx && j >= 1 && j <= g.ny) return;
+  // the two-cell ring around the compute domain only: S / N strips as they lie, W / E strips transposed (lanes along j)
+  // -- a launch over the whole padded plane spends its time on threads that exit (0.49 -> 0.2 ms at C768)
+  auto column = [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
-    const long p = tb + pix;
-    (void)p;
     Real pei = ptop;
     for (int k = 0; k < g.nz; ++k) {
       pei = pei + K_(delp, k);
       K_(pk3, k + 1) = exp(akap * log(pei));
     }
-  });
+  };
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const int nx = g.nx, ny = g.ny;
+  launch2(c, s, Box{-1, nx + 2, -1, 0, 0, 0}, column);
+  launch2(c, s, Box{-1, nx + 2, ny + 1, ny + 2, 0, 0}, column);
+  launch2(c, s, Box{1, ny, 0, 1, 0, 0}, [=] FV3_HD(int t, int a, int b_) { column(t, b_ - 1, a); });
+  launch2(c, s, Box{1, ny, 0, 1, 0, 0}, [=] FV3_HD(int t, int a, int b_) { column(t, nx + 1 + b_, a); });
   return fv3_post(c, (fv3_stream_t)stream, "pk3_halo");
 }
 
