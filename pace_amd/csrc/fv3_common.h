@@ -366,6 +366,63 @@ inline void launch2(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// launch_chain: a CHAIN of dependent stages on up to four small windows in ONE launch.  One workgroup owns one
+// (window, sub-domain, level) and runs the stages one after the other with a workgroup barrier in between -- the
+// stages communicate through global fields, but only inside their own window and level, so nothing else has to
+// be ordered.  Replaces 6-7 launches of a few dozen microseconds each (the cube-corner patches of the marching
+// kernels) by one.  A stage = {natural box, f(t, k, i, j)}; it runs on natural box ∩ window.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct ChainStage {
+  Box nat;
+  F f;
+};
+template <class F>
+inline ChainStage<F> chain_stage(Box nat, F f) {
+  return ChainStage<F>{nat, f};
+}
+#ifndef FV3_HOST_EMU
+template <class... St>
+__global__ void __launch_bounds__(256) fv3_kchain(Wins ws, int k0, int nk, int nplanes, St... st) {
+  const int kz = (int)blockIdx.x;
+  if (kz >= nplanes) return;
+  const int wi = kz % ws.n;
+  const int tk = kz / ws.n;
+  const int t = tk / nk;
+  const int k = k0 + (tk - t * nk);
+  const int tid = (int)threadIdx.x;
+  auto run = [&](const auto &sg) {
+    const Box b = fv3_clip(sg.nat, ws.w[wi]);
+    const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1;
+    if (ni > 0 && nj > 0 && k >= sg.nat.k0 && k <= sg.nat.k1)
+      for (int idx = tid; idx < ni * nj; idx += 256) {
+        const int jj = idx / ni;
+        sg.f(t, k, b.i0 + (idx - jj * ni), b.j0 + jj);
+      }
+    __syncthreads();
+  };
+  (run(st), ...);
+}
+#endif
+template <class... St>
+inline void launch_chain(const fv3_ctx *c, fv3_stream_t s, const Wins &ws, int k0, int k1, St... st) {
+  const int nk = k1 - k0 + 1;
+  if (ws.n <= 0 || nk <= 0) return;
+#ifdef FV3_HOST_EMU
+  auto run = [&](const auto &sg) {
+    Box nat = sg.nat;
+    nat.k0 = std::max(nat.k0, k0);
+    nat.k1 = std::min(nat.k1, k1);
+    launch3w(c, s, nat, ws, sg.f);
+  };
+  (run(st), ...);
+#else
+  const int nplanes = c->g.nsub * nk * ws.n;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kchain<St...>), dim3(nplanes, 1, 1), dim3(256, 1, 1), 0, s, ws, k0, nk, nplanes, st...);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // block-level launch for LDS-tiled kernels: f(blk, smem) runs once per workgroup with
 // blk.tid / blk.nthr / blk.bx,by,bz and a dynamic LDS buffer; phases are separated by blk.sync().
 // Work inside a phase is distributed as `for (w = blk.tid; w < n; w += blk.nthr)`, so the host

@@ -28,8 +28,12 @@ static inline Box clip(Box a, const Box *w) {
 // Stage-per-launch form (global intermediates).  `win` restricts every launch to a window: used
 // for the few tiles next to a cube corner, where the corner-halo remap makes a tile-local
 // evaluation awkward; results are valid 4 cells inside the window.
-static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1,
-                                const Box *win_, const Wins *wins_ = nullptr) {
+// tail: one more stage run after the chain in the same launch (window mode only; the corner patches copy their
+// result into the flux fields there)
+struct NoTail {};
+template <class Tail>
+static void del6_vt_flux_staged_t(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1,
+                                  const Box *win_, const Wins *wins_, Tail tail) {
   Wins ws;
   ws.n = 0;
   if (wins_) ws = *wins_;
@@ -41,15 +45,17 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
   const int nm = dn.nord_max;
   const Deln d = dn;
   // d2 = damp * q on (is-1-nord .. ie+1+nord)^2
-  launch3w(c, s, Box{-nm, g.nx + 1 + nm, -nm, g.ny + 1 + nm, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+  const Box box0{-nm, g.nx + 1 + nm, -nm, g.ny + 1 + nm, k0, k1};
+  auto st0 = [=] FV3_HD(int t, int k, int i, int j) {
     if (!deln_on(d, k)) return;
     const int n = deln_nord(d, k);
     if (i < -n || i > g.nx + 1 + n || j < -n || j > g.ny + 1 + n) return;
     const long p = t * g.st + k * g.sk + IX(i, j);
     d2[p] = q_raw ? q[p] : deln_damp(d, k) * q[p];
-  });
+  };
   // first fluxes (copy_corners only when nord > 0)
-  launch3w(c, s, Box{1 - nm, g.nx + nm + 1, 1 - nm, g.ny + nm + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+  const Box box1{1 - nm, g.nx + nm + 1, 1 - nm, g.ny + nm + 1, k0, k1};
+  auto st1 = [=] FV3_HD(int t, int k, int i, int j) {
     if (!deln_on(d, k)) return;
     const int n = deln_nord(d, k);
     const int fl = g.flags[t];
@@ -66,9 +72,10 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
       const Real e = n > 0 ? cc<2>(dd, g, fl, i, j) : dd[IX(i, j)];
       (fy2 + b)[IX(i, j)] = (g.del6_u + m2)[IX(i, j)] * (a - e);
     }
-  });
-  for (int n = 1; n <= nm; ++n) {
-    launch3w(c, s, Box{-(nm - n), g.nx + 1 + (nm - n), -(nm - n), g.ny + 1 + (nm - n), k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+  };
+  auto boxA = [=](int n) { return Box{-(nm - n), g.nx + 1 + (nm - n), -(nm - n), g.ny + 1 + (nm - n), k0, k1}; };
+  auto mkA = [=](int n) {
+    return [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(d, k)) return;
       const int nord = deln_nord(d, k);
       if (n > nord) return;
@@ -77,8 +84,11 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
       const long b = t * g.st + k * g.sk;
       const unsigned p = IX(i, j);
       (d2 + b)[p] = ((fx2 + b)[p] - (fx2 + b)[IX(i + 1, j)] + (fy2 + b)[p] - (fy2 + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + p];
-    });
-    launch3w(c, s, Box{1 - (nm - n), g.nx + (nm - n) + 1, 1 - (nm - n), g.ny + (nm - n) + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+    };
+  };
+  auto boxB = [=](int n) { return Box{1 - (nm - n), g.nx + (nm - n) + 1, 1 - (nm - n), g.ny + (nm - n) + 1, k0, k1}; };
+  auto mkB = [=](int n) {
+    return [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(d, k)) return;
       const int nord = deln_nord(d, k);
       if (n > nord) return;
@@ -91,8 +101,27 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
         (fx2 + b)[IX(i, j)] = (g.del6_v + m2)[IX(i, j)] * (cc<1>(dd, g, fl, i, j) - cc<1>(dd, g, fl, i - 1, j));
       if (i >= 1 - nt && i <= g.nx + nt && j >= 1 - nt && j <= g.ny + nt + 1)
         (fy2 + b)[IX(i, j)] = (g.del6_u + m2)[IX(i, j)] * (cc<2>(dd, g, fl, i, j) - cc<2>(dd, g, fl, i, j - 1));
-    });
+    };
+  };
+  if constexpr (!std::is_same<Tail, NoTail>::value) {
+    // window mode with a tail: the whole chain (orders up to 2) and the tail in one launch
+    if (ws.n > 0 && nm <= 2) {
+      launch_chain(c, s, ws, k0, k1, chain_stage(box0, st0), chain_stage(box1, st1), chain_stage(boxA(1), mkA(1)), chain_stage(boxB(1), mkB(1)),
+                   chain_stage(boxA(2), mkA(2)), chain_stage(boxB(2), mkB(2)), tail);
+      return;
+    }
   }
+  launch3w(c, s, box0, ws, st0);
+  launch3w(c, s, box1, ws, st1);
+  for (int n = 1; n <= nm; ++n) {
+    launch3w(c, s, boxA(n), ws, mkA(n));
+    launch3w(c, s, boxB(n), ws, mkB(n));
+  }
+  if constexpr (!std::is_same<Tail, NoTail>::value) launch3w(c, s, tail.nat, ws, tail.f);
+}
+static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1,
+                                const Box *win_, const Wins *wins_ = nullptr) {
+  del6_vt_flux_staged_t(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1, win_, wins_, NoTail{});
 }
 
 
@@ -138,10 +167,10 @@ static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
   }
   if (wins.n == 0) return;
   auto run = [&](const Wins &ws, const Wins &ps, const int *nd) {
-    del6_vt_flux_staged(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, nullptr, &ws);
     Wins psc = ps;
     int n0 = nd[0], n1 = ps.n > 1 ? nd[1] : 0, n2 = ps.n > 2 ? nd[2] : 0, n3 = ps.n > 3 ? nd[3] : 0;
-    launch3w(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, ps, [=] FV3_HD(int t, int k, int i, int j) {
+    // (the copy of the patch into the flux fields is the last stage of the same launch; it tests patch membership itself)
+    auto copy_patch = [=] FV3_HD(int t, int k, int i, int j) {
       if (!deln_on(dd, k) || deln_nord(dd, k) == 0) return;
       // which corner's patch is this point in (patches handled together are disjoint)
       int need = 0;
@@ -152,7 +181,8 @@ static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
       const long p = t * g.st + k * g.sk + IX(i, j);
       if (j <= g.ny) fx2[p] = tfx[p];
       if (i <= g.nx) fy2[p] = tfy[p];
-    });
+    };
+    del6_vt_flux_staged_t(c, s, q, d2, tfx, tfy, dn, q_raw, k0, k1, nullptr, &ws, chain_stage(Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, copy_patch));
   };
   if (fv3_wins_disjoint(wins)) {
     run(wins, patches, needs);  // one set of launches for all corners
