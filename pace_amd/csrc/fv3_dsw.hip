@@ -494,16 +494,20 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
 // the reference); `win` restricts every launch to a window (results exact >= 4 points inside an
 // artificial window boundary) -- used for the cube-corner patches of the marching form.
 // ---------------------------------------------------------------------------------------------
-static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Wins *wins_) {
+struct DdNone {};
+// head / tail: extra stages run before / after the iteration in the same launch (window mode: the corner patches
+// copy their window in and their result out there)
+template <class Head, class Tail>
+static void divdamp_staged_t(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Wins *wins_, Head head, Tail tail) {
   const Geo g = c->g;
   Wins ws;
   ws.n = 0;
   if (wins_) ws = *wins_;
   const int nz1 = k1;
-  for (int n = 1; n <= nord_max; ++n) {
-    const int ntm = nord_max - n;
-    // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
-    launch3w(c, s, Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, k0, nz1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+  // vc = d(divg)/dx * divg_u ; uc = d(divg)/dy * divg_v   (fill_corners via remapped reads when nt != 0)
+  auto boxA = [=](int n) { const int ntm = nord_max - n; return Box{1 - 1 - ntm, g.nx + 1 + ntm, 1 - 1 - ntm, g.ny + 1 + ntm, k0, nz1}; };
+  auto mkA = [=](int n) {
+    return [=] FV3_HD(int t, int k, int i, int j) {
       const int nord = g.nord[k];
       if (n > nord) return;
       const int nt = nord - n;
@@ -521,8 +525,11 @@ static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Re
         const Real e = fill ? dg[bc_index<2>(g, fl, i, j)] : dg[IX(i, j)];
         (uc + b)[IX(i, j)] = (a - e) * (g.divg_v + m2)[IX(i, j)];
       }
-    });
-    launch3w(c, s, Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, k0, nz1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+    };
+  };
+  auto boxB = [=](int n) { const int ntm = nord_max - n; return Box{1 - ntm, g.nx + 1 + ntm, 1 - ntm, g.ny + 1 + ntm, k0, nz1}; };
+  auto mkB = [=](int n) {
+    return [=] FV3_HD(int t, int k, int i, int j) {
       const int nord = g.nord[k];
       if (n > nord) return;
       const int nt = nord - n;
@@ -541,8 +548,24 @@ static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Re
       if (E && N && i == npx && j == npy) d += UCR(npx, npy);
       if (W && N && i == 1 && j == npy) d += UCR(1, npy);
       (divgd + b)[IX(i, j)] = d * (g.rarea_c + m2)[IX(i, j)];
-    });
+    };
+  };
+  if constexpr (!std::is_same<Head, DdNone>::value) {
+    if (ws.n > 0 && nord_max <= 3) {
+      launch_chain(c, s, ws, k0, k1, head, chain_stage(boxA(1), mkA(1)), chain_stage(boxB(1), mkB(1)), chain_stage(boxA(2), mkA(2)), chain_stage(boxB(2), mkB(2)),
+                   chain_stage(boxA(3), mkA(3)), chain_stage(boxB(3), mkB(3)), tail);
+      return;
+    }
+    launch3w(c, s, head.nat, ws, head.f);
   }
+  for (int n = 1; n <= nord_max; ++n) {
+    launch3w(c, s, boxA(n), ws, mkA(n));
+    launch3w(c, s, boxB(n), ws, mkB(n));
+  }
+  if constexpr (!std::is_same<Tail, DdNone>::value) launch3w(c, s, tail.nat, ws, tail.f);
+}
+static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Real *vc, int nord_max, int k0, int k1, const Wins *wins_) {
+  divdamp_staged_t(c, s, divgd, uc, vc, nord_max, k0, k1, wins_, DdNone{}, DdNone{});
 }
 
 // Marching form (see fv3_tp2d.hip).  A wave owns 58 corner columns and walks j; iteration n runs
@@ -702,15 +725,15 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
   }
   if (wins.n == 0) return;
   auto run = [&](const Wins &ws, const Wins &ps, const int *nd) {
-    // private copy of the windows (the staged form works in place)
-    launch3w(c, s, Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, ws, [=] FV3_HD(int t, int k, int i, int j) {
+    // private copy of the windows (the staged form works in place), the iteration and the copy of the patches into
+    // the result: one chained launch
+    auto copy_in = [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       tmp[p] = divgd[p];
-    });
-    divdamp_staged(c, s, tmp, uc, vc, nord_max, k0, k1, &ws);
+    };
     Wins psc = ps;
     int n0 = nd[0], n1 = ps.n > 1 ? nd[1] : 0, n2 = ps.n > 2 ? nd[2] : 0, n3 = ps.n > 3 ? nd[3] : 0;
-    launch3w(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, ps, [=] FV3_HD(int t, int k, int i, int j) {
+    auto copy_out = [=] FV3_HD(int t, int k, int i, int j) {
       if (nk_[k] == 0) return;
       int need = 0;
       const int nn[4] = {n0, n1, n2, n3};
@@ -719,7 +742,9 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
       if (need == 0 || (g.flags[t] & need) != need) return;
       const long p = t * g.st + k * g.sk + IX(i, j);
       out[p] = tmp[p];
-    });
+    };
+    divdamp_staged_t(c, s, tmp, uc, vc, nord_max, k0, k1, &ws, chain_stage(Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, copy_in),
+                     chain_stage(Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, copy_out));
   };
   if (fv3_wins_disjoint(wins)) {
     run(wins, patches, needs);
