@@ -82,28 +82,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
 
   // (A) contravariant A-grid winds on is-2..ie+2
   const int nkc = (nz1 + FV3_KC) / FV3_KC;  // level chunks of the kernels that walk FV3_KC levels per thread
-  launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
-    const int fl = g.flags[t];
-    const long m2 = t * g.st2;
-    const unsigned p = IX(i, j);
-    const Real cs = (g.cosa_s + m2)[p], rs2 = (g.rsin2 + m2)[p];
-#pragma unroll 1
-    for (int kk = 0; kk < FV3_KC; ++kk) {
-      const int k = FV3_KC * kp + kk;
-      if (k > nz1) break;
-      const long b = t * g.st + k * g.sk;
-      D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
-      const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
-      (ua + b)[p] = (ut_ - vt_ * cs) * rs2;
-      (va + b)[p] = (vt_ - ut_ * cs) * rs2;
-    }
-  });
-
-  // (B) C-grid winds + contravariant ut, vt (already scaled: dt2 * ut * dy * sin_sg)
-  // The generic per-point form does 32 u / v loads per point and is bound by them (halving them in a timing
-  // experiment took 2.5 ms off c_sw).  Points whose whole stencil uses the interior formulas are therefore done by
-  // a lean kernel in which a thread owns TWO rows and shares the utmp / vtmp rows between them (20 loads per point);
-  // the generic form then only runs on four windows along the sub-domain boundary (and skips the interior).
+  // Where stage B's two-row interior kernel runs (below) it also produces ua / va -- it holds utmp(i, j) and vtmp(i, j)
+  // of its points anyway -- so this per-point form then only covers the boundary windows and the outer ring.
   const bool b_split = g.nx >= 16 && g.ny >= 16 && !getenv("FV3_CSW_B_GENERIC");
   // interior rectangle of sub-domain t: columns [i_lo, i_hi], rows [j_lo, j_lo + 2 * n_pairs - 1]
   struct BRect {
@@ -118,6 +98,42 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     r.n_pairs = (j_hi - r.j_lo + 1) / 2;
     return r;
   };
+  auto stage_a = [=] FV3_HD(int t, int kp, int i, int j) {
+    const int fl = g.flags[t];
+    if (b_split) {
+      const BRect rc = b_rect(fl);
+      if (i >= rc.i_lo && i <= rc.i_hi && j >= rc.j_lo && j < rc.j_lo + 2 * rc.n_pairs) return;  // done by the two-row kernel
+    }
+    const long m2 = t * g.st2;
+    const unsigned p = IX(i, j);
+    const Real cs = (g.cosa_s + m2)[p], rs2 = (g.rsin2 + m2)[p];
+#pragma unroll 1
+    for (int kk = 0; kk < FV3_KC; ++kk) {
+      const int k = FV3_KC * kp + kk;
+      if (k > nz1) break;
+      const long b = t * g.st + k * g.sk;
+      D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
+      const Real ut_ = d.utmp0(i, j), vt_ = d.vtmp0(i, j);
+      (ua + b)[p] = (ut_ - vt_ * cs) * rs2;
+      (va + b)[p] = (vt_ - ut_ * cs) * rs2;
+    }
+  };
+  if (b_split) {
+    // W / E windows transposed (lanes along j), then S / N
+    const int e0 = g.nx - 3;
+    launch3(c, s, Box{-1, g.ny + 2, 0, 6, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_a(t, kp, b_ - 1, a); });
+    launch3(c, s, Box{-1, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_a(t, kp, e0 + b_, a); });
+    launch3(c, s, Box{6, g.nx - 4, -1, 5, 0, nkc - 1}, stage_a);
+    launch3(c, s, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, nkc - 1}, stage_a);
+  } else {
+    launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nkc - 1}, stage_a);
+  }
+
+  // (B) C-grid winds + contravariant ut, vt (already scaled: dt2 * ut * dy * sin_sg)
+  // The generic per-point form does 32 u / v loads per point and is bound by them (halving them in a timing
+  // experiment took 2.5 ms off c_sw).  Points whose whole stencil uses the interior formulas are therefore done by
+  // a lean kernel in which a thread owns TWO rows and shares the utmp / vtmp rows between them (20 loads per point);
+  // the generic form then only runs on four windows along the sub-domain boundary (and skips the interior).
   if (b_split) {
     launch3(c, s, Box{0, g.nx + 1, 0, (g.ny + 2) / 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int jp) {
       const BRect rc = b_rect(g.flags[t]);
@@ -126,7 +142,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       int i = i_, j = rc.j_lo + 2 * jp;
       const int j_base = j;
       // metric terms of the two points, shared by the levels of the chunk
-      Real mcu[2], mru[2], mdy[2], ms3[2], ms1[2], mcv[2], mrv[2], mdx[2], ms4[2], ms2[2];
+      Real mcu[2], mru[2], mdy[2], ms3[2], ms1[2], mcv[2], mrv[2], mdx[2], ms4[2], ms2[2], mcs[2], mr2[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const unsigned q = IX(i, j + r);
@@ -140,6 +156,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         mdx[r] = (g.dx + m2)[q];
         ms4[r] = (g.sin_sg4 + m2)[IX(i, j + r - 1)];
         ms2[r] = (g.sin_sg2 + m2)[q];
+        mcs[r] = (g.cosa_s + m2)[q];
+        mr2[r] = (g.rsin2 + m2)[q];
       }
 #pragma unroll 1
       for (int kk = 0; kk < FV3_KC; ++kk) {
@@ -177,6 +195,11 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const unsigned p = IX(i, j + r);
+          {  // stage A's ua / va of the point: utmp(i, j) and vtmp(i, j) are at hand
+            const Real ut0 = ut_[2][r], vt0 = vt_[2 + r];
+            (ua + b)[p] = (ut0 - vt0 * mcs[r]) * mr2[r];
+            (va + b)[p] = (vt0 - ut0 * mcs[r]) * mr2[r];
+          }
           const Real ucv = CSW_A2 * (ut_[0][r] + ut_[3][r]) + CSW_A1 * (ut_[1][r] + ut_[2][r]);
           const Real utv = (ucv - vc0[r] * mcu[r]) * mru[r];
           (uc + b)[p] = ucv;
