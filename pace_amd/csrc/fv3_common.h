@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(W
 // of the 4- and 8-GPU runs, where the tail of the launch matters more).  16 / 32-row segments were 1-7 %
 // slower than 64 at every size measured on MI355X, 128 equal to 64.
 inline int fv3_pick_seg(long waves_at_64, int wpe) {
-  static const char *e = getenv("FV3_SEG");
-  if (e) return atoi(e);
+  const char *e = getenv("FV3_SEG");  // (read per launch: the production-shape parity tests force 96 on small level counts)
+  if (e && atoi(e) > 0) return atoi(e);
   const long slots = 256L * 4 * wpe;
   return waves_at_64 * 2 / 3 >= 8 * slots ? 96 : 64;
 }

@@ -268,7 +268,9 @@ class AcousticDynamics:
             delpc, ptc = self.cgrid_shallow_water_lagrangian_dynamics(
                 state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._ut, self._vt, self._divgd, state.omga, dt2
             )
-            self._checkpoint("C_SW-Out", delpd=state.delp, ptd=state.pt, ucd=state.uc, vcd=state.vc, uad=state.ua, vad=state.va, utd=self._ut, vtd=self._vt, divgdd=self._divgd)
+            # (omgad / delpcd / ptcd: beyond the reference's variable list -- the remaining c_sw outputs, for single-rank oracle spot checks)
+            self._checkpoint("C_SW-Out", delpd=state.delp, ptd=state.pt, ucd=state.uc, vcd=state.vc, uad=state.ua, vad=state.va, utd=self._ut, vtd=self._vt, divgdd=self._divgd,
+                             omgad=state.omga, delpcd=delpc, ptcd=ptc)
             if cfg.nord > 0:
                 up["divgd"].start()
             if it == 0:
@@ -283,13 +285,16 @@ class AcousticDynamics:
             if cfg.nord > 0:
                 up["divgd"].wait()
             up["uc__vc"].wait()
-            self._checkpoint("D_SW-In", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, zhd=self._zh, divgdd=self._divgd)
+            # (q_cond .. heat_sourced: beyond the reference's variable list -- the remaining d_sw inputs / outputs)
+            self._checkpoint("D_SW-In", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, zhd=self._zh, divgdd=self._divgd,
+                             q_cond=state.q_con, mfxd=state.mfxd, mfyd=state.mfyd, cxd=state.cxd, cyd=state.cyd, heat_sourced=self._heat_source)
             self.dgrid_shallow_water_lagrangian_dynamics(
                 self._vt_scratch, state.delp, state.pt, state.u, state.v, state.w, state.uc, state.vc, state.ua, state.va, self._divgd,
                 state.mfxd, state.mfyd, state.cxd, state.cyd, self._crx, self._cry, self._xfx, self._yfx, state.q_con, self._zh,
                 self._heat_source, state.diss_estd, dt,
             )  # fmt: skip
-            self._checkpoint("D_SW-Out", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, divgdd=self._divgd, mfxd=state.mfxd, mfyd=state.mfyd, xfxd=self._xfx, yfxd=self._yfx)
+            self._checkpoint("D_SW-Out", ucd=state.uc, vcd=state.vc, wd=state.w, delpcd=self._vt_scratch, delpd=state.delp, ud=state.u, vd=state.v, ptd=state.pt, uad=state.ua, vad=state.va, divgdd=self._divgd, mfxd=state.mfxd, mfyd=state.mfyd, xfxd=self._xfx, yfxd=self._yfx,
+                             q_cond=state.q_con, cxd=state.cxd, cyd=state.cyd, crxd=self._crx, cryd=self._cry, heat_sourced=self._heat_source)
             up["delp__pt__q_con"].update()
             self.update_height_on_d_grid(self._zs, self._zh, self._crx, self._cry, self._xfx, self._yfx, self._wsd, dt)
             self.vertical_solver(remap_step, dt, state.cappa, self._ptop, self._zs, self._wsd, state.delz, state.q_con, state.delp, state.pt, self._zh, state.pe, self._pkc, self._pk3, state.pk, state.peln, state.w)

@@ -1,0 +1,186 @@
+"""BASELINE.json configurations on the MI355X, each against the oracle (or, where the full-size oracle is out of reach,
+against a single-rank oracle spot check + size-independent properties).
+
+  cfg-2  C192 L79 fp64, 6 tiles on one GPU (the per-GPU content of the 6-GPU run; RCCL itself needs > 1 device):
+         full acoustic call, global air-mass conservation, c_sw and d_sw of tile 0 vs the oracle at all 79 levels
+  cfg-3  C768 L79 fp64 layout 2x2: the PRODUCTION KERNEL SHAPE -- 24 sub-domains of 384^2 in one context, 7 strips x 4 row
+         segments of 96 rows per marching wave (what fv3_pick_seg selects for the bench), transposed W / E windows, 384^2
+         corner patches -- full acoustic call vs the oracle on a reduced level count (the oracle needs ~4 s per 1e6 cells)
+  cfg-4  C768 L127 fp32: one acoustic call at full size (finite, bounds, mass conservation at fp32 round-off) and the fp32
+         build vs the fp64 ORACLE at C96 L127 including w and delz
+The level-count reductions are stated per test; horizontal shapes, layouts and kernel launch shapes are the configs' own.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import compare_cubes, oracle_cube, run_device_cube
+from pace_amd.constants import get_constants
+
+from fv3_oracle import c_sw as o_csw
+from fv3_oracle import d_sw as o_dsw
+from fv3_oracle.util import Dom
+
+gpu = pytest.mark.gpu
+
+STATE = "u v w ua va delp delz pt pe pk peln q_con omga mfxd mfyd cxd cyd".split()
+TOL = {"default": 1e-12, "w": 1e-10, "omga": 1e-10, "delz": 1e-11, "u": 1e-11, "v": 1e-11}
+
+
+@gpu
+def test_c768_layout_2x2_production_kernel_shape_vs_oracle(gpu_backend, monkeypatch):
+    """cfg-3 shape: 24 x 384^2 sub-domains, 96-row march segments forced (FV3_SEG is what fv3_pick_seg returns at L79),
+    nz = 4 (the three sponge levels + one regular level), one acoustic sub-step with the headline dt (225 / 2 / 6 s)."""
+    monkeypatch.setenv("FV3_SEG", "96")
+    nz = 4
+    part, cfg, grids, ost, phis, odyn = oracle_cube(768, (2, 2), nz, dict(n_split=1))
+    assert part.total_ranks == 24 and part.nx == 384
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 18.75, 1)
+    got, *_ = run_device_cube(gpu_backend, part, cfg, grids, init, phis, 18.75)
+    worst = compare_cubes(got, ost, part, nz, STATE, TOL)
+    print("C768 2x2 production shape, worst field-relative errors:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@gpu
+def test_c768_segment_choice_is_bitwise_neutral(gpu_backend, monkeypatch):
+    """64- and 96-row march segments give bitwise equal states on the 384^2 sub-domains (the segment length only moves
+    the warm-up rows of a wave, never the arithmetic of an owned row)."""
+    nz = 3
+    part, cfg, grids, ost, phis, _ = oracle_cube(768, (2, 2), nz, dict(n_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for seg in ("64", "96"):
+        monkeypatch.setenv("FV3_SEG", seg)
+        res[seg], *_ = run_device_cube(gpu_backend, part, cfg, grids, init, phis, 18.75)
+    for r in range(part.total_ranks):
+        for n in STATE:
+            assert np.array_equal(res["64"][r][n], res["96"][r][n]), f"{n} rank {r}"
+
+
+class _Capture:
+    """Checkpointer that keeps the first occurrence of each savepoint for one sub-domain as host arrays."""
+
+    def __init__(self, sub=0):
+        self.sub = sub
+        self.data = {}
+
+    def __call__(self, name, **kw):
+        if name not in self.data:
+            self.data[name] = {k: q.numpy(self.sub) for k, q in kw.items()}
+
+
+@gpu
+def test_c192_l79_six_tiles_one_gpu(gpu_backend):
+    """cfg-2 (C192 L79, 6 tiles; dt_atmos 200 s as in the reference yaml, k_split / n_split reduced from 7 / 8 to 1 / 2):
+    air mass is conserved to round-off over the acoustic call and tile 0's c_sw / d_sw match the oracle at all 79 levels."""
+    _conservation_and_tile0_spot_check(gpu_backend, 192, 79)
+
+
+def test_spot_check_machinery_on_the_host_emulation(hostemu):
+    """The same check at C12 L8 on the host-emulation build (runs in the GPU-less container)."""
+    _conservation_and_tile0_spot_check("hostemu", 12, 8)
+
+
+def _conservation_and_tile0_spot_check(backend, nx, nz):
+    from pace_amd.harness import DycoreHarness
+
+    h = DycoreHarness(nx, nz=nz, layout=(1, 1), dt_atmos=200.0, k_split=1, n_split=2, backend=backend)
+    area = h.sf.grid_fields["area"].storage  # [n_sub, nj, ni]
+    nh = 3
+
+    def mass():
+        d = h.state.delp.storage[:, :nz, nh : nh + nx, nh : nh + nx].double()
+        return float((d * area[:, None, nh : nh + nx, nh : nh + nx].double()).sum().item())
+
+    m0 = mass()
+    cap = _Capture(0)
+    h.dyn.checkpointer = cap  # -> the Python twin of the sequencer (bitwise = fv3_acoustic_step, test_parity)
+    h.step()
+    h.synchronize()
+    m1 = mass()
+    assert abs(m1 - m0) <= 1e-13 * abs(m0), f"air mass drifted by {(m1 - m0) / m0:.2e}"
+    san = h.sanity()
+    assert all(v[2] for v in san.values()), san
+    # ---- tile 0, first sub-step: c_sw and d_sw against the oracle on the device's own inputs
+    D = Dom(h.grids[0], get_constants())
+    V = lambda a: a[:, :, :nz].copy()  # noqa: E731
+    dt = 200.0 / 2
+    ci, co = cap.data["C_SW-In"], cap.data["C_SW-Out"]
+    z = lambda: np.zeros_like(V(ci["ud"]))  # noqa: E731
+    o = dict(uc=z(), vc=z(), ua=z(), va=z(), ut=z(), vt=z(), divgd=z(), omga=z())
+    delpc, ptc = o_csw.c_sw(D, V(ci["delpd"]), V(ci["ptd"]), V(ci["ud"]), V(ci["vd"]), V(ci["wd"]), o["uc"], o["vc"], o["ua"], o["va"], o["ut"], o["vt"], o["divgd"], o["omga"], 0.5 * dt,
+                            nord=h.cfg.nord)
+    C1 = D.sl(1, D.nx, 1, D.ny)
+
+    def rel(a, b, R):
+        return float(np.abs(V(a)[R] - b[R]).max() / np.abs(b[R]).max())
+
+    errs = {
+        "delpc": rel(co["delpcd"], delpc, C1), "ptc": rel(co["ptcd"], ptc, C1), "omga": rel(co["omgad"], o["omga"], C1),
+        "uc": rel(co["ucd"], o["uc"], D.sl(1, D.nx + 1, 1, D.ny)), "vc": rel(co["vcd"], o["vc"], D.sl(1, D.nx, 1, D.ny + 1)),
+        "divgd": rel(co["divgdd"], o["divgd"], D.sl(1, D.nx + 1, 1, D.ny + 1)), "ut": rel(co["utd"], o["ut"], D.sl(1, D.nx + 1, 1, D.ny)),
+    }
+    assert max(errs.values()) < 1e-12, errs
+    di, do = cap.data["D_SW-In"], cap.data["D_SW-Out"]
+    x = {k: V(v) for k, v in di.items()}
+    col = o_dsw.get_column_namelist(h.cfg, nz)
+    w = dict(crx=z(), cry=z(), xfx=z(), yfx=z(), diss=z())
+    o_dsw.d_sw(D, h.cfg, col, x["delpcd"], x["delpd"], x["ptd"], x["ud"], x["vd"], x["wd"], x["ucd"], x["vcd"], x["uad"], x["vad"], x["divgdd"], x["mfxd"], x["mfyd"], x["cxd"], x["cyd"],
+               w["crx"], w["cry"], w["xfx"], w["yfx"], x["q_cond"], None, x["heat_sourced"], w["diss"], dt)
+    errs = {
+        "delp": rel(do["delpd"], x["delpd"], C1), "pt": rel(do["ptd"], x["ptd"], C1), "w": rel(do["wd"], x["wd"], C1), "q_con": rel(do["q_cond"], x["q_cond"], C1),
+        "u": rel(do["ud"], x["ud"], D.sl(1, D.nx, 1, D.ny + 1)), "v": rel(do["vd"], x["vd"], D.sl(1, D.nx + 1, 1, D.ny)),
+        "mfx": rel(do["mfxd"], x["mfxd"], D.sl(1, D.nx + 1, 1, D.ny)), "mfy": rel(do["mfyd"], x["mfyd"], D.sl(1, D.nx, 1, D.ny + 1)),
+        "xfx": rel(do["xfxd"], w["xfx"], D.sl(1, D.nx + 1, 1, D.ny)), "crx": rel(do["crxd"], w["crx"], D.sl(1, D.nx + 1, 1, D.ny)),
+        "heat_source": rel(do["heat_sourced"], x["heat_sourced"], C1),
+    }
+    assert max(errs.values()) < 1e-11, errs
+    print(f"C{nx} L{nz} tile-0 spot check:", {k: f"{v:.1e}" for k, v in errs.items()})
+
+
+# fp32 build against the fp64 oracle: field-scale relative.  fp32 has eps = 6e-8; one acoustic sub-step amplifies it through
+# differences of O(1e5 Pa) pressures and O(1e4 m) heights -- measured 3e-7 (delp) .. 2e-4 (w); bounds = measured x ~5.
+TOL32 = {"default": 1e-5, "delp": 2e-6, "pt": 2e-6, "u": 1e-4, "v": 1e-4, "w": 2e-3, "delz": 2e-5, "ua": 1e-4, "va": 1e-4, "omga": 5e-3, "q_con": 1e-4}
+
+
+@gpu
+def test_fp32_build_vs_fp64_oracle_c96_l127(gpu_backend):
+    """cfg-4 precision: libfv3_mi355x_f32 (PACE_FLOAT_PRECISION=32) against the fp64 ORACLE (not against the fp64 HIP build) at
+    L127, one acoustic sub-step at C96, w and delz included."""
+    nz = 127
+    part, cfg, grids, ost, phis, odyn = oracle_cube(96, (1, 1), nz, dict(n_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    odyn(ost, 18.75, 1)
+    got, *_ = run_device_cube(gpu_backend, part, cfg, grids, init, phis, 18.75, dtype=torch.float32)
+    worst = compare_cubes(got, ost, part, nz, ["u", "v", "w", "ua", "va", "delp", "delz", "pt", "q_con", "omga"], TOL32)
+    print("fp32 vs fp64 oracle, C96 L127:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@gpu
+def test_c768_l127_fp32_one_call(gpu_backend):
+    """cfg-4 size: C768 L127 fp32, 24 sub-domains of 384^2 on one GPU, one acoustic call of 2 sub-steps: finite, inside the
+    SafetyChecker-style bounds [REF driver/pace/driver/driver.py:557-560], air mass conserved to fp32 round-off."""
+    from pace_amd.harness import DycoreHarness
+
+    nz = 127
+    h = DycoreHarness(768, nz=nz, layout=(2, 2), dt_atmos=225.0, k_split=6, n_split=2, backend=gpu_backend, dtype=torch.float32)
+    area = h.sf.grid_fields["area"].storage
+    nh, nx = 3, 384
+
+    def mass():
+        tot = 0.0
+        for t in range(24):  # per sub-domain in fp64 (a 24 x 127 x 384^2 fp64 temporary would be 3.6 GB)
+            d = h.state.delp.storage[t, :nz, nh : nh + nx, nh : nh + nx].double()
+            tot += float((d * area[t, None, nh : nh + nx, nh : nh + nx].double()).sum().item())
+        return tot
+
+    m0 = mass()
+    h.dyn(h.state, 225.0 / 6, n_map=1)
+    h.synchronize()
+    m1 = mass()
+    san = h.sanity()
+    assert all(v[2] for v in san.values()), san
+    assert 0.0 < san["delp"][0] and san["delp"][1] < 1.0e5 and 100.0 < san["pt"][0] and san["pt"][1] < 5000.0, san
+    assert max(abs(san["u"][0]), abs(san["u"][1]), abs(san["v"][0]), abs(san["v"][1])) < 200.0 and max(abs(san["w"][0]), abs(san["w"][1])) < 50.0, san
+    assert abs(m1 - m0) <= 2e-6 * abs(m0), f"air mass drifted by {(m1 - m0) / m0:.2e} (fp32)"
