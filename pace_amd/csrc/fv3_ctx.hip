@@ -263,6 +263,15 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
       d6_w[k] = (Real)std::pow(c->damp_w_h[k] * grid->da_min_c, (double)(c->nord_w_h[k] + 1));
       d6_vt[k] = (Real)std::pow(c->damp_vt_h[k] * grid->da_min_c, (double)(c->nord_v_h[k] + 1));
       dd8[k] = (Real)std::pow(grid->da_min_c * cfg->d4_bg, (double)(c->nord_h[k] + 1));
+      // the tables are formed in double and stored as Real: in the fp32 build (da_min_c * d4_bg)^(nord + 1) leaves the
+      // float range on coarse grids (C48 and coarser: ~(6e9)^4) -- refuse instead of producing NaN states later
+      if (!std::isfinite((double)tp_vt[k]) || !std::isfinite((double)tp_t[k]) || !std::isfinite((double)d6_w[k]) || !std::isfinite((double)d6_vt[k]) ||
+          !std::isfinite((double)dd8[k])) {
+        fv3_ctx_destroy(c);
+        return fv3_fail(nullptr, FV3_ERR_UNSUPPORTED,
+                        "a damping coefficient (damp * da_min)^(nord + 1) overflows this build's floating-point type (fp32 build on a coarse grid): use the fp64 build or a "
+                        "lower damping order");
+      }
     }
     c->tab.tp_vt = upload(c, tp_vt);
     c->tab.tp_t = upload(c, tp_t);

@@ -797,73 +797,104 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   Deln dn_vt{g.nord_v, tab.tp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-4, nord_max_v};
   Deln dn_w{g.nord_w, tab.d6_w, g.damp_w, 0, (Real)0, false, (Real)1.0e-5, nord_max_w};
   Deln dn_t{g.nord_t, tab.tp_t, g.damp_t, 0, (Real)0, false, (Real)1.0e-4, nord_max_t};
-  fv3_signal(c, s, 0);
-  fv3_wait(c, s2, 0);
-  del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
-  fv3_signal(c, s2, 1);
-  // (w's damping fluxes get their own pair: the kernel that applies them runs after the transports)
-  Real *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
-  del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
-  fv3_signal(c, s2, 2);
-
-  fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
-
-  // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
-  //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
-  Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
-  {
-    // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
-    const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+  // FV3_DSW_SCALARS=separate: the four transports as four launches + the division kernel (round-1 form, A/B reference)
+  const char *sc_env = getenv("FV3_DSW_SCALARS");  // (read per call: the A/B parity test flips it in one process)
+  const bool fused_scalars = !(sc_env && !strcmp(sc_env, "separate")) && nord_max_v <= 2 && nord_max_t <= 2 && nord_max_w <= 2;
+  if (fused_scalars) {
+    // ---- air mass, vertical velocity, condensate, potential temperature: the four del-n chains (bandwidth-bound, the
+    //      fields themselves are their only input) first, fxadv beside them, then ONE march for the four transports, the
+    //      divisions by the new air mass and w's damping increment / heat (fv3_tp4.hip).  The march reads the old
+    //      fields through its halo columns / rows while it produces the new ones, so it writes beside them.
+    Real *dQ_x = c->scratch[SC_C], *dQ_y = c->scratch[SC_D], *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
+    Real *n_dp = c->scratch[SC_N], *n_w = c->scratch[SC_O], *n_qc = c->scratch[SC_P], *n_pt = c->scratch[SC_Q];
+    fv3_signal(c, s, 0);
+    fv3_wait(c, s2, 0);
+    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
+    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
+    del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, nz1);
+    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
+    fv3_signal(c, s2, 1);
+    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s, 1);
-    tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
-    fv3_signal(c, s, 5);
-  }
-  fv3_wait(c, s2, 5);
-  del6_vt_flux(c, s2, q_con, d2w, dA_x, dA_y, dn_t, true, 0, nz1);
-  fv3_signal(c, s2, 3);
+    DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
+                  cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt};
+    dsw_scalars_stream(c, s, q4);
+    launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      delp[p] = n_dp[p];
+      pt[p] = n_pt[p];
+      w[p] = n_w[p];
+      q_con[p] = n_qc[p];
+    });
+  } else {
+  fv3_signal(c, s, 0);
+    fv3_wait(c, s2, 0);
+    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
+    fv3_signal(c, s2, 1);
+    // (w's damping fluxes get their own pair: the kernel that applies them runs after the transports)
+    Real *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
+    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
+    fv3_signal(c, s2, 2);
 
-  // ---- vertical velocity: transport with the mass fluxes; its del-n damping increment dw and the heat it
-  //      dissipates are formed by the post-transport kernel below straight from the damping fluxes (the old w is
-  //      still in place there), so neither a dw field nor a separate pass over the fluxes exists
-  fv3_wait(c, s, 2);
-  fv3_signal(c, s, 6);
-  fv3_wait(c, s2, 6);
-  del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
-  fv3_signal(c, s2, 4);
-  {
-    const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr};  // delp * w + div
-    tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
-  }
-  // ---- condensate
-  {
-    const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
-    fv3_wait(c, s, 3);
-    tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
-  }
-  // ---- potential temperature, then the divisions by the new air mass
-  {
-    const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dB_x, dB_y};
-    fv3_wait(c, s, 4);  // (also the join: nothing is left on the auxiliary stream after this chain)
-    tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
-  }
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk;
-    const unsigned q = IX(i, j);
-    const long p = b + q;
-    const Real dpnv = dpn[p];
-    delp[p] = dpnv;
-    pt[p] = pt_dp[p] / dpnv;
-    Real wn = w_dp[p] / dpnv, hs = (Real)0;
-    if (g.damp_w[k] > (Real)1.0e-5) {
-      const Real dd8 = g.ke_bg[k] * fabs(dt);
-      const Real dwv = ((dC_x + b)[q] - (dC_x + b)[IX(i + 1, j)] + (dC_y + b)[q] - (dC_y + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + q];
-      hs = dd8 - dwv * (w[p] + (Real)0.5 * dwv);  // (w[p]: still the pre-transport value)
-      wn = wn + dwv;
+    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
+
+    // ---- air mass.  The flux-form updates (delp + div, delp * q + div) are formed inside the transport
+    //      kernel (TpEpi); the tracer fluxes gx / gy never reach memory.
+    Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
+    {
+      // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
+      const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+      fv3_wait(c, s, 1);
+      tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
+      fv3_signal(c, s, 5);
     }
-    w[p] = wn;
-    heat_s[p] = hs;
-    q_con[p] = qc_dp[p] / dpnv;
-  });
+    fv3_wait(c, s2, 5);
+    del6_vt_flux(c, s2, q_con, d2w, dA_x, dA_y, dn_t, true, 0, nz1);
+    fv3_signal(c, s2, 3);
+
+    // ---- vertical velocity: transport with the mass fluxes; its del-n damping increment dw and the heat it
+    //      dissipates are formed by the post-transport kernel below straight from the damping fluxes (the old w is
+    //      still in place there), so neither a dw field nor a separate pass over the fluxes exists
+    fv3_wait(c, s, 2);
+    fv3_signal(c, s, 6);
+    fv3_wait(c, s2, 6);
+    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
+    fv3_signal(c, s2, 4);
+    {
+      const TpEpi e{w_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr};  // delp * w + div
+      tp2d(c, s, w, crx, cry, xfx, yfx, gx, gy, fx, fy, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
+    }
+    // ---- condensate
+    {
+      const TpEpi e{qc_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+      fv3_wait(c, s, 3);
+      tp2d(c, s, q_con, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_dp, &dn_t, 0, nz1, &e);
+    }
+    // ---- potential temperature, then the divisions by the new air mass
+    {
+      const TpEpi e{pt_dp, delp, false, nullptr, nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dB_x, dB_y};
+      fv3_wait(c, s, 4);  // (also the join: nothing is left on the auxiliary stream after this chain)
+      tp2d(c, s, pt, crx, cry, xfx, yfx, gx, gy, fx, fy, delp, cf.hord_tm, &dn_vt, 0, nz1, &e);
+    }
+    launch3(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+      const long b = t * g.st + k * g.sk;
+      const unsigned q = IX(i, j);
+      const long p = b + q;
+      const Real dpnv = dpn[p];
+      delp[p] = dpnv;
+      pt[p] = pt_dp[p] / dpnv;
+      Real wn = w_dp[p] / dpnv, hs = (Real)0;
+      if (g.damp_w[k] > (Real)1.0e-5) {
+        const Real dd8 = g.ke_bg[k] * fabs(dt);
+        const Real dwv = ((dC_x + b)[q] - (dC_x + b)[IX(i + 1, j)] + (dC_y + b)[q] - (dC_y + b)[IX(i, j + 1)]) * g.rarea[t * g.st2 + q];
+        hs = dd8 - dwv * (w[p] + (Real)0.5 * dwv);  // (w[p]: still the pre-transport value)
+        wn = wn + dwv;
+      }
+      w[p] = wn;
+      heat_s[p] = hs;
+      q_con[p] = qc_dp[p] / dpnv;
+    });
+  }
 
   // ---- cell-mean relative vorticity (+ absolute vorticity)
   Real *vabs = c->scratch[SC_R];

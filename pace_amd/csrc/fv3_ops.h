@@ -80,6 +80,24 @@ struct TpEpi {
 void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
           const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi = nullptr);
 
+// d_sw's four scalar transports (delp, w, q_con, pt) and the division by the new air mass as ONE march (fv3_tp2d.hip):
+// the Courant numbers / area fluxes / cell areas are read once for the four tracers, the air-mass fluxes the three
+// mass-weighted transports ride on never leave the wave (they are only accumulated into mfx / mfy), and the
+// flux-form updates, the divisions and w's damping increment + dissipated heat are the epilogue of the cell.
+// Inputs are read-only; the new fields go to o_* (out of place: neighbouring waves still read the old halo values).
+struct DswScalars {
+  const Real *delp, *w, *q_con, *pt;
+  Real *o_delp, *o_w, *o_q_con, *o_pt, *heat;
+  const Real *crx, *cry, *xfx, *yfx;
+  Real *mfx, *mfy;                  // accumulated: += air-mass flux
+  const Real *dpx, *dpy;            // del-n damping fluxes of delp (plain), q_con and pt (mass-weighted), w (applied as an increment)
+  const Real *dqx, *dqy, *dtx, *dty, *dwx, *dwy;
+  int hord_dp, hord_vt, hord_tm;
+  Deln dn_vt, dn_t;
+  Real dt;
+};
+void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
+
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 

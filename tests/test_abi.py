@@ -69,6 +69,19 @@ def test_ctx_create_rejects_unsupported_config(hostemu):
     assert st == -1 and b"null" in so.fv3_last_error(None)  # griddata pointers missing
 
 
+def test_fp32_build_refuses_overflowing_damping_tables():
+    """(da_min_c * d4_bg)^(nord + 1) ~ (6e9)^4 leaves the float range on C48 and coarser grids: the fp32 build must refuse the
+    context instead of stepping into NaN."""
+    import torch
+
+    from helpers import Case
+
+    build.build(32, hostemu=True, verbose=False)
+    with pytest.raises(lib.Fv3Error, match="overflows"):
+        Case(12, (1, 1), (0,), nz=4, dtype=torch.float32)
+    Case(12, (1, 1), (0,), nz=4, dtype=torch.float32, cfg_kw=dict(nord=1))  # (6e9)^2 fits
+
+
 def test_python_config_validation():
     from pace_amd.config import AcousticDynamicsConfig
 

@@ -139,9 +139,14 @@ def _conservation_and_tile0_spot_check(backend, nx, nz):
     print(f"C{nx} L{nz} tile-0 spot check:", {k: f"{v:.1e}" for k, v in errs.items()})
 
 
-# fp32 build against the fp64 oracle: field-scale relative.  fp32 has eps = 6e-8; one acoustic sub-step amplifies it through
-# differences of O(1e5 Pa) pressures and O(1e4 m) heights -- measured 3e-7 (delp) .. 2e-4 (w); bounds = measured x ~5.
-TOL32 = {"default": 1e-5, "delp": 2e-6, "pt": 2e-6, "u": 1e-4, "v": 1e-4, "w": 2e-3, "delz": 2e-5, "ua": 1e-4, "va": 1e-4, "omga": 5e-3, "q_con": 1e-4}
+# fp32 build against the fp64 oracle: field-scale relative.  fp32 has eps = 6e-8.  Measured on MI355X (C96 L127, one sub-step):
+# delp / pt / ua / va / omga 2-4e-7, delz 4e-6, u / v / q_con 2e-5, w 2.3e-2; bounds = measured x 2-5.
+# w is the outlier by construction, not by a kernel choice: the solver's layer thickness is the difference of two fp32
+# interface heights (~1e4 m, so dz ~ 1e2 m carries a 1e-5 relative error), which moves the full pressure
+# exp(gamma log(-dm / dz R pt)) ~ 1e5 Pa by ~1 Pa against a perturbation pressure of ~1e2 Pa that drives w.  Evaluating the
+# exp / log / layer-mean-pressure chain in fp64 inside the fp32 build changes w's error from 2.0e-2 to 1.8e-2 (measured on the
+# host emulation): the error is carried by the fp32 STORAGE of zh, as in any 32-bit FV3 build.
+TOL32 = {"default": 1e-5, "delp": 1e-6, "pt": 1e-6, "u": 1e-4, "v": 1e-4, "w": 6e-2, "delz": 2e-5, "ua": 2e-6, "va": 2e-6, "omga": 2e-6, "q_con": 1e-4}
 
 
 @gpu

@@ -259,6 +259,23 @@ def test_full_acoustic_call_multi_tile(backend, n):
     compare_cubes(got, ost, part, nz, STATE, TOL)
 
 
+@pytest.mark.parametrize("n, layout", [(65, (1, 1)), (24, (2, 2))])
+def test_fused_scalar_march_is_bitwise_the_four_transports(backend, monkeypatch, n, layout):
+    """d_sw's fused four-tracer march (fv3_tp4.hip) against the four single-tracer launches + the division kernel it
+    replaces (FV3_DSW_SCALARS=separate): same expressions in the same order, so every field is bitwise equal -- on
+    multi-strip sub-domains (C65: two strips, two row segments) and on 2 x 2 ranks."""
+    nz = 4
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("fused", "separate"):
+        monkeypatch.setenv("FV3_DSW_SCALARS", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
+
+
 def test_native_and_python_sequencers_are_identical(backend):
     """fv3_acoustic_step (C, the product path) and its Python twin in dyn_core.py issue the same
     operator / halo sequence: bitwise equal states, and the per-operator profile is populated."""
