@@ -800,6 +800,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   // FV3_DSW_SCALARS=separate: the four transports as four launches + the division kernel (round-1 form, A/B reference)
   const char *sc_env = getenv("FV3_DSW_SCALARS");  // (read per call: the A/B parity test flips it in one process)
   const bool fused_scalars = !(sc_env && !strcmp(sc_env, "separate")) && nord_max_v <= 2 && nord_max_t <= 2 && nord_max_w <= 2;
+  const int scalars_mode = sc_env && !strcmp(sc_env, "quad") ? 0 : 1;
   if (fused_scalars) {
     // ---- air mass, vertical velocity, condensate, potential temperature: the four del-n chains (bandwidth-bound, the
     //      fields themselves are their only input) first, fxadv beside them, then ONE march for the four transports, the
@@ -816,9 +817,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     fv3_signal(c, s2, 1);
     fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s, 1);
-    DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
+    DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
                   cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt};
-    dsw_scalars_stream(c, s, q4);
+    dsw_scalars_stream(c, s, q4, scalars_mode);
     launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       delp[p] = n_dp[p];

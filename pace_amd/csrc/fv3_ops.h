@@ -90,13 +90,15 @@ struct DswScalars {
   Real *o_delp, *o_w, *o_q_con, *o_pt, *heat;
   const Real *crx, *cry, *xfx, *yfx;
   Real *mfx, *mfy;                  // accumulated: += air-mass flux
+  Real *fx, *fy;                    // air-mass fluxes (work fields of the two-launch form)
   const Real *dpx, *dpy;            // del-n damping fluxes of delp (plain), q_con and pt (mass-weighted), w (applied as an increment)
   const Real *dqx, *dqy, *dtx, *dty, *dwx, *dwy;
   int hord_dp, hord_vt, hord_tm;
   Deln dn_vt, dn_t;
   Real dt;
 };
-void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
+// mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
+void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
 
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);

@@ -1,93 +1,170 @@
 // fv3_tp4.hip -- d_sw's four scalar transports (air mass delp, vertical velocity w, condensate q_con, potential
-// temperature pt) fused into ONE marching wave kernel.  CPU twin: oracle/fv3_oracle/d_sw.py (the four fv_tp_2d calls
+// temperature pt) as multi-tracer marching wave kernels.  CPU twin: oracle/fv3_oracle/d_sw.py (the four fv_tp_2d calls
 // and the divisions by the new air mass of d_sw_levels).  [SURVEY A.3.2 - A.3.4, A.4]
 //
 // Why: as four launches of tp2d_stream_t the transports re-read the Courant numbers, the area fluxes and the cell areas
 // four times, the air-mass fluxes go out to memory to come back three times as the mass fluxes of the other tracers, the
 // flux-form updates go out as delp * q fields and a fifth kernel divides them by the new air mass: 141 GB + 29 GB of the
-// 352 GB one d_sw call moved at C768 (PMC, round 1) for 8 fields of algorithmic traffic.  Here a wave carries the four
+// 352 GB one d_sw call moved at C768 (PMC, round 1) for 8 fields of algorithmic traffic.  Here a wave carries several
 // tracers of its strip together:
-//   * crx / cry / xfx / yfx / area are loaded once per row for the four tracers (and the two denominators of the
+//   * crx / cry / xfx / yfx / area are loaded once per row for the tracers of the wave (and the two denominators of the
 //     cross-direction updates are shared);
-//   * the final air-mass flux of a face is used in the same lane, in the same step, as the mass flux of w / q_con / pt
-//     (a pointwise dependency) and only leaves the wave as the mfx / mfy accumulation;
-//   * the old air mass is the damping weight and the epilogue multiplier of q_con / pt: it is already in the wave as the
-//     delp tracer's own window;
-//   * the epilogue of a cell forms delp_new, (delp * q + div) / delp_new for the three tracers, w's del-n increment and
-//     the heat it dissipates -- the post-transport kernel of round 1 is gone.
-// One wave per SIMD (about 440 VGPRs): the four tracers are four independent dependency chains, which is the
-// instruction-level parallelism the single-tracer march lacks at two waves per SIMD, and every LDS exchange
-// (one ordering point) now serves four rows.  The arithmetic of each tracer is expression for expression the one of
-// tp2d_stream_t (same operation order: bitwise equal results, checked by tests/test_gpu_invariants.py and the A/B switch
-// FV3_DSW_SCALARS=separate).
+//   * the final air-mass flux of a face is used in the same lane, in the same step, as the mass flux of w
+//     (a pointwise dependency);
+//   * the old air mass is the damping weight and the epilogue multiplier of q_con / pt;
+//   * the epilogue of a cell forms delp_new, (delp * q + div) / delp_new, w's del-n increment and the heat it
+//     dissipates -- the post-transport kernel of round 1 is gone.
+// Instantiations of the same step (ROLE):
+//   QUAD  all four tracers in one wave: least traffic (28 field passes), but ~500 registers = one wave per SIMD with half
+//         of the state parked in AGPRs: measured 39.4 ms at C768 (48 % of the wave cycles issuing, 46 % waiting) against
+//         33.2 ms for the five round-1 launches -- kept as an experiment (FV3_DSW_SCALARS=quad);
+//   AIR   delp + w (w rides on the air-mass flux of the same lane); the air-mass fluxes are also stored for TRC;
+//   TRC   q_con + pt on the stored air-mass fluxes, the old air mass as damping weight, the new one as divisor.
+// and (PART) of the way the cube-tile edges are served:
+//   ALL       every strip, the strips that touch a W / E tile edge with the one-sided PPM formulas among their faces
+//             evaluated per lane (divergent: 3.2 x the instructions of an interior strip, +130 registers);
+//   INTERIOR  every strip with the interior formulas only; the faces / cells the W / E one-sided formulas reach
+//             (x-faces 1..3 / nx-1..nx+1, cells and y-faces of columns 1..3 / nx-2..nx) are masked out;
+//   EDGE      those columns, by a TRANSPOSED march: lanes along j, marching ~9 steps along i across the tile edge.  The
+//             W / E one-sided formulas are then the march-direction edge, i.e. wave-uniform branches (what the S / N edges
+//             are for the normal march), and fv_tp_2d is symmetric in x and y, so it is the same step with the roles of
+//             (crx, xfx, dxa, fx, W / E, nx) and (cry, yfx, dya, fy, S / N, ny) exchanged and the two strides swapped.
+// AIR + TRC, INTERIOR + EDGE (the default) = four launches: two-tracer interior waves fit 212 registers (two waves per
+// SIMD, no spill; compiled with the per-lane edge path they needed 397) and run at HBM speed (9.0 ms each, 5.1 / 3.8 TB/s),
+// the edge launches are ~2 % of the interior work.
+// The arithmetic of each tracer is expression for expression the one of tp2d_stream_t (same operation order: bitwise
+// equal results, checked by tests/test_parity.py::test_fused_scalar_march_is_bitwise_the_four_transports and the A/B
+// switch FV3_DSW_SCALARS=separate).
 #include "fv3_ops.h"
 #include "fv3_ppm.h"
+
+#include <type_traits>
+#include <utility>
 
 #define Q4_OUT 58
 #define Q4_LINE (FV3_WAVE + 6)
 #define Q4_PF 2
-#define Q4_NT 4  // tracer slots: 0 = delp, 1 = w, 2 = q_con, 3 = pt
+enum { Q4_QUAD = 0, Q4_AIR = 1, Q4_TRC = 2 };
+enum { Q4_ALL = 0, Q4_INTERIOR = 1, Q4_EDGE = 2 };
+#define Q4_EW 3  // cells next to a W / E tile edge the EDGE launch owns
 
-void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
+// tracer identity of slot n: 0 = delp, 1 = w, 2 = q_con, 3 = pt
+template <int ROLE>
+FV3_HD constexpr int q4_id(int n) {
+  return ROLE == Q4_TRC ? n + 2 : n;
+}
+
+// compile-time loop over the tracer slots: the slot index is a constant expression in the body (a plain unrolled loop
+// leaves it to the optimizer; when a body is not unrolled the per-slot register arrays turn into indexed scratch)
+template <int N0, int N1, class F>
+FV3_HD inline void q4_for(F &&f) {
+  if constexpr (N0 < N1) {
+    f(std::integral_constant<int, N0>{});
+    q4_for<N0 + 1, N1>(f);
+  }
+}
+#define Q4_EACH(n) q4_for<0, Q4_NT>([&](auto n##_c) { constexpr int n = decltype(n##_c)::value; constexpr int id = q4_id<ROLE>(n); (void)id;
+#define Q4_END });
+
+// Naming inside the kernel: L = the lane direction (x for the normal march, y for the transposed one), M = the march
+// direction.  "lc" / "r" are the Fortran-local coordinates along L / M.
+template <int ROLE, int PART>
+static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
+  constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
+  constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
+  constexpr bool TR = PART == Q4_EDGE;      // transposed march
+  constexpr int WPE = (ROLE == Q4_QUAD || PART == Q4_EDGE) ? 1 : 2;
   const Geo g = c->g;
-  const DswScalars a = a_;
+  DswScalars a = a_;
+  if (TR) {  // exchange the roles of the two directions
+    std::swap(a.crx, a.cry);
+    std::swap(a.xfx, a.yfx);
+    std::swap(a.mfx, a.mfy);
+    std::swap(a.fx, a.fy);
+    std::swap(a.dpx, a.dpy);
+    std::swap(a.dqx, a.dqy);
+    std::swap(a.dtx, a.dty);
+  }
   const int nk = g.nz;
-  const int nstrip = (g.nx + 1 + Q4_OUT - 1) / Q4_OUT;
-  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 1);
-  const int nseg = (g.ny + seg - 1) / seg;
-  // LDS: per tracer the two x-sweep row lines (q on the new row, q_i three rows behind), xfx * fx_in and the final x flux;
-  // shared: xfx, the old air mass of row r-3, the tile-edge dxa ring
+  const int nL = TR ? g.ny : g.nx, nM = TR ? g.nx : g.ny;  // cells along the lanes / along the march
+  const int npL = nL + 1, npM = nM + 1;
+  const int nstrip = (nL + 1 + Q4_OUT - 1) / Q4_OUT;
+  const int seg = TR ? 1 : fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, WPE);
+  const int nseg = TR ? 2 : (nM + seg - 1) / seg;  // transposed: "segment" 0 = the low (W) edge columns, 1 = the high (E) ones
+  // LDS: per tracer the two L-sweep row lines (q on the new row, the M-advected q three rows behind), (area flux) * (inner
+  // L flux) and the final L flux; shared: the L area flux, the old air mass of row r-3, the tile-edge metric ring
   const size_t smem = sizeof(Real) * (Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
   const Geo *gp = c->g_dev;
-  const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
+  const int nh = g.nh, sj32 = g.sj32, go = g.o;
+  const int LS = TR ? sj32 : 1, MS = TR ? 1 : sj32;  // element strides of one step along L / along M
   const long st = g.st, sk = g.sk, st2 = g.st2;
-  const MPtr area = g.area, gdxa = g.dxa, rarea = g.rarea;
+  const MPtr area = g.area, rarea = g.rarea;
+  const MPtr metL = TR ? g.dya : g.dxa;  // cell widths of the one-sided formulas along L
   const Real *damp_w_k = g.damp_w, *ke_bg_k = g.ke_bg;
-  launch_waves<1>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+  const int bitLlo = TR ? FV3_S : FV3_W, bitLhi = TR ? FV3_N : FV3_E, bitMlo = TR ? FV3_W : FV3_S, bitMhi = TR ? FV3_E : FV3_N;
+  launch_waves<WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / nk, k = blk.bz - t * nk;
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
-    const int i0 = 1 + blk.bx * Q4_OUT;
-    const int ja = 1 + blk.by * seg;
-    const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;
-    const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
+    const int l0 = 1 + blk.bx * Q4_OUT;  // first owned L face / cell of the strip
+    // owned M range: cells ca..cb (and the L faces of those rows), M faces fa..fb
+    int ca, cb, fa, fb;
+    if (TR) {
+      if (!(fl & (blk.by == 0 ? bitMlo : bitMhi))) return;  // this sub-domain does not touch that tile edge
+      if (blk.by == 0) {
+        ca = 1, cb = Q4_EW, fa = 1, fb = Q4_EW;
+      } else {
+        ca = nM - Q4_EW + 1, cb = nM, fa = nM - Q4_EW + 2, fb = nM + 1;
+      }
+    } else {
+      ca = fa = 1 + blk.by * seg;
+      fb = blk.by == nseg - 1 ? nM + 1 : fa + seg - 1;
+      cb = fb < nM ? fb : nM;
+    }
+    const int Led = nL + nh, Msd = 1 - nh, Med = nM + nh;
     Real *lq[Q4_NT], *lqi[Q4_NT], *exp_[Q4_NT], *exf[Q4_NT];
     {
       Real *p = (Real *)smem_;
-#pragma unroll
-      for (int n = 0; n < Q4_NT; ++n) {
+      Q4_EACH(n)
         lq[n] = p;
         lqi[n] = p + Q4_LINE;
         exp_[n] = p + 2 * Q4_LINE;
         exf[n] = p + 2 * Q4_LINE + FV3_WAVE + 1;
         p += 2 * Q4_LINE + 2 * (FV3_WAVE + 1);
-      }
+      Q4_END
     }
-    Real *exx = (Real *)smem_ + Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1));  // xfx of the lane's face (read by lane - 1)
-    Real *exm = exx + FV3_WAVE + 1;                                          // old delp(i, r-3) of the lane (read by lane + 1)
-    Real *emr = exm + FV3_WAVE + 1;                                          // tile-edge strips: dxa ring (4 rows x 8 cells)
-    const Real *qin[Q4_NT] = {a.delp + b, a.w + b, a.q_con + b, a.pt + b};
-    const int hord[Q4_NT] = {a.hord_dp, a.hord_vt, a.hord_dp, a.hord_tm};
-    const Real *crxb = a.crx + b, *cryb = a.cry + b, *xfxb = a.xfx + b, *yfxb = a.yfx + b;
+    Real *exx = (Real *)smem_ + Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1));  // L area flux of the lane's face (read by lane - 1)
+    Real *exm = exx + FV3_WAVE + 1;                                          // old delp(lc, r-3) of the lane (read by lane + 1)
+    Real *emr = exm + FV3_WAVE + 1;                                          // tile-edge strips: metric ring (4 rows x 8 cells)
+    const Real *const qall[4] = {a.delp + b, a.w + b, a.q_con + b, a.pt + b};
+    const int hall[4] = {a.hord_dp, a.hord_vt, a.hord_dp, a.hord_tm};
+    const Real *qin[Q4_NT];
+    int hord[Q4_NT];
+    Q4_EACH(n)
+      qin[n] = qall[id];
+      hord[n] = hall[id];
+    Q4_END
+    const Real *crLb = a.crx + b, *crMb = a.cry + b, *afLb = a.xfx + b, *afMb = a.yfx + b;  // Courant numbers / area fluxes along L, M
     const MPtr areab = area + m2;
-    const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + Q4_OUT + 1 >= npx - 1;
-    const bool S = fl & FV3_S, N = fl & FV3_N;
-    const bool halo_cols = i0 - 3 < 1 || i0 + FV3_WAVE - 4 > nx;
+    const bool Llo = (fl & bitLlo) && l0 <= 3, Lhi = (fl & bitLhi) && l0 + Q4_OUT + 1 >= npL - 1;
+    const bool Mlo = fl & bitMlo, Mhi = fl & bitMhi;
+    const bool halo_cols = l0 - 3 < 1 || l0 + FV3_WAVE - 4 > nL;
     const bool on_vt = deln_on(a.dn_vt, k), on_t = deln_on(a.dn_t, k);
     const Real damp_vt = on_vt ? deln_damp(a.dn_vt, k) : (Real)0, damp_t = on_t ? deln_damp(a.dn_t, k) : (Real)0;
     const bool on_w = damp_w_k[k] > (Real)1.0e-5;
     const Real dd8 = ke_bg_k[k] * fabs(a.dt);
-    const int r_end = jb + 3 < jed ? jb + 3 : jed;
+    const int r_end = fb + 3 < Med ? fb + 3 : Med;
 
     struct Row {
       Real qy[Q4_NT], cx, xv, ar, cy, yv, em;
     };
     // inputs consumed at the end of a step, loaded at its top ahead of the prefetch (loads return in order: waiting for
     // them leaves the prefetched rows in flight)
-    Real o_ax[FV3_LPT], o_ay[FV3_LPT];                  // accumulated mass fluxes
-    Real o_dx[Q4_NT][FV3_LPT], o_dy[Q4_NT][FV3_LPT];    // damping fluxes (slot 1 unused: w's enter as an increment)
-    Real era[FV3_LPT];                                  // rarea(i, r-3)
-    Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // w's damping fluxes around the cell (i, r-3)
+    Real o_ax[FV3_LPT], o_ay[FV3_LPT];                  // accumulated mass fluxes (AIR / QUAD)
+    Real o_mx[FV3_LPT], o_my[FV3_LPT], o_mc[FV3_LPT], o_dn[FV3_LPT], mbk[FV3_LPT];  // TRC: air-mass fluxes, old delp(lc, r-2) / (lc, r-3), new delp(lc, r-3)
+    Real o_dx[Q4_NT][FV3_LPT], o_dy[Q4_NT][FV3_LPT];    // damping fluxes along L / M (w's enter as an increment instead)
+    Real era[FV3_LPT];                                  // rarea(lc, r-3)
+    Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // w's damping fluxes around the cell (lc, r-3): x, x + 1, y, y + 1
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real a1[FV3_LPT], a2[FV3_LPT], a3[FV3_LPT];
     Real w2[Q4_NT][FV3_LPT], w3[Q4_NT][FV3_LPT], w4[Q4_NT][FV3_LPT], w5[Q4_NT][FV3_LPT], al_q[Q4_NT][FV3_LPT];
@@ -97,85 +174,110 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     Real fi1[Q4_NT][FV3_LPT], fi2[Q4_NT][FV3_LPT], fi3[Q4_NT][FV3_LPT];
     Real cx1[FV3_LPT], cx2[FV3_LPT], cx3[FV3_LPT], xv1[FV3_LPT], xv2[FV3_LPT], xv3[FV3_LPT];
     Real fyin[Q4_NT][FV3_LPT], px[Q4_NT][FV3_LPT];
-    Real fxk[Q4_NT][FV3_LPT], fyp[Q4_NT][FV3_LPT];  // x flux of the west face / y flux of the south face of cell (i, r-3)
-    unsigned pcol[FV3_LPT];
+    Real fxk[Q4_NT][FV3_LPT], fyp[Q4_NT][FV3_LPT];  // L flux of the low L face / M flux of the low M face of cell (lc, r-3)
+    unsigned pcol[FV3_LPT];  // in-plane offset of (lc, M coordinate 0)
     bool own_x[FV3_LPT], own_y[FV3_LPT];
 
-    const MPtr dxab0 = gdxa + m2;
+    const MPtr metLb = metL + m2;
+    const unsigned pbase = (unsigned)(go * sj32 + go);
     auto load_row = [&](int r, int l, int lane) -> Row {
-      const int rf = r - 2 < jsd ? jsd : r - 2;
-      const unsigned p0 = pcol[l] + (unsigned)(r * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
+      const int rf = r - 2 < Msd ? Msd : r - 2;
+      const unsigned p0 = pcol[l] + (unsigned)(r * MS), pf = pcol[l] + (unsigned)(rf * MS);
       Row w;
-#pragma unroll
-      for (int n = 0; n < Q4_NT; ++n) w.qy[n] = qin[n][p0];
-      w.cx = crxb[p0];
-      w.xv = xfxb[p0];
+      Q4_EACH(n)
+        w.qy[n] = qin[n][p0];
+      Q4_END
+      w.cx = crLb[p0];
+      w.xv = afLb[p0];
       w.ar = areab[p0];
-      w.cy = cryb[pf];
-      w.yv = yfxb[pf];
+      w.cy = crMb[pf];
+      w.yv = afMb[pf];
       w.em = (Real)1;
-      if ((W || E) && lane < 8) {
-        const bool have = lane < 4 ? W : E;
-        const int sc = lane < 4 ? lane - 1 : npx - 2 + (lane - 4);
-        if (have) w.em = dxab0[(unsigned)((r + go) * sj32 + sc + go)];
+      if (PART != Q4_INTERIOR && (Llo || Lhi) && lane < 8) {
+        const bool have = lane < 4 ? Llo : Lhi;
+        const int sc = lane < 4 ? lane - 1 : npL - 2 + (lane - 4);
+        if (have) w.em = metLb[pbase + (unsigned)(sc * LS + r * MS)];
       }
       return w;
     };
     FV3_LANES(blk, lane, l) {
-      const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
-      pcol[l] = (unsigned)(go * sj32 + ic + go);
-      own_x[l] = i >= i0 && i < i0 + Q4_OUT && i <= nx + 1;
-      own_y[l] = i >= i0 && i < i0 + Q4_OUT && i <= nx;
+      const int lc = l0 - 3 + lane, lcc = lc < Led ? lc : Led;
+      pcol[l] = pbase + (unsigned)(lcc * LS);
+      own_x[l] = lc >= l0 && lc < l0 + Q4_OUT && lc <= nL + 1;
+      own_y[l] = lc >= l0 && lc < l0 + Q4_OUT && lc <= nL;
+      if (PART == Q4_INTERIOR) {  // the columns the W / E one-sided formulas reach belong to the EDGE launch
+        if (fl & bitLlo) {
+          own_x[l] = own_x[l] && lc > Q4_EW;
+          own_y[l] = own_y[l] && lc > Q4_EW;
+        }
+        if (fl & bitLhi) {
+          own_x[l] = own_x[l] && lc < nL - Q4_EW + 2;
+          own_y[l] = own_y[l] && lc < nL - Q4_EW + 1;
+        }
+      }
       a1[l] = a2[l] = a3[l] = (Real)1;
       o_ax[l] = o_ay[l] = era[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = y_prev[l] = (Real)0;
+      o_mx[l] = o_my[l] = o_mc[l] = mbk[l] = (Real)0;
+      o_dn[l] = (Real)1;
       cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
-#pragma unroll
-      for (int n = 0; n < Q4_NT; ++n) {
+      Q4_EACH(n)
         w2[n][l] = w3[n][l] = w4[n][l] = w5[n][l] = al_q[n][l] = v2[n][l] = v3[n][l] = v4[n][l] = v5[n][l] = al_v[n][l] = (Real)0;
         cq[n][l] = cv[n][l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
         p_prev[n][l] = fi1[n][l] = fi2[n][l] = fi3[n][l] = fyin[n][l] = px[n][l] = fxk[n][l] = fyp[n][l] = o_dx[n][l] = o_dy[n][l] = (Real)0;
         if (lane == 0) exf[n][FV3_WAVE] = exp_[n][FV3_WAVE] = (Real)0;
         if (lane < 3) lq[n][lane] = lqi[n][lane] = lq[n][FV3_WAVE + 3 + lane] = lqi[n][FV3_WAVE + 3 + lane] = (Real)0;
-      }
+      Q4_END
       if (lane == 0) exx[FV3_WAVE] = (Real)0;
-      nxt[l] = load_row(ja - 3, l, lane);
-      nx2[l] = load_row(ja - 2 < r_end ? ja - 2 : r_end, l, lane);
+      nxt[l] = load_row(ca - 3, l, lane);
+      nx2[l] = load_row(ca - 2 < r_end ? ca - 2 : r_end, l, lane);
       if (lane < 32) emr[lane] = (Real)1;
       exm[lane] = (Real)0;
     }
 
     auto march = [&](auto xe_tag) {
-      constexpr bool XE = decltype(xe_tag)::value;
+      constexpr bool XE = decltype(xe_tag)::value;  // one-sided formulas among the L faces of this strip (evaluated per lane)
       auto step = [&](int r) {
-        const int r3 = r - 3 < jsd ? jsd : r - 3;
+        const int r3 = r - 3 < Msd ? Msd : r - 3;
         const int rn = r + Q4_PF < r_end ? r + Q4_PF : r_end;
-        const int sy = r - 1;
-        const bool y_edge = (S && sy >= 0 && sy <= 2) || (N && sy >= npy - 1 && sy <= npy + 1);
-        const bool corner_row = halo_cols && (r < 1 || r > ny);
-        // ---- phase 1: prefetch row r+2; inner y-fluxes at face r-2, q_i at row r-3 (four tracers)
+        const int sy = r - 1;  // cell whose low edge value the M windows complete at this step
+        const bool m_edge = (Mlo && sy >= 0 && sy <= 2) || (Mhi && sy >= npM - 1 && sy <= npM + 1);
+        const bool corner_row = halo_cols && (r < 1 || r > nM);
+        // ---- phase 1: prefetch row r+2; inner M fluxes at face r-2, the M-advected q at row r-3
         FV3_LANES(blk, lane, l) {
           {
-            const int rf = r - 2 < jsd ? jsd : r - 2;
-            const unsigned p3 = pcol[l] + (unsigned)(r3 * sj32), pf = pcol[l] + (unsigned)(rf * sj32);
-            o_ax[l] = (a.mfx + b)[p3];
-            o_ay[l] = (a.mfy + b)[pf];
-            if (on_vt) {
-              o_dx[0][l] = (a.dpx + b)[p3];
-              o_dy[0][l] = (a.dpy + b)[pf];
-              o_dx[3][l] = (a.dtx + b)[p3];
-              o_dy[3][l] = (a.dty + b)[pf];
+            const int rf = r - 2 < Msd ? Msd : r - 2;
+            const unsigned p3 = pcol[l] + (unsigned)(r3 * MS), pf = pcol[l] + (unsigned)(rf * MS);
+            if constexpr (HAS_AIR) {
+              o_ax[l] = (a.mfx + b)[p3];
+              o_ay[l] = (a.mfy + b)[pf];
+              if (on_vt) {
+                o_dx[0][l] = (a.dpx + b)[p3];
+                o_dy[0][l] = (a.dpy + b)[pf];
+              }
+              if (on_w) {
+                zx0[l] = (a.dwx + b)[p3];
+                zx1[l] = (a.dwx + b)[p3 + 1];
+                zy0[l] = (a.dwy + b)[p3];
+                zy1[l] = (a.dwy + b)[p3 + (unsigned)sj32];
+              }
+            } else {
+              o_mx[l] = (a.fx + b)[p3];
+              o_my[l] = (a.fy + b)[pf];
+              o_mc[l] = (a.delp + b)[pf];
+              o_dn[l] = (a.o_delp + b)[p3];
             }
-            if (on_t) {
-              o_dx[2][l] = (a.dqx + b)[p3];
-              o_dy[2][l] = (a.dqy + b)[pf];
+            if constexpr (ROLE != Q4_AIR) {
+              constexpr int nq = ROLE == Q4_QUAD ? 2 : 0, np_ = nq + 1;  // slots of q_con / pt
+              if (on_vt) {
+                o_dx[np_][l] = (a.dtx + b)[p3];
+                o_dy[np_][l] = (a.dty + b)[pf];
+              }
+              if (on_t) {
+                o_dx[nq][l] = (a.dqx + b)[p3];
+                o_dy[nq][l] = (a.dqy + b)[pf];
+              }
             }
             era[l] = (rarea + m2)[p3];
-            if (on_w) {
-              zx0[l] = (a.dwx + b)[p3];
-              zx1[l] = (a.dwx + b)[p3 + 1];
-              zy0[l] = (a.dwy + b)[p3];
-              zy1[l] = (a.dwy + b)[p3 + (unsigned)sj32];
-            }
           }
           cur[l] = nxt[l];
           nxt[l] = nx2[l];
@@ -184,14 +286,18 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           const Real yv = cur[l].yv;
           const Real ar3 = a3[l];
           const Real den_y = ar3 + y_prev[l] - yv;
-#pragma unroll
-          for (int n = 0; n < Q4_NT; ++n) {
+          Q4_EACH(n)
             Real qy = cur[l].qy[n], qx = qy;
-            if (corner_row) {
-              const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
-              const int rc = r < jed ? r : jed;
-              qy = cc<2>(qin[n], *gp, fl, ic, rc);
-              qx = cc<1>(qin[n], *gp, fl, ic, rc);
+            if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
+              const int lc = l0 - 3 + lane, lcc = lc < Led ? lc : Led;
+              const int rc = r < Med ? r : Med;
+              if (TR) {
+                qy = cc<1>(qin[n], *gp, fl, rc, lcc);
+                qx = cc<2>(qin[n], *gp, fl, rc, lcc);
+              } else {
+                qy = cc<2>(qin[n], *gp, fl, lcc, rc);
+                qx = cc<1>(qin[n], *gp, fl, lcc, rc);
+              }
               cur[l].qy[n] = qy;
             }
             w2[n][l] = w3[n][l];
@@ -199,10 +305,10 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             w4[n][l] = w5[n][l];
             w5[n][l] = qy;
             Real al_new;
-            if (y_edge) {
-              const MPtr dyab = gp->dya + m2;
-              auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
-              al_new = ppm_al_win(w2[n][l], w3[n][l], w4[n][l], w5[n][l], My, sy, S, N, npy);
+            if (m_edge) {
+              const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
+              auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
+              al_new = ppm_al_win(w2[n][l], w3[n][l], w4[n][l], w5[n][l], My, sy, Mlo, Mhi, npM);
             } else {
               al_new = PPM_P1 * (w3[n][l] + w4[n][l]) + PPM_P2 * (w2[n][l] + w5[n][l]);
             }
@@ -215,49 +321,59 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             p_prev[n][l] = pn;
             lq[n][3 + lane] = qx;
             lqi[n][3 + lane] = qi;
-          }
+          Q4_END
           y_prev[l] = yv;
-          exm[lane] = w2[0][l];  // old air mass of the cell (i, r-3)
+          exm[lane] = HAS_AIR ? w2[0][l] : mbk[l];  // old air mass of the cell (lc, r-3)
         }
         blk.wave_sync();
-        // ---- phase 2: inner x-fluxes on row r, outer x-fluxes on row r-3, final x fluxes of row r-3
+        // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3
         const int jr = r - 3;
-        const bool fx_row = jr >= ja && jr <= jb && jr <= ny;
+        const bool fx_row = jr >= ca && jr <= cb;
         FV3_LANES(blk, lane, l) {
           const Real cx = cur[l].cx, xv = cur[l].xv;
           Real fxin[Q4_NT], fxout[Q4_NT];
-#pragma unroll
-          for (int n = 0; n < Q4_NT; ++n) {
+          Q4_EACH(n)
             if (XE) {
-              const int i = i0 - 3 + lane;
-              auto EI = [&](int s_) { return s_ <= 2 ? s_ + 1 : s_ - (npx - 2) + 4; };
-              auto Qx = [&](int s_) { return lq[n][s_ - i0 + 6]; };
+              const int lc = l0 - 3 + lane;
+              auto EI = [&](int s_) { return s_ <= 2 ? s_ + 1 : s_ - (npL - 2) + 4; };  // ring column of an edge cell
+              auto Qx = [&](int s_) { return lq[n][s_ - l0 + 6]; };
               auto Mx = [&](int s_) { return emr[(r & 3) * 8 + EI(s_)]; };
-              fxin[n] = ppm_flux(Qx, Mx, cx, i, W, E, npx, hord[n]);
-              auto Qi = [&](int s_) { return lqi[n][s_ - i0 + 6]; };
+              fxin[n] = ppm_flux(Qx, Mx, cx, lc, Llo, Lhi, npL, hord[n]);
+              auto Qi = [&](int s_) { return lqi[n][s_ - l0 + 6]; };
               auto Mx3 = [&](int s_) { return emr[((r - 3) & 3) * 8 + EI(s_)]; };
-              fxout[n] = ppm_flux(Qi, Mx3, cx3[l], i, W, E, npx, hord[n]);
+              fxout[n] = ppm_flux(Qi, Mx3, cx3[l], lc, Llo, Lhi, npL, hord[n]);
             } else {
               const Real *aq = lq[n] + lane, *bq = lqi[n] + lane;
               fxin[n] = ppm_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx, hord[n]);
               fxout[n] = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord[n]);
             }
-          }
-          const Real mb = w2[0][l];                                       // old delp(i, r-3)
-          const Real mw = (lane > 0 ? exm[lane - 1] : (Real)0) + mb;      // + old delp(i-1, r-3)
-          // air mass: area-flux weighted, plain damping flux
-          Real vm = (Real)0.5 * (fxout[0] + fi3[0][l]) * xv3[l];
-          if (on_vt) vm = vm + o_dx[0][l];
-          if (fx_row && own_x[l]) (a.mfx + b)[pcol[l] + (unsigned)(jr * sj32)] = o_ax[l] + vm;
-          // the three tracers riding on the air-mass flux
-          Real vw = (Real)0.5 * (fxout[1] + fi3[1][l]) * vm;
-          Real vq = (Real)0.5 * (fxout[2] + fi3[2][l]) * vm;
-          if (on_t) vq = vq + (Real)0.5 * damp_t * mw * o_dx[2][l];
-          Real vp = (Real)0.5 * (fxout[3] + fi3[3][l]) * vm;
-          if (on_vt) vp = vp + (Real)0.5 * damp_vt * mw * o_dx[3][l];
-          const Real vx[Q4_NT] = {vm, vw, vq, vp};
-#pragma unroll
-          for (int n = 0; n < Q4_NT; ++n) {
+          Q4_END
+          const Real mb = HAS_AIR ? w2[0][l] : mbk[l];                    // old delp(lc, r-3)
+          const Real mw = (lane > 0 ? exm[lane - 1] : (Real)0) + mb;      // + old delp(lc-1, r-3)
+          Real vx[Q4_NT];
+          Real vm = o_mx[l];  // TRC: the stored air-mass flux of the face
+          Q4_EACH(n)
+            if constexpr (id == 0) {  // air mass: area-flux weighted, plain damping flux
+              Real v = (Real)0.5 * (fxout[n] + fi3[n][l]) * xv3[l];
+              if (on_vt) v = v + o_dx[n][l];
+              if (fx_row && own_x[l]) {
+                const unsigned p = pcol[l] + (unsigned)(jr * MS);
+                (a.mfx + b)[p] = o_ax[l] + v;
+                if constexpr (ROLE == Q4_AIR) (a.fx + b)[p] = v;
+              }
+              vm = v;
+              vx[n] = v;
+            } else {  // riding on the air-mass flux; q_con / pt with the mass-weighted damping flux
+              Real v = (Real)0.5 * (fxout[n] + fi3[n][l]) * vm;
+              if constexpr (id == 2) {
+                if (on_t) v = v + (Real)0.5 * damp_t * mw * o_dx[n][l];
+              } else if constexpr (id == 3) {
+                if (on_vt) v = v + (Real)0.5 * damp_vt * mw * o_dx[n][l];
+              }
+              vx[n] = v;
+            }
+          Q4_END
+          Q4_EACH(n)
             fxk[n][l] = vx[n];
             exf[n][lane] = vx[n];
             fi3[n][l] = fi2[n][l];
@@ -265,7 +381,7 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             fi1[n][l] = fxin[n];
             px[n][l] = xv * fxin[n];
             exp_[n][lane] = px[n][l];
-          }
+          Q4_END
           cx3[l] = cx2[l];
           cx2[l] = cx1[l];
           cx1[l] = cx;
@@ -275,16 +391,15 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           exx[lane] = xv;
         }
         blk.wave_sync();
-        // ---- phase 3: q_j on row r, outer y-fluxes at face r-2, final y fluxes, the cell update of (i, r-3)
+        // ---- phase 3: the L-advected q on row r, outer M fluxes at face r-2, final M fluxes, the cell update of (lc, r-3)
         const int jf = r - 2;
-        const bool fy_row = jf >= ja && jf <= jb;
+        const bool fy_row = jf >= fa && jf <= fb;
         FV3_LANES(blk, lane, l) {
           const Real x1 = exx[lane + 1];
           const Real ar = cur[l].ar;
           const Real den_x = ar + cur[l].xv - x1;
           Real fyout[Q4_NT];
-#pragma unroll
-          for (int n = 0; n < Q4_NT; ++n) {
+          Q4_EACH(n)
             const Real p1 = exp_[n][lane + 1];
             const Real qj = (cur[l].qy[n] * ar + px[n][l] - p1) / den_x;
             v2[n][l] = v3[n][l];
@@ -292,10 +407,10 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             v4[n][l] = v5[n][l];
             v5[n][l] = qj;
             Real al_new;
-            if (y_edge) {
-              const MPtr dyab = gp->dya + m2;
-              auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
-              al_new = ppm_al_win(v2[n][l], v3[n][l], v4[n][l], v5[n][l], My, sy, S, N, npy);
+            if (m_edge) {
+              const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
+              auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
+              al_new = ppm_al_win(v2[n][l], v3[n][l], v4[n][l], v5[n][l], My, sy, Mlo, Mhi, npM);
             } else {
               al_new = PPM_P1 * (v3[n][l] + v4[n][l]) + PPM_P2 * (v2[n][l] + v5[n][l]);
             }
@@ -303,60 +418,107 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             al_v[n][l] = al_new;
             fyout[n] = ppm_face(cv[n][l], co, cur[l].cy);
             cv[n][l] = co;
-          }
-          const Real mb = w2[0][l], mc = w3[0][l];  // old delp(i, r-3), old delp(i, r-2)
-          Real vm = (Real)0.5 * (fyout[0] + fyin[0][l]) * cur[l].yv;
-          if (on_vt) vm = vm + o_dy[0][l];
-          if (fy_row && own_y[l]) (a.mfy + b)[pcol[l] + (unsigned)(jf * sj32)] = o_ay[l] + vm;
-          Real vw = (Real)0.5 * (fyout[1] + fyin[1][l]) * vm;
-          Real vq = (Real)0.5 * (fyout[2] + fyin[2][l]) * vm;
-          if (on_t) vq = vq + (Real)0.5 * damp_t * (mb + mc) * o_dy[2][l];
-          Real vp = (Real)0.5 * (fyout[3] + fyin[3][l]) * vm;
-          if (on_vt) vp = vp + (Real)0.5 * damp_vt * (mb + mc) * o_dy[3][l];
-          const Real vy[Q4_NT] = {vm, vw, vq, vp};
+          Q4_END
+          const Real mb = HAS_AIR ? w2[0][l] : mbk[l], mc = HAS_AIR ? w3[0][l] : o_mc[l];  // old delp(lc, r-3), old delp(lc, r-2)
+          Real vy[Q4_NT];
+          Real vm = o_my[l];
+          Q4_EACH(n)
+            if constexpr (id == 0) {
+              Real v = (Real)0.5 * (fyout[n] + fyin[n][l]) * cur[l].yv;
+              if (on_vt) v = v + o_dy[n][l];
+              if (fy_row && own_y[l]) {
+                const unsigned p = pcol[l] + (unsigned)(jf * MS);
+                (a.mfy + b)[p] = o_ay[l] + v;
+                if constexpr (ROLE == Q4_AIR) (a.fy + b)[p] = v;
+              }
+              vm = v;
+              vy[n] = v;
+            } else {
+              Real v = (Real)0.5 * (fyout[n] + fyin[n][l]) * vm;
+              if constexpr (id == 2) {
+                if (on_t) v = v + (Real)0.5 * damp_t * (mb + mc) * o_dy[n][l];
+              } else if constexpr (id == 3) {
+                if (on_vt) v = v + (Real)0.5 * damp_vt * (mb + mc) * o_dy[n][l];
+              }
+              vy[n] = v;
+            }
+          Q4_END
           if (fx_row && own_y[l]) {
-            // flux-form updates of the cell (i, r-3): west / south fluxes fxk / fyp, east from lane + 1, north = vy
-            const unsigned p = pcol[l] + (unsigned)(jr * sj32);
+            // flux-form updates of the cell (lc, r-3): low L / M fluxes fxk / fyp, high L flux from lane + 1, high M flux = vy
+            // (x terms first, as the reference writes the divergence)
+            const unsigned p = pcol[l] + (unsigned)(jr * MS);
             Real up[Q4_NT];
-#pragma unroll
-            for (int n = 0; n < Q4_NT; ++n) {
-              const Real dv_ = (fxk[n][l] - exf[n][lane + 1] + fyp[n][l] - vy[n]) * era[l];
-              up[n] = n == 0 ? w2[0][l] + dv_ : mb * w2[n][l] + dv_;
-            }
-            const Real dpn = up[0];
-            Real wn = up[1] / dpn, hs = (Real)0;
-            if (on_w) {
-              const Real dwv = (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
-              hs = dd8 - dwv * (w2[1][l] + (Real)0.5 * dwv);
-              wn = wn + dwv;
-            }
-            (a.o_delp + b)[p] = dpn;
-            (a.o_pt + b)[p] = up[3] / dpn;
-            (a.o_w + b)[p] = wn;
-            (a.heat + b)[p] = hs;
-            (a.o_q_con + b)[p] = up[2] / dpn;
+            Q4_EACH(n)
+              const Real dv_ = TR ? (fyp[n][l] - vy[n] + fxk[n][l] - exf[n][lane + 1]) * era[l] : (fxk[n][l] - exf[n][lane + 1] + fyp[n][l] - vy[n]) * era[l];
+              up[n] = id == 0 ? w2[n][l] + dv_ : mb * w2[n][l] + dv_;
+            Q4_END
+            const Real dpn = HAS_AIR ? up[0] : o_dn[l];  // new air mass of the cell
+            Q4_EACH(n)
+              if constexpr (id == 0) {
+                (a.o_delp + b)[p] = dpn;
+              } else if constexpr (id == 1) {
+                Real wn = up[n] / dpn, hs = (Real)0;
+                if (on_w) {
+                  const Real dwv = (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
+                  hs = dd8 - dwv * (w2[n][l] + (Real)0.5 * dwv);
+                  wn = wn + dwv;
+                }
+                (a.o_w + b)[p] = wn;
+                (a.heat + b)[p] = hs;
+              } else if constexpr (id == 2) {
+                (a.o_q_con + b)[p] = up[n] / dpn;
+              } else {
+                (a.o_pt + b)[p] = up[n] / dpn;
+              }
+            Q4_END
           }
-#pragma unroll
-          for (int n = 0; n < Q4_NT; ++n) fyp[n][l] = vy[n];
+          if constexpr (!HAS_AIR) mbk[l] = o_mc[l];
+          Q4_EACH(n)
+            fyp[n][l] = vy[n];
+          Q4_END
           a3[l] = a2[l];
           a2[l] = a1[l];
           a1[l] = cur[l].ar;
         }
         blk.wave_sync();
       };
-      if constexpr (XE) {
-        for (int r = ja - 3; r <= r_end; ++r) step(r);
+      // The prefetched rows rotate through three register sets (cur <- nxt <- nx2).  Unrolled by the rotation period the
+      // copies are renames (the four-tracer wave, which has the registers); rolled they wait for the row fetched one
+      // step earlier (the two-tracer waves: -50 registers, what lets them fit two waves per SIMD).
+      if constexpr (XE || PART != Q4_ALL || ROLE != Q4_QUAD) {
+        for (int r = ca - 3; r <= r_end; ++r) step(r);
       } else {
-        for (int r = ja - 3; r <= r_end; r += Q4_PF + 1) {
+        for (int r = ca - 3; r <= r_end; r += Q4_PF + 1) {
           step(r);
           step(r + 1);
           step(r + 2);
         }
       }
     };
-    if (W || E)
-      march(std::true_type{});
-    else
+    if constexpr (PART == Q4_INTERIOR) {
       march(std::false_type{});
+    } else {
+      if (Llo || Lhi)
+        march(std::true_type{});
+      else
+        march(std::false_type{});
+    }
   });
+}
+
+void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode) {
+  int any = 0;
+  for (int t = 0; t < c->g.nsub; ++t) any |= c->g.flags[t];
+  const bool edges = any & (FV3_W | FV3_E);
+  if (mode == 0) {
+    dsw_scalars_t<Q4_QUAD, Q4_ALL>(c, s, a);
+  } else if (mode == 2) {  // two-tracer waves, all strips in one launch (per-lane tile-edge formulas)
+    dsw_scalars_t<Q4_AIR, Q4_ALL>(c, s, a);
+    dsw_scalars_t<Q4_TRC, Q4_ALL>(c, s, a);
+  } else {
+    dsw_scalars_t<Q4_AIR, Q4_INTERIOR>(c, s, a);
+    if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE>(c, s, a);
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+  }
 }

@@ -268,12 +268,13 @@ def test_fused_scalar_march_is_bitwise_the_four_transports(backend, monkeypatch,
     part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
     init = [{k: v.copy() for k, v in s.items()} for s in ost]
     res = {}
-    for mode in ("fused", "separate"):
+    for mode in ("pair", "quad", "separate"):  # pair (default): delp + w, then q_con + pt; quad: all four in one wave
         monkeypatch.setenv("FV3_DSW_SCALARS", mode)
         res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
     for r in range(part.total_ranks):
         for name in STATE:
-            assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
+            assert np.array_equal(res["pair"][r][name], res["separate"][r][name]), f"{name} rank {r} (pair)"
+            assert np.array_equal(res["quad"][r][name], res["separate"][r][name]), f"{name} rank {r} (quad)"
 
 
 def test_native_and_python_sequencers_are_identical(backend):
