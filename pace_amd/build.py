@@ -57,13 +57,21 @@ def build(precision: int = 64, hostemu: bool = False, force: bool = False, verbo
     flags = (HOST_FLAGS if hostemu else HIP_FLAGS) + real + os.environ.get("FV3_EXTRA_FLAGS", "").split()
     cc = os.environ.get("CXX", "g++") if hostemu else HIPCC
     stamp = os.path.join(objdir, "stamp")
-    dig = _digest(srcs + hdrs, flags)
+    dig = _digest(srcs + hdrs, (flags, sorted((k, v) for k, v in os.environ.items() if k.startswith("FV3_FLAGS_"))))
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
         return out
     objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
 
+    per_file = {}
+    if not hostemu:
+        # per-file flag overrides: FV3_FLAGS_<stem>="..." (experiments), e.g. FV3_FLAGS_fv3_nh="-ffp-contract=fast"
+        for sname in SOURCES:
+            extra = os.environ.get("FV3_FLAGS_" + os.path.splitext(sname)[0])
+            if extra:
+                per_file[sname] = extra.split()
+
     def one(i):
-        _run([cc] + flags + ["-c", srcs[i], "-o", objs[i]])
+        _run([cc] + flags + per_file.get(SOURCES[i], []) + ["-c", srcs[i], "-o", objs[i]])
 
     with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         list(ex.map(one, range(len(srcs))))

@@ -809,13 +809,13 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     Real *dQ_x = c->scratch[SC_C], *dQ_y = c->scratch[SC_D], *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
     Real *n_dp = c->scratch[SC_N], *n_w = c->scratch[SC_O], *n_qc = c->scratch[SC_P], *n_pt = c->scratch[SC_Q];
     fv3_signal(c, s, 0);
+    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s2, 0);
     del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
     del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
     del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, nz1);
     del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
     fv3_signal(c, s2, 1);
-    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s, 1);
     DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
                   cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt};
