@@ -13,8 +13,8 @@ k_split 2, n_split 6, dycore-only.  The 24 sub-domains are split over the N proc
 Extra objects on the JSON line:
   roofline     d_sw (all launches of one fv3_d_sw call), algorithmic bytes = 33 field passes x 8 B x
                local cells / mean HIP-event duration of the call, vs 8 TB/s HBM peak
-  cpu_baseline the numpy oracle on one host core on a bounded sample (a C48 L79 cube, a few acoustic
-               sub-steps), scaled per cell to the C768 step -- baseline only
+  cpu_baseline the numpy oracle on the host cores on a bounded sample: a C48 L79 cube, one pinned single-threaded process
+               per tile (6 processes), a few acoustic sub-steps, scaled per cell to the C768 step -- baseline only
   operators    per-operator mean milliseconds per acoustic sub-step (HIP events recorded by fv3_acoustic_step)
 """
 import argparse
@@ -33,38 +33,91 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 D_SW_PASSES = 33  # algorithmic field passes of d_sw
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (numpy, 1 core) on a C48 L79 cube, up to 8 acoustic sub-steps (~10-20 s of CPU work);
-    checker code used as a *reported* baseline only (never on the product path)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from fv3_oracle.dyn_core import OracleAcousticDynamics
-    from pace_amd.config import AcousticDynamicsConfig
-    from pace_amd.constants import get_constants
-    from pace_amd.grid import make_grid
-    from pace_amd.init import synthetic_state
-    from pace_amd.topology import CubedSpherePartitioner
+_CPU_WORKER = r"""
+import json, os, sys, time
+tile, core, budget, root = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
+try:
+    os.sched_setaffinity(0, {core})
+except Exception:
+    pass
+for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[v] = "1"
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+import numpy as np
+from fv3_oracle.dyn_core import OracleAcousticDynamics
+from fv3_oracle.util import Dom
+from pace_amd.config import AcousticDynamicsConfig
+from pace_amd.constants import get_constants
+from pace_amd.grid import make_grid
+from pace_amd.init import synthetic_state
+from pace_amd.topology import CubedSpherePartitioner
 
-    torch.set_num_threads(1)
+class NoExchange:  # one tile per process: the halo cells keep their initial (smooth, finite) values -- same arithmetic per cell
+    def scalar(self, *a, **k): pass
+    def vector(self, *a, **k): pass
+    def synchronize_vector_interfaces(self, *a, **k): pass
+
+n, nz = 48, 79
+c = get_constants()
+part = CubedSpherePartitioner(n, (1, 1))
+cfg = AcousticDynamicsConfig(npx=n + 1, npy=n + 1, npz=nz, n_split=1, k_split=1)
+g = make_grid(part, tile, nz=nz)
+s = synthetic_state(g, rank=tile)
+phis = s.pop("phis")
+one = CubedSpherePartitioner(n, (1, 1))
+dyn = OracleAcousticDynamics.__new__(OracleAcousticDynamics)
+OracleAcousticDynamics.__init__(dyn, part, [g] * 6, cfg, c, [phis] * 6)
+dyn.nranks, dyn.doms, dyn.tmp, dyn.ex = 1, dyn.doms[:1], dyn.tmp[:1], NoExchange()
+dyn.zs, dyn.phis = dyn.zs[:1], dyn.phis[:1]
+states = [s]
+dt_sub = 225.0 / 2 / 6
+dyn(states, dt_sub, 1)  # warm-up (imports, page faults)
+times = []
+t_all = time.time()
+while len(times) < 8 and time.time() - t_all < budget:
+    t0 = time.time()
+    dyn(states, dt_sub, 1)
+    times.append(time.time() - t0)
+ok = bool(np.isfinite(states[0]["delp"]).all())
+print(json.dumps({"tile": tile, "core": core, "t_sub": float(np.mean(times)), "n": len(times), "finite": ok}))
+"""
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The numpy oracle on the host cores, as SURVEY 8d asks: a C48 L79 cube, ONE single-threaded process per tile pinned
+    to its own core (6 processes; the processes never touch the GPU), up to 8 acoustic sub-steps each (~10-20 s);
+    wall time of a sub-step = the slowest process.  Checker code used as a *reported* baseline only."""
+    import subprocess
+
+    ncpu = os.cpu_count() or 1
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cores = list(range(ncpu))
+    nproc = 6
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, str(t), str(cores[t % len(cores)]), str(seconds_budget), ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=env) for t in range(nproc)]
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed:\n" + err[-2000:])
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    t_sub = max(r["t_sub"] for r in res)
     n, nz = 48, 79
-    c = get_constants()
-    part = CubedSpherePartitioner(n, (1, 1))
-    cfg = AcousticDynamicsConfig(npx=n + 1, npy=n + 1, npz=nz, n_split=1, k_split=1)
-    grids = [make_grid(part, r, nz=nz) for r in range(6)]
-    states = [synthetic_state(g, rank=r) for r, g in enumerate(grids)]
-    phis = [s.pop("phis") for s in states]
-    dyn = OracleAcousticDynamics(part, grids, cfg, c, phis)
-    dyn.ex.synchronize_vector_interfaces([s["u"] for s in states], [s["v"] for s in states])
-    dt_sub = 225.0 / 2 / 6
-    dyn(states, dt_sub, 1)  # warm-up (imports, page faults)
-    times = []
-    t_all = time.time()
-    while len(times) < 8 and time.time() - t_all < seconds_budget:
-        t0 = time.time()
-        dyn(states, dt_sub, 1)
-        times.append(time.time() - t0)
-    t_sub = float(np.mean(times))
     cells = 6 * n * n * nz
-    return t_sub / cells, f"numpy oracle, 1 core, C{n} L{nz} cube ({cells} cells), {len(times)} acoustic sub-steps of {t_sub:.2f}s"
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    sample = (f"numpy {np.__version__} oracle, C{n} L{nz} cube ({cells} cells), one single-threaded process per tile pinned to its own core ({nproc} of {ncpu} host cores, "
+              f"{model}), {min(r['n'] for r in res)} acoustic sub-steps, slowest process {t_sub:.2f} s / sub-step (per-process " + ", ".join("%.2f" % r["t_sub"] for r in res) + ")")
+    return t_sub / cells, sample, nproc
 
 
 def main():
@@ -197,12 +250,12 @@ def main():
             }
         line["operators_ms_per_substep"] = op_ms
         if not a.no_cpu_baseline:
-            per_cell, sample = cpu_baseline()
+            per_cell, sample, cores = cpu_baseline()
             t_step_cpu = per_cell * h.cells_global * n_sub_steps
             line["cpu_baseline"] = {
                 "value": cfg.dt_atmos / t_step_cpu,
                 "unit": "simulated-days/day",
-                "cores": 1,
+                "cores": cores,
                 "kind": "port",
                 "sample": sample + "; scaled per cell to the benchmarked step (own numpy restatement -- stands in for the reference numpy backend, which cannot run offline)",
             }

@@ -230,6 +230,53 @@ int fv3_gather_plan_destroy(fv3_gather_plan *);
 int fv3_gather_run(fv3_ctx *, const fv3_gather_plan *, void *dst, int64_t dst_kstride, const void *src,
                    int64_t src_kstride, int nk, void *stream);
 
+/* ---- halo updaters behind the ABI (fv3_halo_plan_create / start / wait) ----------------------------
+ * One plan = one HaloUpdater of the reference [REF docs/util/communication.rst:100-109,169-176]: a list of gather
+ * operations on borrowed field pointers -- copies between co-resident sub-domains, packs into and unpacks out of one
+ * message buffer per peer process -- and the peers with their message sizes.  start(): pack, post every message of the
+ * update (RCCL: one ncclGroupStart/End of ncclSend/ncclRecv), local copies; wait(): unpack.  With a communicator
+ * the exchange runs on the context's communication stream and overlaps what the caller enqueues in between. */
+typedef struct fv3_halo_plan fv3_halo_plan;
+enum { FV3_HALO_LOCAL = 0, FV3_HALO_PACK = 1, FV3_HALO_UNPACK = 2 };
+typedef struct {
+  const fv3_gather_plan *plan;
+  void *dst;           /* LOCAL / UNPACK: destination field (all sub-domains); PACK: ignored (the peer's send buffer) */
+  const void *src;     /* LOCAL / PACK: source field; UNPACK: ignored (the peer's receive buffer) */
+  int64_t dst_kstride; /* elements between levels of the field side(s) */
+  int64_t src_kstride;
+  int64_t buf_off;     /* PACK / UNPACK: element offset of this piece inside the message buffer ... */
+  int64_t buf_kstride; /* ... and the elements between its levels there */
+  int32_t peer;        /* PACK / UNPACK: index into the plan's peer list */
+  int32_t kind;        /* FV3_HALO_LOCAL / PACK / UNPACK */
+  int32_t nk;          /* levels moved per gather entry */
+  int32_t reserved;
+} fv3_halo_op;
+typedef struct {
+  int32_t rank;        /* communicator rank of the peer process */
+  int32_t reserved;
+  int64_t send_elems, recv_elems;
+  void *send_buf, *recv_buf; /* optional caller-owned message buffers (NULL: allocated by the plan, device memory) */
+} fv3_halo_peer;
+int fv3_halo_plan_create(fv3_ctx *, fv3_halo_plan **out, int n_ops, const fv3_halo_op *ops, int n_peers,
+                         const fv3_halo_peer *peers);
+int fv3_halo_plan_start(fv3_ctx *, fv3_halo_plan *, void *stream);
+int fv3_halo_plan_wait(fv3_ctx *, fv3_halo_plan *, void *stream);
+int fv3_halo_plan_destroy(fv3_halo_plan *);
+int fv3_halo_plan_buffer(fv3_halo_plan *, int peer_index, int recv, void **ptr, int64_t *elems);
+
+/* Transport.  RCCL point-to-point over xGMI: the 128-byte id is made on rank 0 (fv3_comm_unique_id), distributed by the
+ * launcher's own channel, and every process calls fv3_ctx_comm_init (= ncclCommInitRank) once, before its first
+ * exchange; librccl.so is bound at run time.  Host-driven transport (tests, gloo): the plan packs, calls
+ * fn(user, plan, 0) [post the messages], later fn(user, plan, 1) [complete them], then unpacks. */
+typedef struct { char internal[128]; } fv3_nccl_id;
+int fv3_comm_unique_id(fv3_nccl_id *id);
+int fv3_ctx_comm_init(fv3_ctx *, const fv3_nccl_id *id, int world, int rank);
+int fv3_ctx_comm_destroy(fv3_ctx *);
+typedef int (*fv3_xfer_fn)(void *user, fv3_halo_plan *plan, int phase);
+int fv3_ctx_set_xfer(fv3_ctx *, fv3_xfer_fn fn, void *user);
+/* run the exchanges on the context's second stream (default: on with a communicator, off without) */
+int fv3_ctx_set_comm_stream(fv3_ctx *, int on);
+
 /* ---- whole acoustic call [REF AcousticDynamics.__call__; SURVEY §3.3] ----------------------------
  * Temporaries AcousticDynamics owns (allocated by the host's QuantityFactory, borrowed here). */
 typedef struct {
@@ -262,8 +309,12 @@ enum fv3_halo_update {
  * enqueued on `stream`.  Returns 0 on success.  The library never moves halos on its own. */
 typedef int (*fv3_halo_fn)(void *user, int update /* fv3_halo_update */, int phase, void *stream);
 
+/* The updaters as plans, indexed by fv3_halo_update: fv3_acoustic_step then needs no callback (halo = NULL) and no
+ * host code runs between its operators. */
+int fv3_ctx_set_halo_plans(fv3_ctx *, fv3_halo_plan *const *plans, int n);
+
 /* n_split acoustic sub-steps (+ the once-per-call diffusive heating when d_con > 1e-5);
- * timestep = dt_atmos / k_split, n_map = 1..k_split. */
+ * timestep = dt_atmos / k_split, n_map = 1..k_split.  halo == NULL: the registered plans (fv3_ctx_set_halo_plans). */
 int fv3_acoustic_step(fv3_ctx *, const fv3_state *state, const fv3_workspace *work, double timestep, int n_map,
                       fv3_halo_fn halo, void *halo_user, void *stream);
 

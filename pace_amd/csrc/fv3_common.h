@@ -123,6 +123,16 @@ struct fv3_ctx {
   void *aux_stream = nullptr;
   void *aux_events[8] = {nullptr};
   int aux_on = 1;
+  // halo exchange behind the ABI (fv3_halo.hip): communicator, communication stream + its two ordering events,
+  // host-driven transport, the updaters registered for fv3_acoustic_step
+  void *nccl_comm = nullptr;
+  int comm_world = 1, comm_rank = 0;
+  void *comm_stream = nullptr;
+  void *comm_ev[2] = {nullptr, nullptr};
+  int comm_stream_on = 0;
+  fv3_xfer_fn xfer = nullptr;
+  void *xfer_user = nullptr;
+  fv3_halo_plan *halo_plans[FV3_HALO_COUNT] = {nullptr};
   // per-operator profiling (fv3_step.hip)
   int profiling = 0;
   struct ProfEvent {
@@ -155,6 +165,7 @@ void fv3_wait(fv3_ctx *c, fv3_stream_t to, int e);
 // ---------------------------------------------------------------------------------------------
 extern std::string g_fv3_create_error;
 int fv3_fail(fv3_ctx *c, int code, const std::string &msg);
+int fv3_halo_step(fv3_ctx *c, int update, int phase, void *stream);  // fv3_halo.hip
 void *fv3_dev_alloc(fv3_ctx *c, size_t bytes);
 void fv3_h2d(void *dst, const void *src, size_t bytes);
 int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what);

@@ -313,6 +313,11 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     c->aux_on = (e && e[0] == '1') && !(m && !strcmp(m, "staged"));
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) c->aux_stream = (void *)st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) c->comm_stream = (void *)st;
+    for (auto &ev : c->comm_ev) {
+      hipEvent_t h;
+      if (hipEventCreateWithFlags(&h, hipEventDisableTiming) == hipSuccess) ev = (void *)h;
+    }
     for (auto &ev : c->aux_events) {
       hipEvent_t h;
       if (hipEventCreateWithFlags(&h, hipEventDisableTiming) == hipSuccess) ev = (void *)h;
@@ -361,6 +366,10 @@ int fv3_ctx_destroy(fv3_ctx *c) {
   for (void *e : c->aux_events)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
   if (c->aux_stream) (void)hipStreamDestroy((hipStream_t)c->aux_stream);
+  (void)fv3_ctx_comm_destroy(c);
+  if (c->comm_stream) (void)hipStreamDestroy((hipStream_t)c->comm_stream);
+  for (auto &ev : c->comm_ev)
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
 #endif
   for (void *p : c->owned) raw_free(p);
   delete c;

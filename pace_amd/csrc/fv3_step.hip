@@ -95,14 +95,18 @@ extern "C" int fv3_profile_read(fv3_ctx *c, double *ms_sum, int64_t *calls, int 
 #define HALO(id, phase)                                                                                  \
   do {                                                                                                   \
     OpTimer tm_(c, s, FV3_OP_HALO);                                                                      \
-    const int st_ = halo(halo_user, id, phase, stream);                                                  \
-    if (st_ != 0) return fv3_fail(c, FV3_ERR_ARG, "acoustic_step: the halo callback reported an error"); \
+    const int st_ = halo ? halo(halo_user, id, phase, stream) : fv3_halo_step(c, id, phase, stream);     \
+    if (st_ != 0) return halo ? fv3_fail(c, FV3_ERR_ARG, "acoustic_step: the halo callback reported an error") : st_; \
   } while (0)
 
 extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_workspace *ws, double timestep, int n_map, fv3_halo_fn halo, void *halo_user,
                                  void *stream) {
   if (!c || !st || !ws) return FV3_ERR_ARG;
-  if (!halo) return fv3_fail(c, FV3_ERR_ARG, "acoustic_step: a halo-exchange callback is required (sub-domain halos are never implicit)");
+  if (!halo) {
+    bool any = false;
+    for (int i = 0; i < FV3_HALO_COUNT; ++i) any = any || c->halo_plans[i] != nullptr;
+    if (!any) return fv3_fail(c, FV3_ERR_ARG, "acoustic_step: a halo-exchange callback or registered halo plans are required (sub-domain halos are never implicit)");
+  }
   fv3_stream_t s = (fv3_stream_t)stream;
   const fv3_acoustic_config &cf = c->cfg;
   const int n_split = cf.n_split;

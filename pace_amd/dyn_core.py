@@ -200,15 +200,23 @@ class AcousticDynamics:
         def halo(_user, update, phase, _stream):
             try:
                 if phase == 0:
-                    ups[update].start()
+                    ups[update].start(_stream)
                 else:
-                    ups[update].wait()
+                    ups[update].wait(_stream)
                 return 0
             except Exception as e:  # never let an exception cross the C frame
                 errors.append(e)
                 return 1
 
-        self._native_args = (st, ws, _lib.fv3_halo_fn(halo), errors)
+        if self.halo.native:
+            # the updaters as fv3_halo_plans registered with the context: fv3_acoustic_step runs without a callback
+            plans = (C.c_void_p * len(ups))(*[u._native_plan() for u in ups])
+            rc = self.sf.lib.fv3_ctx_set_halo_plans(self.sf.ctx, plans, len(ups))
+            if rc != 0:
+                raise _lib.Fv3Error("fv3_ctx_set_halo_plans failed: " + self.sf.lib.fv3_last_error(self.sf.ctx).decode())
+            self._native_args = (st, ws, _lib.fv3_halo_fn(), errors)
+        else:
+            self._native_args = (st, ws, _lib.fv3_halo_fn(halo), errors)
 
     def _call_native(self, state: DycoreState, timestep: float, n_map: int):
         import ctypes as C
@@ -222,6 +230,10 @@ class AcousticDynamics:
             e = errors.pop()
             errors.clear()
             raise e
+        xe = getattr(self.halo, "_xfer_error", None)
+        if xe is not None:
+            self.halo._xfer_error = None
+            raise xe
         if rc != 0:
             from . import lib as _lib
 

@@ -117,6 +117,7 @@ class HaloExchanger:
         self.st = self.sk * self.nk
         self._phases: Dict[Tuple[str, int], _Phase] = {}
         self._buffers: Dict[Tuple, torch.Tensor] = {}
+        self._next_uid = 0  # message buffers are keyed by a per-exchanger serial number (id() of a collected updater can be recycled)
         # Second HIP stream for the exchange: pack / device-local copies / RCCL point-to-point / unpack
         # run there, ordered against the compute stream by two events (start: comm waits for compute;
         # wait: compute waits for comm), so everything the sequencer issues between start() and wait()
@@ -136,6 +137,58 @@ class HaloExchanger:
             import torch.distributed as dist
 
             self.host_staged = dist.get_backend(group) == "gloo"
+        # Native updaters (default): every HaloUpdater is a fv3_halo_plan -- pack / RCCL send+recv / local copies / unpack are
+        # issued by the library (fv3_halo_plan_start / wait), fv3_acoustic_step needs no callback and no Python runs between
+        # its operators.  FV3_HALO_NATIVE=0 keeps the torch.distributed path below (A/B reference).
+        self.native = os.environ.get("FV3_HALO_NATIVE", "1") != "0"
+        self.transport = None
+        self._by_plan: Dict[int, "HaloUpdater"] = {}
+        self._xfer_cb = None
+        if self.native:
+            lib = sf.lib
+            if not sf.hostemu:
+                lib.fv3_ctx_set_comm_stream(sf.ctx, 1 if want else 0)
+            if layout.world_size > 1:
+                self._init_transport(group)
+
+    def _init_transport(self, group):
+        """RCCL through the library when the process group is nccl (device buffers go straight to ncclSend / ncclRecv on the
+        context's communication stream); otherwise the host-driven transport: the library packs, calls back with
+        (plan, phase), this process moves the message buffers with torch.distributed (gloo), the library unpacks."""
+        import torch.distributed as dist
+
+        from . import lib as _lib
+
+        sf, lay = self.sf, self.layout
+        backend = dist.get_backend(group)
+        if backend == "nccl" and not sf.hostemu and os.environ.get("FV3_HALO_TRANSPORT", "rccl") == "rccl":
+            ident = _lib.fv3_nccl_id()
+            payload = [None]
+            if lay.proc == 0:
+                st = sf.lib.fv3_comm_unique_id(C.byref(ident))
+                if st != 0:
+                    raise RuntimeError("fv3_comm_unique_id failed: " + sf.lib.fv3_last_error(None).decode())
+                payload = [bytes(ident.internal)]
+            dist.broadcast_object_list(payload, src=0, group=group)
+            C.memmove(C.byref(ident), payload[0], 128)
+            st = sf.lib.fv3_ctx_comm_init(sf.ctx, C.byref(ident), lay.world_size, lay.proc)
+            if st != 0:
+                raise RuntimeError("fv3_ctx_comm_init failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
+            self.transport = "rccl"
+            return
+
+        def xfer(_user, plan, phase):
+            try:
+                up = self._by_plan[int(plan)]
+                up._host_transfer(int(phase))
+                return 0
+            except Exception as e:  # never let an exception cross the C frame
+                self._xfer_error = e
+                return 1
+
+        self._xfer_cb = _lib.fv3_xfer_fn(xfer)
+        sf.lib.fv3_ctx_set_xfer(sf.ctx, self._xfer_cb, None)
+        self.transport = "host"
 
     # ------------------------------------------------------------------------------------------
     def _maps(self, key, rank) -> GatherMap:
@@ -232,8 +285,102 @@ class HaloUpdater:
         if any(q.is_2d != two_d for gp in self.groups for q in gp):
             raise ValueError("a halo updater cannot mix 2-D and 3-D quantities")
         self.ph = ex._phase(key, two_d)
+        self.uid = ex._next_uid
+        ex._next_uid += 1
         self._inflight = None
         self.nk = 1 if two_d else ex.nk
+        self._plan = None  # fv3_halo_plan handle (native updaters)
+        self._peers: List[int] = []
+
+    # ------------------------------------------------------------------------------------------
+    # native form: the whole update as one fv3_halo_plan
+    def _native_plan(self):
+        if self._plan is not None:
+            return self._plan
+        from . import lib as _lib
+
+        ex, ph, sf = self.ex, self.ph, self.ex.sf
+        ng, nk = len(self.groups), self.nk
+        peers = sorted(set(ph.send_count) | set(ph.recv_count))
+        pidx = {p: i for i, p in enumerate(peers)}
+        ops = []
+
+        def op(kind, plan, dst=None, src=None, dks=0, sks=0, boff=0, bks=0, peer=-1):
+            ops.append(_lib.fv3_halo_op(plan.h, dst, src, dks, sks, boff, bks, peer, kind, nk, 0))
+
+        for gi, gp in enumerate(self.groups):
+            for (dc, sc), plan in ph.local.items():
+                if plan.n:
+                    op(_lib.HALO_LOCAL, plan, gp[dc].storage.data_ptr(), gp[sc].storage.data_ptr(), ex.sk, ex.sk)
+            for peer, cnt in ph.send_count.items():
+                for comp, plan in ph.send[peer].items():
+                    op(_lib.HALO_PACK, plan, None, gp[comp].storage.data_ptr(), 0, ex.sk, gi * cnt * nk, cnt, pidx[peer])
+            for peer, cnt in ph.recv_count.items():
+                for comp, plan in ph.recv[peer].items():
+                    op(_lib.HALO_UNPACK, plan, gp[comp].storage.data_ptr(), None, ex.sk, 0, gi * cnt * nk, cnt, pidx[peer])
+        plist = []
+        self._send_bufs, self._recv_bufs = {}, {}
+        for p in peers:
+            ns, nr = ph.send_count.get(p, 0) * nk * ng, ph.recv_count.get(p, 0) * nk * ng
+            sb = ex._buffer(("s", self.uid, p), ns) if ns else None
+            rb = ex._buffer(("r", self.uid, p), nr) if nr else None
+            self._send_bufs[p], self._recv_bufs[p] = sb, rb
+            plist.append(_lib.fv3_halo_peer(p, 0, ns, nr, sb.data_ptr() if sb is not None else None, rb.data_ptr() if rb is not None else None))
+        self._peers = peers
+        h = C.c_void_p()
+        ops_a = (_lib.fv3_halo_op * max(len(ops), 1))(*ops)
+        peers_a = (_lib.fv3_halo_peer * max(len(plist), 1))(*plist)
+        st = sf.lib.fv3_halo_plan_create(sf.ctx, C.byref(h), len(ops), ops_a, len(plist), peers_a)
+        if st != 0:
+            raise RuntimeError("fv3_halo_plan_create failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
+        self._plan = h
+        ex._by_plan[int(h.value)] = self
+        return h
+
+    def _host_transfer(self, phase: int):
+        """Host-driven transport (gloo): move the plan's message buffers between the processes."""
+        import torch.distributed as dist
+
+        ex = self.ex
+        dev = torch.device(ex.sf.device).type == "cuda"
+        if phase == 0:
+            if dev:
+                torch.cuda.synchronize(ex.sf.device)  # the pack kernels (on the library's stream)
+            ops = []
+            self._wires = {}
+            for p in self._peers:
+                rb, sb = self._recv_bufs[p], self._send_bufs[p]
+                if rb is not None:
+                    wire = ex._buffer(("r", self.uid, p), rb.numel(), host=True) if dev else rb
+                    self._wires[p] = wire
+                    ops.append(dist.P2POp(dist.irecv, wire, p, group=ex.group))
+                if sb is not None:
+                    wire = sb
+                    if dev:
+                        wire = ex._buffer(("s", self.uid, p), sb.numel(), host=True)
+                        wire.copy_(sb)
+                    ops.append(dist.P2POp(dist.isend, wire, p, group=ex.group))
+            self._reqs = dist.batch_isend_irecv(ops) if ops else []
+        else:
+            for r in self._reqs:
+                r.wait()
+            if dev:
+                for p, wire in self._wires.items():
+                    self._recv_bufs[p].copy_(wire)
+                torch.cuda.synchronize(ex.sf.device)  # the unpack kernels run on the library's stream
+            self._reqs = []
+
+    def _native_call(self, fn, stream_handle):
+        ex = self.ex
+        sf = ex.sf
+        h = stream_handle if stream_handle else self._stream()
+        st = fn(sf.ctx, self._native_plan(), h)
+        if st != 0:
+            err = getattr(ex, "_xfer_error", None)
+            if err is not None:
+                ex._xfer_error = None
+                raise err
+            raise RuntimeError("halo plan failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
 
     def _stream(self):
         return self.ex.sf.stream_handle
@@ -247,12 +394,31 @@ class HaloUpdater:
             return contextlib.nullcontext(), self._stream()
         return torch.cuda.stream(ex.comm_stream), ex.comm_stream.cuda_stream
 
-    def start(self):
+    def _compute_stream(self, handle=None):
+        """The stream the operators run on, as a torch stream: the handle the C sequencer passes to the halo callback
+        (or the factory's stream_handle) -- NOT torch's current stream, which is a different one when the factory was
+        given a raw hipStream_t."""
+        ex = self.ex
+        h = handle if handle else self._stream()
+        cur = torch.cuda.current_stream(ex.sf.device)
+        if h is None or int(h) == int(cur.cuda_stream):
+            return cur
+        return torch.cuda.ExternalStream(int(h), device=ex.sf.device)
+
+    def start(self, stream_handle=None):
         ex, ph = self.ex, self.ph
+        if ex.native:
+            self._native_call(ex.sf.lib.fv3_halo_plan_start, stream_handle)
+            self._inflight = True
+            return
         if ex.comm_stream is not None:
             # the exchange may start once everything enqueued so far on the compute stream is done
-            ex.comm_stream.wait_stream(torch.cuda.current_stream(ex.sf.device))
-        ctx, stream = self._on_comm_stream()
+            ex.comm_stream.wait_stream(self._compute_stream(stream_handle))
+            ctx, stream = self._on_comm_stream()
+        else:
+            import contextlib
+
+            ctx, stream = contextlib.nullcontext(), (stream_handle if stream_handle else self._stream())
         with ctx:
             self._start(stream)
 
@@ -265,19 +431,19 @@ class HaloUpdater:
             ops = []
             self._recv_bufs = {}
             for peer, cnt in ph.recv_count.items():
-                buf = ex._buffer(("r", id(self), peer), cnt * self.nk * len(self.groups))
+                buf = ex._buffer(("r", self.uid, peer), cnt * self.nk * len(self.groups))
                 self._recv_bufs[peer] = buf
-                wire = ex._buffer(("r", id(self), peer), buf.numel(), host=True) if ex.host_staged else buf
+                wire = ex._buffer(("r", self.uid, peer), buf.numel(), host=True) if ex.host_staged else buf
                 ops.append(dist.P2POp(dist.irecv, wire, peer, group=ex.group))
             for peer, cnt in ph.send_count.items():
-                buf = ex._buffer(("s", id(self), peer), cnt * self.nk * len(self.groups))
+                buf = ex._buffer(("s", self.uid, peer), cnt * self.nk * len(self.groups))
                 for gi, gp in enumerate(self.groups):
                     base = buf.data_ptr() + gi * cnt * self.nk * buf.element_size()
                     for comp, plan in ph.send[peer].items():
                         plan.run(base, cnt, gp[comp].storage.data_ptr(), ex.sk, self.nk, stream)
                 wire = buf
                 if ex.host_staged:
-                    wire = ex._buffer(("s", id(self), peer), buf.numel(), host=True)
+                    wire = ex._buffer(("s", self.uid, peer), buf.numel(), host=True)
                     wire.copy_(buf)  # synchronous device -> host copy, ordered after the pack kernels
                 ops.append(dist.P2POp(dist.isend, wire, peer, group=ex.group))
             if ops:
@@ -290,16 +456,25 @@ class HaloUpdater:
                 plan.run(gp[dc].storage.data_ptr(), ex.sk, gp[sc].storage.data_ptr(), ex.sk, self.nk, stream)
         self._inflight = reqs
 
-    def wait(self):
+    def wait(self, stream_handle=None):
         ex = self.ex
         if self._inflight is None:
             return
-        ctx, stream = self._on_comm_stream()
+        if ex.native:
+            self._native_call(ex.sf.lib.fv3_halo_plan_wait, stream_handle)
+            self._inflight = None
+            return
+        if ex.comm_stream is not None:
+            ctx, stream = self._on_comm_stream()
+        else:
+            import contextlib
+
+            ctx, stream = contextlib.nullcontext(), (stream_handle if stream_handle else self._stream())
         with ctx:
             self._wait(stream)
         if ex.comm_stream is not None:
             # what follows on the compute stream sees the filled halos
-            torch.cuda.current_stream(ex.sf.device).wait_stream(ex.comm_stream)
+            self._compute_stream(stream_handle).wait_stream(ex.comm_stream)
 
     def _wait(self, stream):
         ex, ph = self.ex, self.ph
@@ -308,7 +483,7 @@ class HaloUpdater:
         for peer, cnt in ph.recv_count.items():
             buf = self._recv_bufs[peer]
             if ex.host_staged:
-                buf.copy_(ex._buffer(("r", id(self), peer), buf.numel(), host=True))
+                buf.copy_(ex._buffer(("r", self.uid, peer), buf.numel(), host=True))
             for gi, gp in enumerate(self.groups):
                 base = buf.data_ptr() + gi * cnt * self.nk * buf.element_size()
                 for comp, plan in ph.recv[peer].items():

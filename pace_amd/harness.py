@@ -115,7 +115,8 @@ class DycoreHarness:
         """Order-fixed float64 sums of the prognostic fields (bitwise comparable between runs of one build)."""
         out = {}
         for n in ("delp", "pt", "u", "v", "w", "delz", "q_con"):
-            v = getattr(self.state, n).view[..., : self.cfg.npz].double()
+            q = getattr(self.state, n)
+            v = torch.stack([q.sub(i).view[...][..., : self.cfg.npz] for i in range(q.n_sub)]).double()
             out[n] = float(v.sum().item())
         return out
 

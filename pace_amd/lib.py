@@ -85,6 +85,23 @@ class fv3_workspace(C.Structure):
     _fields_ = [(n, fv3_field) for n in WORK_FIELDS]
 
 
+class fv3_halo_op(C.Structure):
+    _fields_ = [("plan", C.c_void_p), ("dst", C.c_void_p), ("src", C.c_void_p), ("dst_kstride", C.c_int64), ("src_kstride", C.c_int64), ("buf_off", C.c_int64),
+                ("buf_kstride", C.c_int64), ("peer", C.c_int32), ("kind", C.c_int32), ("nk", C.c_int32), ("reserved", C.c_int32)]
+
+
+class fv3_halo_peer(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("reserved", C.c_int32), ("send_elems", C.c_int64), ("recv_elems", C.c_int64), ("send_buf", C.c_void_p), ("recv_buf", C.c_void_p)]
+
+
+class fv3_nccl_id(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+HALO_LOCAL, HALO_PACK, HALO_UNPACK = 0, 1, 2
+# int (*fv3_xfer_fn)(void *user, fv3_halo_plan *plan, int phase)
+fv3_xfer_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
 # int (*fv3_halo_fn)(void *user, int update, int phase, void *stream)
 fv3_halo_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
 
@@ -129,6 +146,17 @@ _PROTOS = {
     "fv3_gather_plan_create": (C.c_int, [C.c_void_p, P(C.c_void_p), C.c_int64, P(C.c_int64), P(C.c_int64), P(C.c_int8)]),
     "fv3_gather_plan_destroy": (C.c_int, [C.c_void_p]),
     "fv3_gather_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _I, _S]),
+    "fv3_halo_plan_create": (C.c_int, [C.c_void_p, P(C.c_void_p), _I, P(fv3_halo_op), _I, P(fv3_halo_peer)]),
+    "fv3_halo_plan_start": (C.c_int, [C.c_void_p, C.c_void_p, _S]),
+    "fv3_halo_plan_wait": (C.c_int, [C.c_void_p, C.c_void_p, _S]),
+    "fv3_halo_plan_destroy": (C.c_int, [C.c_void_p]),
+    "fv3_halo_plan_buffer": (C.c_int, [C.c_void_p, _I, _I, P(C.c_void_p), P(C.c_int64)]),
+    "fv3_comm_unique_id": (C.c_int, [P(fv3_nccl_id)]),
+    "fv3_ctx_comm_init": (C.c_int, [C.c_void_p, P(fv3_nccl_id), _I, _I]),
+    "fv3_ctx_comm_destroy": (C.c_int, [C.c_void_p]),
+    "fv3_ctx_set_xfer": (C.c_int, [C.c_void_p, fv3_xfer_fn, C.c_void_p]),
+    "fv3_ctx_set_comm_stream": (C.c_int, [C.c_void_p, _I]),
+    "fv3_ctx_set_halo_plans": (C.c_int, [C.c_void_p, P(C.c_void_p), _I]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -62,7 +62,9 @@ class GridSizer:
 
 
 class _View:
-    """``quantity.view[:]``: the compute domain [REF docs/util/state.rst:32-49]."""
+    """``quantity.view[:]``: the compute domain [REF docs/util/state.rst:32-49].  Like ``data`` it has a leading
+    sub-domain axis only when the quantity holds more than one sub-domain; code that must work for any count goes
+    through ``quantity.sub(i).view[...]``."""
 
     def __init__(self, q: "Quantity"):
         self._q = q

@@ -11,8 +11,9 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, init_file, out_dir, nx_tile, layout, nz):
+def _worker(rank, world, init_file, out_dir, nx_tile, layout, nz, native):
     sys.path.insert(0, ROOT)
+    os.environ["FV3_HALO_NATIVE"] = native
     import torch.distributed as dist
 
     from pace_amd.harness import DycoreHarness
@@ -28,9 +29,14 @@ def _worker(rank, world, init_file, out_dir, nx_tile, layout, nz):
     dist.destroy_process_group()
 
 
+# native = "1": the updaters are fv3_halo_plans driven by fv3_acoustic_step itself (no halo callback), the messages move
+# through the host-driven transport (gloo) -- the plans, buffers and start / wait protocol the RCCL transport uses;
+# native = "0": the torch.distributed reference path (Python callback per update)
+@pytest.mark.parametrize("native", ["1", "0"])
 @pytest.mark.parametrize("nx_tile, layout", [(12, (1, 1)), (12, (2, 2))])
-def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, layout):
+def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, layout, native, monkeypatch):
     nz = 5
+    monkeypatch.setenv("FV3_HALO_NATIVE", native)
     sys.path.insert(0, ROOT)
     from pace_amd.harness import DycoreHarness
 
@@ -38,7 +44,7 @@ def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, lay
     h.step()
     ref = h.state.to_arrays(["delp", "pt", "u", "v", "w", "delz"])
     init_file = str(tmp_path / "init")
-    mp.spawn(_worker, args=(2, init_file, str(tmp_path), nx_tile, layout, nz), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, init_file, str(tmp_path), nx_tile, layout, nz, native), nprocs=2, join=True)
     per = len(ref) // 2
     for p in range(2):
         got = np.load(tmp_path / f"proc{p}.npz")

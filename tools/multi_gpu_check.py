@@ -49,11 +49,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = int(os.environ.get("FV3_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (before the first call that initialises the HSA runtime)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
         else:
@@ -66,7 +66,7 @@ def main():
     for n in ("delp", "pt", "u", "v", "w", "delz"):
         q = getattr(h.state, n)
         for i, r in enumerate(h.layout.local_ranks):
-            v = q.view[i][..., : a.nz].double()
+            v = q.sub(i).view[...][..., : a.nz].double()  # (Quantity.view has no sub-domain axis when a process owns ONE sub-domain)
             sums[f"{n}[{r}]"] = (float(v.sum()), float(v.abs().max()))
     if world > 1:
         import torch.distributed as dist
