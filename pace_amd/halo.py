@@ -149,7 +149,21 @@ class HaloExchanger:
             if not sf.hostemu:
                 lib.fv3_ctx_set_comm_stream(sf.ctx, 1 if want else 0)
             if layout.world_size > 1:
-                self._init_transport(group)
+                try:
+                    self._init_transport(group)
+                    ok = 1
+                except Exception as e:  # e.g. librccl.so not loadable: agree on the torch.distributed path instead
+                    ok, why = 0, e
+                import torch.distributed as dist
+
+                flag = torch.tensor([ok], dtype=torch.int32, device=sf.device if dist.get_backend(group) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) == 0:
+                    if layout.proc == 0:
+                        print(f"[pace_amd.halo] native transport unavailable ({why if not ok else 'on another rank'}); using the torch.distributed path", flush=True)
+                    if self.transport == "rccl":
+                        sf.lib.fv3_ctx_comm_destroy(sf.ctx)
+                    self.native, self.transport = False, None
 
     def _init_transport(self, group):
         """RCCL through the library when the process group is nccl (device buffers go straight to ncclSend / ncclRecv on the

@@ -116,8 +116,7 @@ class DycoreHarness:
         out = {}
         for n in ("delp", "pt", "u", "v", "w", "delz", "q_con"):
             q = getattr(self.state, n)
-            v = torch.stack([q.sub(i).view[...][..., : self.cfg.npz] for i in range(q.n_sub)]).double()
-            out[n] = float(v.sum().item())
+            out[n] = float(sum(q.sub(i).view[...][..., : self.cfg.npz].double().sum().item() for i in range(q.n_sub)))
         return out
 
     def sanity(self):

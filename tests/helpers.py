@@ -116,7 +116,10 @@ def run_device_cube(backend, part, cfg, grids, ost_init, phis, timestep, n_calls
     return st.to_arrays(), dyn, st, sf
 
 
-def compare_cubes(got, want, part, nz, names, tol):
+def compare_cubes(got, want, part, nz, names, tol, atol=None):
+    """Field-scale relative comparison: max|a - b| <= tol[name] * max|b| (+ atol[name], an absolute floor in the field's own
+    unit for fields whose scale can be arbitrarily small -- w of a balanced state)."""
+    atol = atol or {}
     worst = {}
     for r in range(part.total_ranks):
         for name in names:
@@ -125,6 +128,7 @@ def compare_cubes(got, want, part, nz, names, tol):
             assert np.all(np.isfinite(a)), f"{name} rank {r}: non-finite"
             sc = np.abs(b).max()
             e = np.abs(a - b).max()
+            e = max(0.0, e - atol.get(name, 0.0))
             worst[name] = max(worst.get(name, 0.0), e / sc if sc > 0 else e)
     bad = {k: v for k, v in worst.items() if v > tol.get(k, tol["default"])}
     assert not bad, f"field-scale relative errors above tolerance: {bad} (all: {worst})"

@@ -282,3 +282,13 @@ def test_del2_cubed_and_diffusive_heating(backend, layout):
     delp, delz, cappa, hs, pt = I(0), I(1), I(2), I(3), I(4)
     dv.sf.call("apply_diffusive_heating", delp.fref, delz.fref, cappa.fref, hs.fref, pt.fref, float(cl[0]["ins"][5]))
     _cmp("pt", pt, cl, 4, CELLS, 1e-14, kk=dv.nz)
+
+
+def test_pair_debug_report(hostemu, capsys):
+    """tests/pair_debug.py (the side-by-side run mode, REF driver.py:83-87 pair_debug): every operator replayed against the
+    oracle on a small cube; the report attributes the worst difference (libm round-off in the Riemann solvers) to its operator."""
+    import pair_debug
+
+    assert pair_debug.main(["--nx", "12", "--nz", "6", "--backend", "hostemu", "--n-split", "2", "--tol", "1e-10"]) == 0
+    out = capsys.readouterr().out
+    assert "riem_solver3" in out and "d_sw" in out and "worst difference" in out

@@ -27,6 +27,12 @@ TOL = {"default": 1e-12, "w": 1e-10, "omga": 1e-10, "delz": 1e-11, "u": 1e-11, "
 # the marching divergence-damping kernel keeps its iterates in registers and leaves uc / vc alone.
 # c_sw's uc / vc outputs are checked in test_c_sw.
 STATE = "u v w ua va delp delz pt pe pk peln q_con omga mfxd mfyd cxd cyd".split()
+# The BASELINE target is 1e-10 field-scale relative.  w (and omga, the C-grid w) come out of the semi-implicit solver behind
+# exp / log of O(1e5 Pa) pressures: libm (numpy) and the device's ocml differ in the last bit there, which is an ABSOLUTE error of
+# ~1e-12 m/s in w whatever its size (tests/pair_debug.py: riem_solver3 w 4e-12 of a 0.1 m/s field).  For states whose w is tiny
+# (the balanced baroclinic wave: |w| ~ 1e-3 m/s; real restart data) the relative measure alone would be a test of libm, so
+# those tests add this absolute floor instead of loosening the relative tolerance:
+W_ATOL = {"w": 2e-12, "omga": 2e-12}  # m/s
 
 
 @pytest.fixture(params=["hostemu", pytest.param("hip:gfx950", marks=pytest.mark.gpu)])
@@ -336,8 +342,7 @@ def test_realistic_restart_values(backend):
     init = [{k: v.copy() for k, v in s.items()} for s in ost]
     odyn(ost, 30.0, 1)
     got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 30.0)
-    tol = dict(TOL, w=1e-9, omga=1e-9)
-    compare_cubes(got, ost, part, nz, ("delp", "pt", "u", "v", "w", "delz", "q_con"), tol)
+    compare_cubes(got, ost, part, nz, ("delp", "pt", "u", "v", "w", "delz", "q_con"), TOL, atol=W_ATOL)
 
 
 def test_baroclinic_wave_state(backend):
@@ -357,8 +362,8 @@ def test_baroclinic_wave_state(backend):
     odyn = OracleAcousticDynamics(part, grids, cfg, get_constants(), phis)
     odyn(ost, 225.0, 1)
     got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0)
-    # w / omga are ~1e-3 m/s here (balanced state): exp/log round-off of the solver is measured against that tiny scale
-    compare_cubes(got, ost, part, nz, STATE, dict(TOL, w=1e-9, omga=1e-9))
+    # w / omga are ~1e-3 m/s here (balanced state): the absolute floor W_ATOL covers the solver's exp / log round-off
+    compare_cubes(got, ost, part, nz, STATE, TOL, atol=W_ATOL)
     # balance: after 225 s the wind changed by a small fraction of u0 = 35 m/s, w stays small, pt within 1e-3 relative
     for r in range(6):
         sl = (slice(3, 3 + nx), slice(3, 3 + nx), slice(0, nz))
