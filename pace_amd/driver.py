@@ -65,6 +65,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None, help="override the number of model steps from the yaml")
     ap.add_argument("--out", default=None, help="performance json (default: <experiment>_fv3_mi355x.json)")
     ap.add_argument("--precision", type=int, default=64)
+    ap.add_argument("--restart", default=None, help="start from restart_dycore_state_<rank>.nc files in this directory [REF driver/pace/driver/state.py:154-172]")
+    ap.add_argument("--save-restart", default=None, help="write restart_dycore_state_<rank>.nc files there after the last step [REF state.py:114-123]")
     a = ap.parse_args(argv)
     run, dy, ignored = load_config(a.config)
 
@@ -103,6 +105,12 @@ def main(argv=None):
                       device=f"cuda:{local_rank}", dtype=dtype, verbose=(rank == 0), init=init, config_overrides={k: v for k, v in dy.items() if k not in ("k_split", "n_split")}, **kw)
     if run["device_sync"]:
         h.sf.set_device_sync(True)
+    if a.restart:
+        from . import restart
+
+        restart.load_state(h.state, h.layout.local_ranks, a.restart)
+        h.dyn._bind(h.state)
+        say(f"state loaded from {a.restart}")
     n_steps = a.steps or run["n_steps"]
     times = []
     for step in range(n_steps):
@@ -112,6 +120,11 @@ def main(argv=None):
         h.synchronize()
         times.append(time.perf_counter() - t0)
     ok = all(v[2] for v in h.sanity().values())
+    if a.save_restart:
+        from . import restart
+
+        restart.save_state(h.state, h.layout.local_ranks, a.save_restart)
+        say(f"restart files written to {a.save_restart}")
     local = {r: times for r in h.layout.local_ranks}
     if world > 1:
         import torch.distributed as dist
@@ -128,10 +141,13 @@ def main(argv=None):
         sdpd = run["dt_atmos"] / mean
         out = a.out or f"{run['experiment']}_fv3_mi355x.json"
         json.dump({"setup": {"experiment": run["experiment"], "nx_tile": run["nx_tile"], "nz": run["nz"], "layout": list(run["layout"]), "dt_atmos": run["dt_atmos"],
-                             "k_split": h.cfg.k_split, "n_split": h.cfg.n_split, "n_gpus": world, "backend": "hip:gfx950", "dycore_only": True, "finite": ok},
-                   "times": {"mainloop": {"times": per_rank, "hits": [len(t) for t in per_rank]}},
-                   "simulated_days_per_day": sdpd}, open(out, "w"))
-        say(f"{n_steps} steps of dt_atmos={run['dt_atmos']:g}s: mainloop mean (first step dropped) {mean * 1e3:.2f} ms -> {sdpd:.2f} simulated-days/day; state finite: {ok}; wrote {out}")
+                             "k_split": h.cfg.k_split, "n_split": h.cfg.n_split, "n_gpus": world, "backend": "hip:gfx950", "dycore_only": True, "acoustic_only": True, "finite": ok,
+                             "note": "a step here is k_split AcousticDynamics calls; the reference's dycore_only mainloop (DynamicalCore.step_dynamics) also runs tracer "
+                                     "advection and the Lagrangian-to-Eulerian remap, which this build does not have: not comparable with the reference's 'mainloop' timer"},
+                   # the reference collector's layout (times.<timer>.times per rank), under a timer name of its own
+                   "times": {"acoustic_mainloop": {"times": per_rank, "hits": [len(t) for t in per_rank]}},
+                   "acoustic_simulated_days_per_day": sdpd}, open(out, "w"))
+        say(f"{n_steps} steps of dt_atmos={run['dt_atmos']:g}s: acoustic mainloop mean (first step dropped) {mean * 1e3:.2f} ms -> {sdpd:.2f} simulated-days/day (acoustic dynamics only); state finite: {ok}; wrote {out}")
     return 0
 
 

@@ -57,6 +57,7 @@ def test_driver_runs_the_reference_c12_config_shape(tmp_path):
     out = tmp_path / "perf.json"
     assert driver.main([str(p), "--steps", "3", "--out", str(out)]) == 0
     d = json.load(open(out))
-    times = d["times"]["mainloop"]["times"]
+    assert "mainloop" not in d["times"] and d["setup"]["acoustic_only"]  # not the reference's full step_dynamics timer
+    times = d["times"]["acoustic_mainloop"]["times"]
     assert len(times) == 6 and all(len(t) == 3 for t in times)  # one entry per rank and step, as the reference collector
-    assert d["setup"]["finite"] and d["simulated_days_per_day"] > 0
+    assert d["setup"]["finite"] and d["acoustic_simulated_days_per_day"] > 0

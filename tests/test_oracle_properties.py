@@ -110,3 +110,18 @@ def test_golden_vectors():
         name, r = key.rsplit("_r", 1)
         got = st[int(r)][name][compute_slice(name, 12, 12, nz)]
         assert np.allclose(got, gold[key], rtol=1e-12, atol=1e-12 * np.abs(gold[key]).max()), key
+
+
+def test_oracle_roundoff_growth_matches_the_reference_thresholds():
+    """The reference calibrates its savepoint thresholds from round-off-perturbed trials of itself and commits the result
+    [REF tests/savepoint/test_checkpoints.py:118-128,161-195; tests/savepoint/thresholds/fv_dynamics.yaml:2-170].  The same
+    procedure on the oracle (tests/threshold_study.py: C12 L79 baroclinic wave, 6 ranks) must amplify last-bit noise by the same
+    orders of magnitude in every comparable C_SW-Out / D_SW-Out variable (within a factor of 10; observed: within 6) -- the one
+    reference-held number the oracle can be held against (it does not pin parity: the reference's data stay external)."""
+    import threshold_study
+
+    rows = threshold_study.main(["--trials", "6"])
+    comparable = {k: v for k, v in rows.items() if v["comparable"] and v["log10_ratio"] is not None}
+    assert len(comparable) >= 18, sorted(comparable)
+    bad = {k: v["log10_ratio"] for k, v in comparable.items() if abs(v["log10_ratio"]) > 1.0}
+    assert not bad, bad
