@@ -523,6 +523,43 @@ __global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(W
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Neighbour reads inside a wave: lane_shr<K>(x) = the value lane - K holds in x (0 below lane 0), lane_shl<K>(x) = lane + K's
+// (0 above lane 63).  On the device these are DPP moves (wave_shr:1 / wave_shl:1 of the GFX9 DPP set, two per fp64 value
+// and shift step): register to register, no LDS line, no ordering point, a few cycles of latency instead of the LDS
+// round trip.  The host emulation reads the neighbour's slot of the per-lane array (the phases of a step run lane by
+// lane there, so the value is complete when it is read).
+// ---------------------------------------------------------------------------------------------
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+FV3_DEV inline int fv3_dpp_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+FV3_DEV inline int fv3_dpp_shl1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+FV3_DEV inline double fv3_dpp_shr1(double v) {
+  return __hiloint2double(fv3_dpp_shr1_i(__double2hiint(v)), fv3_dpp_shr1_i(__double2loint(v)));
+}
+FV3_DEV inline double fv3_dpp_shl1(double v) {
+  return __hiloint2double(fv3_dpp_shl1_i(__double2hiint(v)), fv3_dpp_shl1_i(__double2loint(v)));
+}
+FV3_DEV inline float fv3_dpp_shr1(float v) { return __int_as_float(fv3_dpp_shr1_i(__float_as_int(v))); }
+FV3_DEV inline float fv3_dpp_shl1(float v) { return __int_as_float(fv3_dpp_shl1_i(__float_as_int(v))); }
+template <int K>
+FV3_DEV inline Real lane_shr_dev(Real v) {
+#pragma unroll
+  for (int n = 0; n < K; ++n) v = fv3_dpp_shr1(v);
+  return v;
+}
+template <int K>
+FV3_DEV inline Real lane_shl_dev(Real v) {
+#pragma unroll
+  for (int n = 0; n < K; ++n) v = fv3_dpp_shl1(v);
+  return v;
+}
+#define FV3_LANE_SHR(K, arr, l, lane) lane_shr_dev<K>((arr)[l])
+#define FV3_LANE_SHL(K, arr, l, lane) lane_shl_dev<K>((arr)[l])
+#else
+#define FV3_LANE_SHR(K, arr, l, lane) ((lane) >= (K) ? (arr)[(l) - (K)] : (Real)0)
+#define FV3_LANE_SHL(K, arr, l, lane) ((lane) + (K) < FV3_WAVE ? (arr)[(l) + (K)] : (Real)0)
+#endif
+
 // Rows a marching wave owns (FV3_SEG overrides for experiments).  A segment costs 6 warm-up steps, so longer
 // is cheaper per row as long as the launch still fills the chip many times over: 96 rows when that leaves
 // >= 8 waves per resident slot (C768 on one GPU: 1 % faster than 64, measured), 64 otherwise (the per-GPU loads

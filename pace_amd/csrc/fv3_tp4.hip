@@ -74,6 +74,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
   constexpr bool TR = PART == Q4_EDGE;      // transposed march
   constexpr int WPE = (ROLE == Q4_QUAD || PART == Q4_EDGE) ? 1 : 2;
+  // interior strips: every neighbour read of the step is a wavefront shuffle (DPP), the kernel uses no LDS at all
+#ifdef Q4_NO_DPP
+  constexpr bool DPP = false;
+#else
+  constexpr bool DPP = PART == Q4_INTERIOR;
+#endif
   const Geo g = c->g;
   DswScalars a = a_;
   if (TR) {  // exchange the roles of the two directions
@@ -93,7 +99,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
   const int nseg = TR ? 2 : (nM + seg - 1) / seg;  // transposed: "segment" 0 = the low (W) edge columns, 1 = the high (E) ones
   // LDS: per tracer the two L-sweep row lines (q on the new row, the M-advected q three rows behind), (area flux) * (inner
   // L flux) and the final L flux; shared: the L area flux, the old air mass of row r-3, the tile-edge metric ring
-  const size_t smem = sizeof(Real) * (Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
+  const size_t smem = DPP ? 0 : sizeof(Real) * (Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
   const Geo *gp = c->g_dev;
   const int nh = g.nh, sj32 = g.sj32, go = g.o;
   const int LS = TR ? sj32 : 1, MS = TR ? 1 : sj32;  // element strides of one step along L / along M
@@ -175,6 +181,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     Real cx1[FV3_LPT], cx2[FV3_LPT], cx3[FV3_LPT], xv1[FV3_LPT], xv2[FV3_LPT], xv3[FV3_LPT];
     Real fyin[Q4_NT][FV3_LPT], px[Q4_NT][FV3_LPT];
     Real fxk[Q4_NT][FV3_LPT], fyp[Q4_NT][FV3_LPT];  // L flux of the low L face / M flux of the low M face of cell (lc, r-3)
+    Real sqx[Q4_NT][FV3_LPT], sqi[Q4_NT][FV3_LPT], smb[FV3_LPT], sxv[FV3_LPT];  // DPP form: the values the neighbouring lanes read (q on the new row, the M-advected q, old delp, L area flux)
     unsigned pcol[FV3_LPT];  // in-plane offset of (lc, M coordinate 0)
     bool own_x[FV3_LPT], own_y[FV3_LPT];
 
@@ -224,14 +231,22 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
         w2[n][l] = w3[n][l] = w4[n][l] = w5[n][l] = al_q[n][l] = v2[n][l] = v3[n][l] = v4[n][l] = v5[n][l] = al_v[n][l] = (Real)0;
         cq[n][l] = cv[n][l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
         p_prev[n][l] = fi1[n][l] = fi2[n][l] = fi3[n][l] = fyin[n][l] = px[n][l] = fxk[n][l] = fyp[n][l] = o_dx[n][l] = o_dy[n][l] = (Real)0;
-        if (lane == 0) exf[n][FV3_WAVE] = exp_[n][FV3_WAVE] = (Real)0;
-        if (lane < 3) lq[n][lane] = lqi[n][lane] = lq[n][FV3_WAVE + 3 + lane] = lqi[n][FV3_WAVE + 3 + lane] = (Real)0;
+        sqx[n][l] = sqi[n][l] = (Real)0;
+        if constexpr (!DPP) {
+          if (lane == 0) exf[n][FV3_WAVE] = exp_[n][FV3_WAVE] = (Real)0;
+          if (lane < 3) lq[n][lane] = lqi[n][lane] = lq[n][FV3_WAVE + 3 + lane] = lqi[n][FV3_WAVE + 3 + lane] = (Real)0;
+        }
       Q4_END
-      if (lane == 0) exx[FV3_WAVE] = (Real)0;
+      smb[l] = sxv[l] = (Real)0;
+      if constexpr (!DPP) {
+        if (lane == 0) exx[FV3_WAVE] = (Real)0;
+      }
       nxt[l] = load_row(ca - 3, l, lane);
       nx2[l] = load_row(ca - 2 < r_end ? ca - 2 : r_end, l, lane);
-      if (lane < 32) emr[lane] = (Real)1;
-      exm[lane] = (Real)0;
+      if constexpr (!DPP) {
+        if (lane < 32) emr[lane] = (Real)1;
+        exm[lane] = (Real)0;
+      }
     }
 
     auto march = [&](auto xe_tag) {
@@ -319,13 +334,21 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             const Real pn = yv * fyin[n][l];
             const Real qi = (w2[n][l] * ar3 + p_prev[n][l] - pn) / den_y;
             p_prev[n][l] = pn;
-            lq[n][3 + lane] = qx;
-            lqi[n][3 + lane] = qi;
+            if constexpr (DPP) {
+              sqx[n][l] = qx;
+              sqi[n][l] = qi;
+            } else {
+              lq[n][3 + lane] = qx;
+              lqi[n][3 + lane] = qi;
+            }
           Q4_END
           y_prev[l] = yv;
-          exm[lane] = HAS_AIR ? w2[0][l] : mbk[l];  // old air mass of the cell (lc, r-3)
+          if constexpr (DPP)
+            smb[l] = HAS_AIR ? w2[0][l] : mbk[l];
+          else
+            exm[lane] = HAS_AIR ? w2[0][l] : mbk[l];  // old air mass of the cell (lc, r-3)
         }
-        blk.wave_sync();
+        if constexpr (!DPP) blk.wave_sync();
         // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3
         const int jr = r - 3;
         const bool fx_row = jr >= ca && jr <= cb;
@@ -342,6 +365,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
               auto Qi = [&](int s_) { return lqi[n][s_ - l0 + 6]; };
               auto Mx3 = [&](int s_) { return emr[((r - 3) & 3) * 8 + EI(s_)]; };
               fxout[n] = ppm_flux(Qi, Mx3, cx3[l], lc, Llo, Lhi, npL, hord[n]);
+            } else if constexpr (DPP) {
+              // the six cells around the face from the neighbouring lanes' registers (flux-limiter neighbour reads)
+              fxin[n] = ppm_flux_int(FV3_LANE_SHR(3, sqx[n], l, lane), FV3_LANE_SHR(2, sqx[n], l, lane), FV3_LANE_SHR(1, sqx[n], l, lane), sqx[n][l],
+                                     FV3_LANE_SHL(1, sqx[n], l, lane), FV3_LANE_SHL(2, sqx[n], l, lane), cx, hord[n]);
+              fxout[n] = ppm_flux_int(FV3_LANE_SHR(3, sqi[n], l, lane), FV3_LANE_SHR(2, sqi[n], l, lane), FV3_LANE_SHR(1, sqi[n], l, lane), sqi[n][l],
+                                      FV3_LANE_SHL(1, sqi[n], l, lane), FV3_LANE_SHL(2, sqi[n], l, lane), cx3[l], hord[n]);
             } else {
               const Real *aq = lq[n] + lane, *bq = lqi[n] + lane;
               fxin[n] = ppm_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx, hord[n]);
@@ -349,7 +378,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             }
           Q4_END
           const Real mb = HAS_AIR ? w2[0][l] : mbk[l];                    // old delp(lc, r-3)
-          const Real mw = (lane > 0 ? exm[lane - 1] : (Real)0) + mb;      // + old delp(lc-1, r-3)
+          Real mwest;
+          if constexpr (DPP)
+            mwest = FV3_LANE_SHR(1, smb, l, lane);
+          else
+            mwest = lane > 0 ? exm[lane - 1] : (Real)0;
+          const Real mw = mwest + mb;                                     // + old delp(lc-1, r-3)
           Real vx[Q4_NT];
           Real vm = o_mx[l];  // TRC: the stored air-mass flux of the face
           Q4_EACH(n)
@@ -375,12 +409,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           Q4_END
           Q4_EACH(n)
             fxk[n][l] = vx[n];
-            exf[n][lane] = vx[n];
+            if constexpr (!DPP) exf[n][lane] = vx[n];
             fi3[n][l] = fi2[n][l];
             fi2[n][l] = fi1[n][l];
             fi1[n][l] = fxin[n];
             px[n][l] = xv * fxin[n];
-            exp_[n][lane] = px[n][l];
+            if constexpr (!DPP) exp_[n][lane] = px[n][l];
           Q4_END
           cx3[l] = cx2[l];
           cx2[l] = cx1[l];
@@ -388,19 +422,30 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           xv3[l] = xv2[l];
           xv2[l] = xv1[l];
           xv1[l] = xv;
-          exx[lane] = xv;
+          if constexpr (DPP)
+            sxv[l] = xv;
+          else
+            exx[lane] = xv;
         }
-        blk.wave_sync();
+        if constexpr (!DPP) blk.wave_sync();
         // ---- phase 3: the L-advected q on row r, outer M fluxes at face r-2, final M fluxes, the cell update of (lc, r-3)
         const int jf = r - 2;
         const bool fy_row = jf >= fa && jf <= fb;
         FV3_LANES(blk, lane, l) {
-          const Real x1 = exx[lane + 1];
+          Real x1;
+          if constexpr (DPP)
+            x1 = FV3_LANE_SHL(1, sxv, l, lane);
+          else
+            x1 = exx[lane + 1];
           const Real ar = cur[l].ar;
           const Real den_x = ar + cur[l].xv - x1;
           Real fyout[Q4_NT];
           Q4_EACH(n)
-            const Real p1 = exp_[n][lane + 1];
+            Real p1;
+            if constexpr (DPP)
+              p1 = FV3_LANE_SHL(1, px[n], l, lane);
+            else
+              p1 = exp_[n][lane + 1];
             const Real qj = (cur[l].qy[n] * ar + px[n][l] - p1) / den_x;
             v2[n][l] = v3[n][l];
             v3[n][l] = v4[n][l];
@@ -443,13 +488,21 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
               vy[n] = v;
             }
           Q4_END
+          Real fxe[Q4_NT];  // (read outside the branch below: a shuffle needs the source lane active)
+          Q4_EACH(n)
+            if constexpr (DPP)
+              fxe[n] = FV3_LANE_SHL(1, fxk[n], l, lane);
+            else
+              fxe[n] = exf[n][lane + 1];
+          Q4_END
           if (fx_row && own_y[l]) {
             // flux-form updates of the cell (lc, r-3): low L / M fluxes fxk / fyp, high L flux from lane + 1, high M flux = vy
             // (x terms first, as the reference writes the divergence)
             const unsigned p = pcol[l] + (unsigned)(jr * MS);
             Real up[Q4_NT];
             Q4_EACH(n)
-              const Real dv_ = TR ? (fyp[n][l] - vy[n] + fxk[n][l] - exf[n][lane + 1]) * era[l] : (fxk[n][l] - exf[n][lane + 1] + fyp[n][l] - vy[n]) * era[l];
+              const Real fe = fxe[n];  // L flux of the high L face: the neighbouring lane's
+              const Real dv_ = TR ? (fyp[n][l] - vy[n] + fxk[n][l] - fe) * era[l] : (fxk[n][l] - fe + fyp[n][l] - vy[n]) * era[l];
               up[n] = id == 0 ? w2[n][l] + dv_ : mb * w2[n][l] + dv_;
             Q4_END
             const Real dpn = HAS_AIR ? up[0] : o_dn[l];  // new air mass of the cell
@@ -480,7 +533,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           a2[l] = a1[l];
           a1[l] = cur[l].ar;
         }
-        blk.wave_sync();
+        if constexpr (!DPP) blk.wave_sync();
       };
       // The prefetched rows rotate through three register sets (cur <- nxt <- nx2).  Unrolled by the rotation period the
       // copies are renames (the four-tracer wave, which has the registers); rolled they wait for the row fetched one
