@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FV3_MAX_SUB 32
-#define FV3_ABI_VERSION 1
+#define FV3_ABI_VERSION 2
 
 typedef enum {
   FV3_OK = 0,
@@ -89,6 +89,7 @@ typedef struct {
   const double *corner_extrap; /* [n_sub][4][3] a2b_ord4 cube-corner factors */
   const double *ak, *bk;       /* [nz+1] */
   double da_min, da_min_c;
+  const void *sin_sg5; /* (ABI 2) sine of the grid angle at the cell centre: tracer_2d_1l's Courant bound; may be NULL if unused */
 } fv3_griddata;
 
 /* dycore_config fields the acoustic path reads
@@ -317,6 +318,19 @@ int fv3_ctx_set_halo_plans(fv3_ctx *, fv3_halo_plan *const *plans, int n);
  * timestep = dt_atmos / k_split, n_map = 1..k_split.  halo == NULL: the registered plans (fv3_ctx_set_halo_plans). */
 int fv3_acoustic_step(fv3_ctx *, const fv3_state *state, const fv3_workspace *work, double timestep, int n_map,
                       fv3_halo_fn halo, void *halo_user, void *stream);
+
+/* ---- SURVEY §8f-3 (next row): sub-cycled tracer advection ---------------------------------------------------
+ * TracerAdvection.__call__(tracers, dp1, mfxd, mfyd, cxd, cyd) [REF examples/notebooks/functions.py:916-951,
+ * 1037-1044; savepoint Tracer2D1L, tests/savepoint/thresholds/fv_dynamics.yaml:328-360].  The one global quantity of
+ * the operator is the Courant-number bound: fv3_tracer_2d_1l_cmax returns this process's maximum of
+ * max(|cx|, |cy|) + 1 - sin_sg5 (it synchronises the stream), the host all-reduces it (MAX) and passes
+ * n_split = (int)(1 + cmax).  cxd / cyd / mfxd / mfyd are scaled by 1 / n_split in place and dp1 ends as the air mass
+ * before the last sub-cycle, like the reference's fields (Tracer2D1L-Out).  tracer_halo (may be NULL when n_split == 1):
+ * the halo plan of the tracers, run between sub-cycles.  hord: 5 / 6 (the orders of the transport kernels). */
+int fv3_tracer_2d_1l_cmax(fv3_ctx *, const fv3_field *cxd, const fv3_field *cyd, double *cmax, void *stream);
+int fv3_tracer_2d_1l(fv3_ctx *, int n_tracers, const fv3_field *const *tracers, const fv3_field *dp1,
+                     const fv3_field *mfxd, const fv3_field *mfyd, const fv3_field *cxd, const fv3_field *cyd,
+                     int n_split, int hord, fv3_halo_plan *tracer_halo, void *stream);
 
 /* ---- per-operator timing (HIP events on the operators' stream) --------------------------------- */
 enum fv3_op {

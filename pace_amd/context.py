@@ -82,6 +82,8 @@ class StencilFactory:
             else:
                 t = self._upload2d(name)
             setattr(gd, name, t.data_ptr())
+        if "sin_sg5" in self.grids[0].fields:
+            gd.sin_sg5 = self._upload2d("sin_sg5").data_ptr()
         ce = np.ascontiguousarray(np.stack([g.corner_extrap for g in self.grids]), dtype=np.float64)
         ak = np.ascontiguousarray(self.grids[0].ak, dtype=np.float64)
         bk = np.ascontiguousarray(self.grids[0].bk, dtype=np.float64)

@@ -68,6 +68,7 @@ struct Geo {
   MPtr area, rarea, area_c, rarea_c;
   MPtr cosa, sina, rsina, cosa_u, cosa_v, cosa_s, sina_u, sina_v, rsin_u, rsin_v, rsin2;
   MPtr sin_sg1, sin_sg2, sin_sg3, sin_sg4, cos_sg1, cos_sg2, cos_sg3, cos_sg4;
+  MPtr sin_sg5;  // may be null (only tracer_2d_1l reads it)
   MPtr fC, f0, del6_u, del6_v, divg_u, divg_v;
   const Real *edge_w, *edge_e, *edge_s, *edge_n;
   const Real *corner_extrap;  // [nsub][4][3]

@@ -203,6 +203,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   CP(cos_sg1) CP(cos_sg2) CP(cos_sg3) CP(cos_sg4) CP(fC) CP(f0) CP(del6_u) CP(del6_v) CP(divg_u) CP(divg_v)
   CP(edge_w) CP(edge_e) CP(edge_s) CP(edge_n)
 #undef CP
+  g.sin_sg5 = (MPtr)grid->sin_sg5;  // optional (tracer_2d_1l)
   if (!grid->corner_extrap || !grid->ak || !grid->bk) {
     delete c;
     return fv3_fail(nullptr, FV3_ERR_ARG, "griddata host arrays (corner_extrap, ak, bk) are null");

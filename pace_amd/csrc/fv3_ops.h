@@ -100,6 +100,10 @@ struct DswScalars {
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
 
+// two tracers riding on given mass fluxes (the TRC march alone: tracer_2d_1l): a.q_con / a.pt = the two tracers, a.delp = the
+// old air mass, a.o_delp = the new one, a.fx / a.fy = the mass fluxes, outputs a.o_q_con / a.o_pt; no damping (dn_* off)
+void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
+
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 

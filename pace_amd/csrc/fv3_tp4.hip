@@ -575,3 +575,10 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
     if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
   }
 }
+
+void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a) {
+  int any = 0;
+  for (int t = 0; t < c->g.nsub; ++t) any |= c->g.flags[t];
+  dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
+  if (any & (FV3_W | FV3_E)) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+}

@@ -143,7 +143,7 @@ def make_eta(nz: int) -> Tuple[np.ndarray, np.ndarray]:
 _GRID_2D = (
     "dx dy dxa dya dxc dyc rdx rdy rdxa rdya rdxc rdyc area rarea area_c rarea_c "
     "cosa sina rsina cosa_u cosa_v cosa_s sina_u sina_v rsin_u rsin_v rsin2 "
-    "sin_sg1 sin_sg2 sin_sg3 sin_sg4 cos_sg1 cos_sg2 cos_sg3 cos_sg4 "
+    "sin_sg1 sin_sg2 sin_sg3 sin_sg4 sin_sg5 cos_sg1 cos_sg2 cos_sg3 cos_sg4 "
     "fC f0 del6_u del6_v divg_u divg_v lon lat lon_agrid lat_agrid"
 ).split()
 
@@ -459,6 +459,7 @@ def make_grid(
     for k in range(1, 5):
         put(f"sin_sg{k}", sin[k])
         put(f"cos_sg{k}", cos[k])
+    put("sin_sg5", sin[5])  # cell centre (tracer_2d_1l's Courant-number bound)
     put("fC", fC), put("f0", f0)
     put("del6_u", del6_u), put("del6_v", del6_v), put("divg_u", divg_u), put("divg_v", divg_v)
     put("lon", lon_c), put("lat", lat_c), put("lon_agrid", lon_a), put("lat_agrid", lat_a)

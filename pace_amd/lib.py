@@ -56,6 +56,7 @@ class fv3_griddata(C.Structure):
         ("bk", C.POINTER(C.c_double)),
         ("da_min", C.c_double),
         ("da_min_c", C.c_double),
+        ("sin_sg5", C.c_void_p),
     ]
 
 
@@ -157,6 +158,8 @@ _PROTOS = {
     "fv3_ctx_set_xfer": (C.c_int, [C.c_void_p, fv3_xfer_fn, C.c_void_p]),
     "fv3_ctx_set_comm_stream": (C.c_int, [C.c_void_p, _I]),
     "fv3_ctx_set_halo_plans": (C.c_int, [C.c_void_p, P(C.c_void_p), _I]),
+    "fv3_tracer_2d_1l_cmax": (C.c_int, [C.c_void_p, F, F, P(C.c_double), _S]),
+    "fv3_tracer_2d_1l": (C.c_int, [C.c_void_p, _I, P(F), F, F, F, F, F, _I, _I, C.c_void_p, _S]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

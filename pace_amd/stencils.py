@@ -140,3 +140,72 @@ class HyperdiffusionDamping(_Op):
 class ApplyDiffusiveHeating(_Op):
     def __call__(self, delp, delz, cappa, heat_source, pt, delt_time_factor):
         self.sf.call("apply_diffusive_heating", delp.fref, delz.fref, cappa.fref, heat_source.fref, pt.fref, float(delt_time_factor))
+
+
+class TracerAdvection(_Op):
+    """``tracer_2d_1l``: sub-cycled 2-D advection of the tracers with the mass fluxes / Courant numbers the
+    acoustic sub-steps accumulated.  Constructor and call as the reference's
+    ``TracerAdvection(stencil_factory, quantity_factory, transport, grid_data, comm, tracers)`` /
+    ``tracer_advection(tracers, dp1, mfxd, mfyd, cxd, cyd)`` [REF examples/notebooks/functions.py:916-951, 1037-1044].
+    ``transport`` is a :class:`FiniteVolumeTransport` (its ``hord`` is used; 5 / 6 -- the monotone hord 8 of the reference's
+    dycore configs is not implemented), ``comm`` a :class:`pace_amd.halo.Layout` (or None: all ranks local)."""
+
+    def __init__(self, stencil_factory, quantity_factory=None, transport=None, grid_data=None, comm=None, tracers=None):
+        super().__init__(stencil_factory, quantity_factory, grid_data)
+        self.hord = int(getattr(transport, "hord", 6))
+        self.comm = comm
+        self._halo = None
+        self._updater = None
+        self._bound = None
+        self.n_split = None  # of the last call
+
+    def _tracer_updater(self, tracers):
+        from .halo import HaloExchanger, Layout
+        from .topology import CubedSpherePartitioner
+
+        key = tuple(id(q) for q in tracers.values())
+        if self._bound != key:
+            lay = self.comm
+            if lay is None:
+                cfg = self.sf.config
+                lay = Layout(CubedSpherePartitioner(cfg.npx - 1, tuple(cfg.layout)), 1, 0)
+            if self._halo is None:
+                self._halo = HaloExchanger(self.sf, lay, group=getattr(lay, "group", None))
+            self._updater = self._halo.updater("cell", [(q,) for q in tracers.values()])
+            self._bound = key
+        return self._updater
+
+    def __call__(self, tracers, dp1, x_mass_flux, y_mass_flux, x_courant, y_courant):
+        import ctypes as C
+
+        import torch
+
+        from . import lib as _lib
+
+        sf = self.sf
+        cmax = C.c_double()
+        st = sf.lib.fv3_tracer_2d_1l_cmax(sf.ctx, x_courant.fref, y_courant.fref, C.byref(cmax), sf.stream_handle)
+        if st != 0:
+            raise _lib.Fv3Error("fv3_tracer_2d_1l_cmax failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
+        cm = cmax.value
+        lay = self.comm
+        if lay is not None and lay.world_size > 1:  # the operator's one global quantity: all-reduce MAX over the processes
+            import torch.distributed as dist
+
+            t = torch.tensor([cm], dtype=torch.float64, device=sf.device if dist.get_backend(getattr(lay, "group", None)) == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=getattr(lay, "group", None))
+            cm = float(t.item())
+        n_split = int(1.0 + cm)
+        self.n_split = n_split
+        qs = list(tracers.values())
+        arr = (_lib.F * max(len(qs), 1))(*[C.pointer(q.field) for q in qs])
+        plan = None
+        if n_split > 1:
+            up = self._tracer_updater(tracers)
+            if not up.ex.native:
+                raise _lib.Fv3Error("tracer_2d_1l with sub-cycles needs the native halo plans (FV3_HALO_NATIVE=1)")
+            plan = up._native_plan()
+        st = sf.lib.fv3_tracer_2d_1l(sf.ctx, len(qs), arr, dp1.fref, x_mass_flux.fref, y_mass_flux.fref, x_courant.fref, y_courant.fref, n_split, self.hord, plan,
+                                     sf.stream_handle)
+        if st != 0:
+            raise _lib.Fv3Error(f"fv3_tracer_2d_1l failed ({st}): " + sf.lib.fv3_last_error(sf.ctx).decode())

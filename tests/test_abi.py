@@ -32,7 +32,7 @@ def test_hip_library_exports_every_symbol(precision):
     so.fv3_backend.restype = C.c_char_p
     assert so.fv3_backend() == b"hip:gfx950"
     so.fv3_version.restype = C.c_int
-    assert so.fv3_version() == 1
+    assert so.fv3_version() == 2
 
 
 def test_product_loader_refuses_hostemu(hostemu, monkeypatch):
