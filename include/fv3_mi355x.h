@@ -326,7 +326,8 @@ int fv3_acoustic_step(fv3_ctx *, const fv3_state *state, const fv3_workspace *wo
  * max(|cx|, |cy|) + 1 - sin_sg5 (it synchronises the stream), the host all-reduces it (MAX) and passes
  * n_split = (int)(1 + cmax).  cxd / cyd / mfxd / mfyd are scaled by 1 / n_split in place and dp1 ends as the air mass
  * before the last sub-cycle, like the reference's fields (Tracer2D1L-Out).  tracer_halo (may be NULL when n_split == 1):
- * the halo plan of the tracers, run between sub-cycles.  hord: 5 / 6 (the orders of the transport kernels). */
+ * the halo plan of the tracers, run between sub-cycles.  hord: 5 / 6, or 8 = PPM with the fast monotone constraint
+ * (hord_tr of the reference configs [REF driver/examples/configs/baroclinic_c12.yaml:60]). */
 int fv3_tracer_2d_1l_cmax(fv3_ctx *, const fv3_field *cxd, const fv3_field *cyd, double *cmax, void *stream);
 int fv3_tracer_2d_1l(fv3_ctx *, int n_tracers, const fv3_field *const *tracers, const fv3_field *dp1,
                      const fv3_field *mfxd, const fv3_field *mfyd, const fv3_field *cxd, const fv3_field *cyd,

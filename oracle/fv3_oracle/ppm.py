@@ -85,10 +85,100 @@ def _flux_from_blbr(D, q, c, bl, br, j0, j1, mord, cfl_scale=None):
     return out
 
 
+S11, S14, S15, R3 = 11.0 / 14.0, 4.0 / 7.0, 3.0 / 14.0, 1.0 / 3.0
+
+
+def _pert_ppm_full(bl, br):
+    """pert_ppm(..., iv = 1): the full monotonicity constraint on the (bl, br) pairs of a few cells (tp_core.F90)."""
+    da1 = bl - br
+    da2 = da1 * da1
+    a6da = 3.0 * (bl + br) * da1
+    opposite = bl * br < 0.0
+    nbr = np.where(opposite & (a6da < -da2), -2.0 * bl, br)
+    nbl = np.where(opposite & ~(a6da < -da2) & (a6da > da2), -2.0 * br, bl)
+    return np.where(opposite, nbl, 0.0), np.where(opposite, nbr, 0.0)
+
+
+def xppm8(D: Dom, q, c, j0, j1):
+    """iord = 8 (hord_tr of the reference configs [REF driver/examples/configs/baroclinic_c12.yaml:60]): PPM with Lin's fast
+    monotone constraint -- monotonized slopes dm, edge values from them, bl / br limited to 2 |dm|; the flux always carries
+    the sub-grid correction (no smt5 switch).  Tile edges: one-sided bl / br for the three cells either side + pert_ppm.
+    Restated from GFDL_atmos_cubed_sphere tp_core.F90 (xppm, iord >= 8 branch); PARITY UNPINNED."""
+    S, o = D.sl, D.o
+    npx = D.npx
+    dxa = D.m.dxa
+    is_, ie = D.is_, D.ie
+    dm = np.zeros_like(q)
+    R, Rm, Rp = S(is_ - 2, ie + 2, j0, j1), S(is_ - 3, ie + 1, j0, j1), S(is_ - 1, ie + 3, j0, j1)
+    xt = 0.25 * (q[Rp] - q[Rm])
+    hi = np.maximum(np.maximum(q[Rm], q[R]), q[Rp]) - q[R]
+    lo = q[R] - np.minimum(np.minimum(q[Rm], q[R]), q[Rp])
+    dm[R] = np.copysign(np.minimum(np.minimum(np.abs(xt), hi), lo), xt)
+    is1 = max(3, is_ - 1) if D.west else is_ - 1
+    ie1 = min(npx - 3, ie + 1) if D.east else ie + 1
+    al = np.zeros_like(q)
+    R, Rm = S(is1, ie1 + 1, j0, j1), S(is1 - 1, ie1, j0, j1)
+    al[R] = 0.5 * (q[Rm] + q[R]) + R3 * (dm[Rm] - dm[R])
+    bl, br = np.zeros_like(q), np.zeros_like(q)
+    R, Rp = S(is1, ie1, j0, j1), S(is1 + 1, ie1 + 1, j0, j1)
+    x2 = 2.0 * dm[R]
+    bl[R] = -np.copysign(np.minimum(np.abs(x2), np.abs(al[R] - q[R])), x2)
+    br[R] = np.copysign(np.minimum(np.abs(x2), np.abs(al[Rp] - q[R])), x2)
+
+    def Q(i):
+        return _col(D, q, i, j0, j1)
+
+    def M(i):
+        return _col(D, dxa, i, j0, j1)
+
+    def DM(i):
+        return _col(D, dm, i, j0, j1)
+
+    def AL(i):
+        return _col(D, al, i, j0, j1)
+
+    def put(a, i, v):
+        a[i + o : i + o + 1, j0 + o : j1 + o + 1] = v
+
+    def get(a, i0, i1):
+        return a[i0 + o : i1 + o + 1, j0 + o : j1 + o + 1]
+
+    if D.west:
+        put(br, 2, AL(3) - Q(2))
+        xt = _edge_mean(Q(-1), Q(0), Q(1), Q(2), M(-1), M(0), M(1), M(2))
+        put(bl, 1, xt - Q(1))
+        put(br, 0, xt - Q(0))
+        put(bl, 0, S14 * DM(-1) + S11 * (Q(-1) - Q(0)))
+        xt = S15 * Q(1) + S11 * Q(2) - S14 * DM(2)
+        put(br, 1, xt - Q(1))
+        put(bl, 2, xt - Q(2))
+        nbl, nbr = _pert_ppm_full(get(bl, 0, 2), get(br, 0, 2))
+        bl[0 + o : 3 + o, j0 + o : j1 + o + 1], br[0 + o : 3 + o, j0 + o : j1 + o + 1] = nbl, nbr
+    if D.east:
+        put(bl, npx - 2, AL(npx - 2) - Q(npx - 2))
+        xt = _edge_mean(Q(npx - 2), Q(npx - 1), Q(npx), Q(npx + 1), M(npx - 2), M(npx - 1), M(npx), M(npx + 1))
+        put(br, npx - 1, xt - Q(npx - 1))
+        put(bl, npx, xt - Q(npx))
+        put(br, npx, S11 * (Q(npx + 1) - Q(npx)) - S14 * DM(npx + 1))
+        xt = S15 * Q(npx - 1) + S11 * Q(npx - 2) + S14 * DM(npx - 2)
+        put(br, npx - 2, xt - Q(npx - 2))
+        put(bl, npx - 1, xt - Q(npx - 1))
+        nbl, nbr = _pert_ppm_full(get(bl, npx - 2, npx), get(br, npx - 2, npx))
+        bl[npx - 2 + o : npx + 1 + o, j0 + o : j1 + o + 1], br[npx - 2 + o : npx + 1 + o, j0 + o : j1 + o + 1] = nbl, nbr
+    R0, Rm = S(is_, ie + 1, j0, j1), S(is_ - 1, ie, j0, j1)
+    cc = c[R0]
+    flux = np.where(cc > 0.0, q[Rm] + (1.0 - cc) * (br[Rm] - cc * (bl[Rm] + br[Rm])), q[R0] + (1.0 + cc) * (bl[R0] + cc * (bl[R0] + br[R0])))
+    out = np.zeros_like(q)
+    out[R0] = flux
+    return out
+
+
 def xppm(D: Dom, q, c, j0, j1, iord=6):
     """Flux-form PPM value at x faces i = is..ie+1 on rows j0..j1 (Courant number c)."""
+    if iord == 8:
+        return xppm8(D, q, c, j0, j1)
     if iord not in (5, 6):
-        raise NotImplementedError("oracle restates hord 5/6 only (all reference configs use 6)")
+        raise NotImplementedError("oracle restates hord 5 / 6 / 8 (the reference configs use 6 and, for tracers, 8)")
     S = D.sl
     al = compute_al(D, q, D.m.dxa, j0, j1)
     bl = np.zeros_like(q)

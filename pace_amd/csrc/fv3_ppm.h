@@ -149,3 +149,85 @@ FV3_HD inline Real ppm_flux_int_cfl(Real a, Real b, Real c_, Real d, Real e, Rea
   const PpmCell m = ppm_cell(al_m, al_0, c_, mord), o = ppm_cell(al_0, al_p, d, mord);
   return ppm_face_cfl(m, o, cr, cfl_m, cfl_0);
 }
+
+// ---------------------------------------------------------------------------------------------
+// iord = 8 (hord_tr of the reference configs): PPM with Lin's fast monotone constraint.  Monotonized slopes dm, edge values
+// from them, bl / br limited to 2 |dm|; the flux always carries the sub-grid correction.  Tile edges: one-sided edge values
+// at the three faces either side of the edge, plain bl / br in the three cells either side, then pert_ppm (full constraint).
+// CPU twin: oracle/fv3_oracle/ppm.py xppm8 (restated from tp_core.F90, iord >= 8 branch).
+// ---------------------------------------------------------------------------------------------
+#define PPM_S11 ((Real)(11.0 / 14.0))
+#define PPM_S14 ((Real)(4.0 / 7.0))
+#define PPM_S15 ((Real)(3.0 / 14.0))
+#define PPM_R3 ((Real)(1.0 / 3.0))
+
+FV3_HD inline Real ppm8_dm(Real qm, Real q0, Real qp) {
+  const Real xt = (Real)0.25 * (qp - qm);
+  const Real hi = fv3_max(fv3_max(qm, q0), qp) - q0, lo = q0 - fv3_min(fv3_min(qm, q0), qp);
+  return fv3_sign(fv3_min(fv3_min(fabs(xt), hi), lo), xt);
+}
+
+// edge value at the low face of cell s from q(s-2), q(s-1), q(s), q(s+1) = a, b, c_, d
+template <class M>
+FV3_HD inline Real ppm8_al_win(Real a, Real b, Real c_, Real d, M m, int s, bool lo, bool hi, int np_) {
+  if (lo) {
+    if (s == 0) return c_ + (PPM_S14 * ppm8_dm(a, b, c_) + PPM_S11 * (b - c_));
+    if (s == 1) return ppm_edge_mean(a, b, c_, d, m(-1), m(0), m(1), m(2));
+    if (s == 2) return PPM_S15 * b + PPM_S11 * c_ - PPM_S14 * ppm8_dm(b, c_, d);
+  }
+  if (hi) {
+    if (s == np_ - 1) return PPM_S15 * c_ + PPM_S11 * b + PPM_S14 * ppm8_dm(a, b, c_);
+    if (s == np_) return ppm_edge_mean(a, b, c_, d, m(np_ - 2), m(np_ - 1), m(np_), m(np_ + 1));
+    if (s == np_ + 1) return b + (PPM_S11 * (c_ - b) - PPM_S14 * ppm8_dm(b, c_, d));
+  }
+  return (Real)0.5 * (b + c_) + PPM_R3 * (ppm8_dm(a, b, c_) - ppm8_dm(b, c_, d));
+}
+
+// cells whose bl / br are the plain differences + pert_ppm (the three cells either side of a tile edge)
+FV3_HD inline bool ppm8_edge_cell(int cell, bool lo, bool hi, int np_) { return (lo && cell >= 0 && cell <= 2) || (hi && cell >= np_ - 2 && cell <= np_); }
+
+FV3_HD inline PpmCell ppm8_cell(Real al_lo, Real al_hi, Real q, Real dm, bool edge_cell) {
+  PpmCell c;
+  c.q = q;
+  c.sm = true;
+  if (edge_cell) {
+    Real bl = al_lo - q, br = al_hi - q;
+    if (bl * br < (Real)0) {  // pert_ppm, full constraint
+      const Real da1 = bl - br, da2 = da1 * da1, a6da = (Real)3.0 * (bl + br) * da1;
+      if (a6da < -da2)
+        br = (Real)-2.0 * bl;
+      else if (a6da > da2)
+        bl = (Real)-2.0 * br;
+    } else {
+      bl = br = (Real)0;
+    }
+    c.bl = bl;
+    c.br = br;
+  } else {
+    const Real xt = (Real)2.0 * dm;
+    c.bl = -fv3_sign(fv3_min(fabs(xt), fabs(al_lo - q)), xt);
+    c.br = fv3_sign(fv3_min(fabs(xt), fabs(al_hi - q)), xt);
+  }
+  return c;
+}
+
+// interior face from the six cells q(s-3..s+2) = a..f
+FV3_HD inline Real ppm8_flux_int(Real a, Real b, Real c_, Real d, Real e, Real f, Real cr) {
+  const Real dm_b = ppm8_dm(a, b, c_), dm_c = ppm8_dm(b, c_, d), dm_d = ppm8_dm(c_, d, e), dm_e = ppm8_dm(d, e, f);
+  const Real al_c = (Real)0.5 * (b + c_) + PPM_R3 * (dm_b - dm_c);
+  const Real al_d = (Real)0.5 * (c_ + d) + PPM_R3 * (dm_c - dm_d);
+  const Real al_e = (Real)0.5 * (d + e) + PPM_R3 * (dm_d - dm_e);
+  const PpmCell m = ppm8_cell(al_c, al_d, c_, dm_c, false), o = ppm8_cell(al_d, al_e, d, dm_d, false);
+  return ppm_face(m, o, cr);
+}
+
+// face s with the tile-edge formulas among its cells (per-lane evaluation)
+template <class Q, class M>
+FV3_HD inline Real ppm8_flux(Q q, M m, Real c, int s, bool lo, bool hi, int np_) {
+  auto AL = [&](int t) { return ppm8_al_win(q(t - 2), q(t - 1), q(t), q(t + 1), m, t, lo, hi, np_); };
+  const Real al_m = AL(s - 1), al_0 = AL(s), al_p = AL(s + 1);
+  const Real qm = q(s - 1), q0 = q(s);
+  const PpmCell cm = ppm8_cell(al_m, al_0, qm, ppm8_dm(q(s - 2), qm, q0), ppm8_edge_cell(s - 1, lo, hi, np_));
+  const PpmCell c0 = ppm8_cell(al_0, al_p, q0, ppm8_dm(qm, q0, q(s + 1)), ppm8_edge_cell(s, lo, hi, np_));
+  return ppm_face(cm, c0, c);
+}

@@ -68,7 +68,9 @@ FV3_HD inline void q4_for(F &&f) {
 
 // Naming inside the kernel: L = the lane direction (x for the normal march, y for the transposed one), M = the march
 // direction.  "lc" / "r" are the Fortran-local coordinates along L / M.
-template <int ROLE, int PART>
+// M8: the hord-8 (monotone) reconstruction for every slot (tracer_2d_1l with hord_tr = 8), a separate instantiation so
+// that the hord 5 / 6 kernels of d_sw carry none of it
+template <int ROLE, int PART, bool M8 = false>
 static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
@@ -320,6 +322,13 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             w4[n][l] = w5[n][l];
             w5[n][l] = qy;
             Real al_new;
+            PpmCell co;
+            if constexpr (M8) {
+              const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
+              auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
+              al_new = ppm8_al_win(w2[n][l], w3[n][l], w4[n][l], w5[n][l], My, sy, m_edge && Mlo, m_edge && Mhi, npM);
+              co = ppm8_cell(al_q[n][l], al_new, w3[n][l], ppm8_dm(w2[n][l], w3[n][l], w4[n][l]), ppm8_edge_cell(sy - 1, Mlo, Mhi, npM));
+            } else {
             if (m_edge) {
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
@@ -327,7 +336,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             } else {
               al_new = PPM_P1 * (w3[n][l] + w4[n][l]) + PPM_P2 * (w2[n][l] + w5[n][l]);
             }
-            const PpmCell co = ppm_cell(al_q[n][l], al_new, w3[n][l], hord[n]);
+            co = ppm_cell(al_q[n][l], al_new, w3[n][l], hord[n]);
+            }
             al_q[n][l] = al_new;
             fyin[n][l] = ppm_face(cq[n][l], co, cur[l].cy);
             cq[n][l] = co;
@@ -361,20 +371,22 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
               auto EI = [&](int s_) { return s_ <= 2 ? s_ + 1 : s_ - (npL - 2) + 4; };  // ring column of an edge cell
               auto Qx = [&](int s_) { return lq[n][s_ - l0 + 6]; };
               auto Mx = [&](int s_) { return emr[(r & 3) * 8 + EI(s_)]; };
-              fxin[n] = ppm_flux(Qx, Mx, cx, lc, Llo, Lhi, npL, hord[n]);
+              fxin[n] = M8 ? ppm8_flux(Qx, Mx, cx, lc, Llo, Lhi, npL) : ppm_flux(Qx, Mx, cx, lc, Llo, Lhi, npL, hord[n]);
               auto Qi = [&](int s_) { return lqi[n][s_ - l0 + 6]; };
               auto Mx3 = [&](int s_) { return emr[((r - 3) & 3) * 8 + EI(s_)]; };
-              fxout[n] = ppm_flux(Qi, Mx3, cx3[l], lc, Llo, Lhi, npL, hord[n]);
+              fxout[n] = M8 ? ppm8_flux(Qi, Mx3, cx3[l], lc, Llo, Lhi, npL) : ppm_flux(Qi, Mx3, cx3[l], lc, Llo, Lhi, npL, hord[n]);
             } else if constexpr (DPP) {
               // the six cells around the face from the neighbouring lanes' registers (flux-limiter neighbour reads)
-              fxin[n] = ppm_flux_int(FV3_LANE_SHR(3, sqx[n], l, lane), FV3_LANE_SHR(2, sqx[n], l, lane), FV3_LANE_SHR(1, sqx[n], l, lane), sqx[n][l],
-                                     FV3_LANE_SHL(1, sqx[n], l, lane), FV3_LANE_SHL(2, sqx[n], l, lane), cx, hord[n]);
-              fxout[n] = ppm_flux_int(FV3_LANE_SHR(3, sqi[n], l, lane), FV3_LANE_SHR(2, sqi[n], l, lane), FV3_LANE_SHR(1, sqi[n], l, lane), sqi[n][l],
-                                      FV3_LANE_SHL(1, sqi[n], l, lane), FV3_LANE_SHL(2, sqi[n], l, lane), cx3[l], hord[n]);
+              const Real a0 = FV3_LANE_SHR(3, sqx[n], l, lane), a1_ = FV3_LANE_SHR(2, sqx[n], l, lane), a2_ = FV3_LANE_SHR(1, sqx[n], l, lane), a3_ = sqx[n][l],
+                         a4 = FV3_LANE_SHL(1, sqx[n], l, lane), a5 = FV3_LANE_SHL(2, sqx[n], l, lane);
+              const Real b0 = FV3_LANE_SHR(3, sqi[n], l, lane), b1 = FV3_LANE_SHR(2, sqi[n], l, lane), b2 = FV3_LANE_SHR(1, sqi[n], l, lane), b3 = sqi[n][l],
+                         b4 = FV3_LANE_SHL(1, sqi[n], l, lane), b5 = FV3_LANE_SHL(2, sqi[n], l, lane);
+              fxin[n] = M8 ? ppm8_flux_int(a0, a1_, a2_, a3_, a4, a5, cx) : ppm_flux_int(a0, a1_, a2_, a3_, a4, a5, cx, hord[n]);
+              fxout[n] = M8 ? ppm8_flux_int(b0, b1, b2, b3, b4, b5, cx3[l]) : ppm_flux_int(b0, b1, b2, b3, b4, b5, cx3[l], hord[n]);
             } else {
               const Real *aq = lq[n] + lane, *bq = lqi[n] + lane;
-              fxin[n] = ppm_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx, hord[n]);
-              fxout[n] = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord[n]);
+              fxin[n] = M8 ? ppm8_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx) : ppm_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx, hord[n]);
+              fxout[n] = M8 ? ppm8_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l]) : ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord[n]);
             }
           Q4_END
           const Real mb = HAS_AIR ? w2[0][l] : mbk[l];                    // old delp(lc, r-3)
@@ -452,6 +464,13 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             v4[n][l] = v5[n][l];
             v5[n][l] = qj;
             Real al_new;
+            PpmCell co;
+            if constexpr (M8) {
+              const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
+              auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
+              al_new = ppm8_al_win(v2[n][l], v3[n][l], v4[n][l], v5[n][l], My, sy, m_edge && Mlo, m_edge && Mhi, npM);
+              co = ppm8_cell(al_v[n][l], al_new, v3[n][l], ppm8_dm(v2[n][l], v3[n][l], v4[n][l]), ppm8_edge_cell(sy - 1, Mlo, Mhi, npM));
+            } else {
             if (m_edge) {
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
@@ -459,7 +478,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             } else {
               al_new = PPM_P1 * (v3[n][l] + v4[n][l]) + PPM_P2 * (v2[n][l] + v5[n][l]);
             }
-            const PpmCell co = ppm_cell(al_v[n][l], al_new, v3[n][l], hord[n]);
+            co = ppm_cell(al_v[n][l], al_new, v3[n][l], hord[n]);
+            }
             al_v[n][l] = al_new;
             fyout[n] = ppm_face(cv[n][l], co, cur[l].cy);
             cv[n][l] = co;
@@ -579,6 +599,12 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
 void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a) {
   int any = 0;
   for (int t = 0; t < c->g.nsub; ++t) any |= c->g.flags[t];
-  dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
-  if (any & (FV3_W | FV3_E)) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+  const bool edges = any & (FV3_W | FV3_E);
+  if (a.hord_dp == 8) {
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR, true>(c, s, a);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, true>(c, s, a);
+  } else {
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+  }
 }

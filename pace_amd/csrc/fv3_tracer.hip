@@ -49,7 +49,7 @@ extern "C" int fv3_tracer_2d_1l(fv3_ctx *c, int n_tracers, const fv3_field *cons
                                 const fv3_field *cxd_, const fv3_field *cyd_, int n_split, int hord, fv3_halo_plan *tracer_halo, void *stream) {
   if (!c || n_tracers < 0 || (n_tracers && !tracers)) return FV3_ERR_ARG;
   FV3_FIELD(dp1, dp1_) FV3_FIELD(mfx, mfxd_) FV3_FIELD(mfy, mfyd_) FV3_FIELD(cx, cxd_) FV3_FIELD(cy, cyd_)
-  if (hord != 5 && hord != 6) return fv3_fail(c, FV3_ERR_UNSUPPORTED, "tracer_2d_1l: hord must be 5 or 6 (the monotone hord 8 of the reference configs is not implemented)");
+  if (hord != 5 && hord != 6 && hord != 8) return fv3_fail(c, FV3_ERR_UNSUPPORTED, "tracer_2d_1l: hord must be 5, 6 or 8");
   if (n_split < 1) return fv3_fail(c, FV3_ERR_ARG, "tracer_2d_1l: n_split must be >= 1");
   if (n_split > 1 && !tracer_halo) return fv3_fail(c, FV3_ERR_ARG, "tracer_2d_1l: n_split > 1 needs the tracers' halo plan");
   std::vector<Real *> q(n_tracers);

@@ -147,8 +147,8 @@ class TracerAdvection(_Op):
     acoustic sub-steps accumulated.  Constructor and call as the reference's
     ``TracerAdvection(stencil_factory, quantity_factory, transport, grid_data, comm, tracers)`` /
     ``tracer_advection(tracers, dp1, mfxd, mfyd, cxd, cyd)`` [REF examples/notebooks/functions.py:916-951, 1037-1044].
-    ``transport`` is a :class:`FiniteVolumeTransport` (its ``hord`` is used; 5 / 6 -- the monotone hord 8 of the reference's
-    dycore configs is not implemented), ``comm`` a :class:`pace_amd.halo.Layout` (or None: all ranks local)."""
+    ``transport`` is a :class:`FiniteVolumeTransport` (its ``hord`` is used: 5 / 6, or 8 = the monotone scheme of the
+    reference's dycore configs, ``hord_tr: 8``), ``comm`` a :class:`pace_amd.halo.Layout` (or None: all ranks local)."""
 
     def __init__(self, stencil_factory, quantity_factory=None, transport=None, grid_data=None, comm=None, tracers=None):
         super().__init__(stencil_factory, quantity_factory, grid_data)

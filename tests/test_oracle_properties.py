@@ -125,3 +125,32 @@ def test_oracle_roundoff_growth_matches_the_reference_thresholds():
     assert len(comparable) >= 18, sorted(comparable)
     bad = {k: v["log10_ratio"] for k, v in comparable.items() if abs(v["log10_ratio"]) > 1.0}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("rank", [4, 0])
+def test_oracle_hord8_is_monotone_where_hord6_overshoots(rank):
+    """hord_tr = 8 (PPM with Lin's fast monotone constraint, restated from tp_core.F90): advecting narrow bumps by one step
+    creates no value outside the range of a cell's three upwind-side neighbours and keeps a positive field positive -- in the
+    interior (rank 4 of a 3 x 3 layout) and next to a tile edge (rank 0, bump two cells from the W edge); the unlimited-when-smooth
+    hord 6 overshoots by ~2e-2 on the same data (the test has power)."""
+    from helpers import Case
+
+    from fv3_oracle import ppm
+
+    cs = Case(36, (3, 3), (rank,), nz=3, backend="hostemu")
+    D = cs.doms[0]
+    shp = cs.states[0]["pt"][:, :, :3].shape
+    i = np.arange(shp[0])[:, None, None]
+    q = np.exp(-(((i - 9.0) / 1.3) ** 2)) * np.ones(shp) + np.exp(-(((i - 4.0) / 1.0) ** 2))
+    over = {}
+    for c0 in (0.45, -0.45):
+        c = np.full(shp, c0)
+        for iord in (6, 8):
+            f = ppm.xppm(D, q.copy(), c, D.jsd, D.jed, iord)
+            R, Re, Rw = D.sl(1, D.nx, D.jsd, D.jed), D.sl(2, D.nx + 1, D.jsd, D.jed), D.sl(0, D.nx - 1, D.jsd, D.jed)
+            qn = q[R] + c[R] * (f[R] - f[Re])
+            nb = np.stack([q[Rw], q[R], q[Re]])
+            over[(c0, iord)] = (float(np.maximum(qn - nb.max(0), nb.min(0) - qn).max()), float(qn.min()))
+    for c0 in (0.45, -0.45):
+        assert over[(c0, 8)][0] <= 1e-14 and over[(c0, 8)][1] > 0.0, over
+        assert over[(c0, 6)][0] > 1e-3, over

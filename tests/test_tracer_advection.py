@@ -74,8 +74,9 @@ def test_oracle_keeps_a_constant_tracer_constant_and_conserves_tracer_mass():
     assert abs(m1 - m0) <= 1e-13 * abs(m0)
 
 
+@pytest.mark.parametrize("hord", [6, 8])
 @pytest.mark.parametrize("n, layout, want_split, n_tracers", [(12, (1, 1), 1, 2), (12, (1, 1), 2, 3), (12, (2, 2), 3, 1), (65, (1, 1), 1, 2)])
-def test_tracer_advection_matches_the_oracle(backend, n, layout, want_split, n_tracers):
+def test_tracer_advection_matches_the_oracle(backend, n, layout, want_split, n_tracers, hord):
     """n_split = 1 and > 1 (Courant numbers scaled up), even / odd tracer counts, 2 x 2 ranks, multi-strip sub-domains."""
     nz = 4
     part, cfg, grids, odyn, tr, F = _inputs(n, layout, nz, want_split, n_tracers)
@@ -84,9 +85,9 @@ def test_tracer_advection_matches_the_oracle(backend, n, layout, want_split, n_t
     pad = lambda a: np.concatenate([a, a[:, :, -1:]], axis=2)  # noqa: E731
     Q = {k: qf.from_array([pad(a) for a in v], ("x", "y", "z")) for k, v in F.items()}
     T = {name: qf.from_array([pad(t_[name]) for t_ in tr], ("x", "y", "z")) for name in tr[0]}
-    op = TracerAdvection(sf, qf, FiniteVolumeTransport(sf, qf, grids, hord=6), grids, Layout(part, 1, 0), T)
+    op = TracerAdvection(sf, qf, FiniteVolumeTransport(sf, qf, grids, hord=hord), grids, Layout(part, 1, 0), T)
     op(T, Q["dp1"], Q["mfx"], Q["mfy"], Q["cx"], Q["cy"])
-    ns = o_t2.tracer_2d_1l(odyn.doms, tr, F["dp1"], F["mfx"], F["mfy"], F["cx"], F["cy"], 6, halo_update=lambda fs: odyn.ex.scalar(fs))
+    ns = o_t2.tracer_2d_1l(odyn.doms, tr, F["dp1"], F["mfx"], F["mfy"], F["cx"], F["cy"], hord, halo_update=lambda fs: odyn.ex.scalar(fs))
     assert op.n_split == ns == want_split
     for r, D in enumerate(odyn.doms):
         C = D.sl(1, D.nx, 1, D.ny)
