@@ -129,9 +129,10 @@ class OracleAcousticDynamics:
         ex.scalar(F("pt"))
         ex.vector(F("u"), F("v"), "dgrid")
         for r in range(self.nranks):
-            if n_map == 1:
-                for n in ("mfxd", "mfyd", "cxd", "cyd"):
-                    states[r][n][...] = 0.0
+            # every call: the accumulators cover one call, which the tracer advection after it consumes (dyn_core.F90: "Empty the
+            # flux capacitors"); n_map only matters for what the caller does with end_step
+            for n in ("mfxd", "mfyd", "cxd", "cyd"):
+                states[r][n][...] = 0.0
             self.tmp[r]["heat_source"][...] = 0.0
             states[r]["diss_estd"][...] = 0.0
         for it in range(n_split):

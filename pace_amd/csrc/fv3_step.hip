@@ -117,7 +117,10 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   HALO(FV3_HALO_DELP__PT, 0);
   HALO(FV3_HALO_U__V, 0);
   HALO(FV3_HALO_Q_CON__CAPPA, 1);
-  if (n_map == 1) {
+  // "Empty the flux capacitors" (dyn_core.F90): the accumulated mass fluxes / Courant numbers cover ONE call -- the tracer
+  // advection that follows each call consumes exactly them (dp2 = dp1 + div(mfx) must be the air mass after this call)
+  (void)n_map;
+  {
     RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfxd, stream));
     RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfyd, stream));
     RUN(FV3_OP_GLUE, fv3_zero(c, &st->cxd, stream));

@@ -262,9 +262,8 @@ class AcousticDynamics:
         up["u__v"].start()
         up["q_con__cappa"].wait()
         if update_temporaries:
-            if n_map == 1:
-                for q in (state.mfxd, state.mfyd, state.cxd, state.cyd):
-                    sf.call("zero", q.fref)
+            for q in (state.mfxd, state.mfyd, state.cxd, state.cyd):  # every call ("empty the flux capacitors")
+                sf.call("zero", q.fref)
             sf.call("zero", self._heat_source.fref)
             sf.call("zero", state.diss_estd.fref)
         for it in range(n_split):

@@ -56,6 +56,8 @@ class DycoreHarness:
         verbose: bool = False,
         config_overrides: Optional[dict] = None,
         init: str = "synthetic",
+        n_tracers: int = 0,
+        hord_tr: int = 8,
     ):
         self.c = get_constants()
         self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
@@ -98,6 +100,20 @@ class DycoreHarness:
         # shared D-grid interface winds must be single-valued across sub-domains (they are in any
         # physical state; the per-rank white noise of the synthetic recipe breaks it)
         self.dyn._updaters["interface_u__v"].update()
+        # tracers advected after every acoustic call with the mass fluxes / Courant numbers it accumulated
+        # (DynamicalCore.step_dynamics without the vertical remap, which this build does not have)
+        self.tracers = {}
+        if n_tracers:
+            from .stencils import FiniteVolumeTransport, TracerAdvection
+
+            qf = self.sf.quantity_factory
+            for t in range(n_tracers):
+                q = qf.zeros(("x", "y", "z"), "kg/kg")
+                q.storage.copy_(self.state.q_con.storage * (10.0 * (t + 1)) + 1.0e-3 * (t + 1))
+                self.tracers[f"tracer{t}"] = q
+            self.dp1 = qf.zeros(("x", "y", "z"), "Pa")
+            self.tracer_advection = TracerAdvection(self.sf, qf, FiniteVolumeTransport(self.sf, qf, self.grids, hord=hord_tr), self.grids, self.layout, self.tracers)
+            self._tracer_halo = self.dyn.halo.updater("cell", [(q,) for q in self.tracers.values()])
         self.cells_local = self.part.nx * self.part.ny * nz * len(self.grids)
         self.cells_global = nx_tile * nx_tile * 6 * nz
 
@@ -105,7 +121,12 @@ class DycoreHarness:
         """One model step of the dycore-only driver: k_split acoustic-dynamics calls."""
         dt = self.cfg.dt_atmos / self.cfg.k_split
         for k in range(self.cfg.k_split):
+            if self.tracers:
+                self.dp1.storage.copy_(self.state.delp.storage)  # the air mass the accumulated mass fluxes start from
             self.dyn(self.state, dt, n_map=k + 1)
+            if self.tracers:
+                self._tracer_halo.update()
+                self.tracer_advection(self.tracers, self.dp1, self.state.mfxd, self.state.mfyd, self.state.cxd, self.state.cyd)
 
     def synchronize(self):
         if not self.sf.hostemu:
