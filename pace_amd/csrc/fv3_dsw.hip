@@ -844,7 +844,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     Real *dpn = c->scratch[SC_N], *w_dp = c->scratch[SC_O], *qc_dp = c->scratch[SC_P], *pt_dp = c->scratch[SC_Q];
     {
       // cx += crx, cy += cry happen in fxadv; mfx += fx, mfy += fy in the store stage of this transport
-      const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y};
+      const TpEpi e{dpn, nullptr, true, mfx, mfy, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, dA_x, dA_y, nullptr, nullptr, nullptr, nullptr, nullptr};
       fv3_wait(c, s, 1);
       tp2d(c, s, delp, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_dp, &dn_vt, 0, nz1, &e);
       fv3_signal(c, s, 5);
@@ -1090,19 +1090,23 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     });
   }
 
-  // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
-  //      transport kernel's epilogue (the vorticity fluxes are never stored)
-  {
-    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr};
-    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
-  }
-
-  // ---- del-n damping of the relative vorticity, heat from the damped kinetic energy
+  // ---- del-n damping fluxes of the relative vorticity (they depend on wk alone): ahead of the transport, whose wind
+  //      epilogue applies them
   Real *utd = c->scratch[SC_E], *vtd = c->scratch[SC_F];  // (the tracer-flux slots: free since the tracer transports are done)
   {
     Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
     del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, nz1);
   }
+  // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
+  //      transport kernel's epilogue (the vorticity fluxes are never stored), and so is the vorticity damping
+  //      u += vtd, v -= utd on the levels that have it; the winds BEFORE that damping -- what the damping heat is
+  //      formed from -- go to scratch beside
+  Real *u_pre = c->scratch[SC_N], *v_pre = c->scratch[SC_O];
+  {
+    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
+    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
+  }
+
   const bool heat_on = cf.d_con > 1.0e-5;
   // (two levels per thread: the six metric terms are read once)
   launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
@@ -1123,8 +1127,8 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
         const Real vd00 = (vdamp + b)[p], vd10 = (vdamp + b)[pe_], vd01 = (vdamp + b)[pn], vd11 = (vdamp + b)[pne];
         const Real ub0 = (vd00 - vd10 + (vtd + b)[p]) * rdx0, ub1 = (vd01 - vd11 + (vtd + b)[pn]) * rdx1;
         const Real vb0 = (vd00 - vd01 - (utd + b)[p]) * rdy0, vb1 = (vd10 - vd11 - (utd + b)[pe_]) * rdy1;
-        const Real fy0 = (u + b)[p] * rdx0, fy1 = (u + b)[pn] * rdx1;
-        const Real fx0 = (v + b)[p] * rdy0, fx1 = (v + b)[pe_] * rdy1;
+        const Real fy0 = (u_pre + b)[p] * rdx0, fy1 = (u_pre + b)[pn] * rdx1;
+        const Real fx0 = (v_pre + b)[p] * rdy0, fx1 = (v_pre + b)[pe_] * rdy1;
         const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
         const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
         hs = (delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
@@ -1132,12 +1136,6 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       }
       if (heat_on) (heat_source + b)[p] += hs;
     }
-  });
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
-    if (!(g.damp_vt[k] > (Real)1.0e-5)) return;
-    const long p = t * g.st + k * g.sk + IX(i, j);
-    if (i <= g.nx) u[p] += vtd[p];
-    if (j <= g.ny) v[p] -= utd[p];
   });
   return fv3_post(c, s, "d_sw");
 }

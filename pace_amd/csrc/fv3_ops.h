@@ -74,6 +74,11 @@ struct TpEpi {
   // damping fluxes of q already computed by the caller (del6_vt_flux into these arrays): fv_tp_2d then does
   // not run the del-n chain itself (d_sw computes them one transport ahead on the auxiliary stream)
   const Real *damp_fx, *damp_fy;
+  // wind epilogue only (optional): d_sw's vorticity damping applied in the same store,
+  //   u = (u * dx + ke - ke[i+1] + fy) + wind_du,   v = (v * dy + ke - ke[j+1] - fx) - wind_dv     on the levels with wind_don[k] > 1e-5,
+  // while the pre-damping values (what the damping-heat kernel differentiates) go to wind_u_pre / wind_v_pre
+  const Real *wind_du, *wind_dv, *wind_don;
+  Real *wind_u_pre, *wind_v_pre;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

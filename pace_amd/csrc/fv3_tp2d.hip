@@ -518,6 +518,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   Real *acc_x = epi ? epi->acc_x : nullptr, *acc_y = epi ? epi->acc_y : nullptr;
   Real *wind_u = epi ? epi->wind_u : nullptr, *wind_v = epi ? epi->wind_v : nullptr;
   const Real *wind_ke = epi ? epi->wind_ke : nullptr;
+  const Real *wind_du = epi ? epi->wind_du : nullptr, *wind_dv = epi ? epi->wind_dv : nullptr, *wind_don = epi ? epi->wind_don : nullptr;
+  Real *wind_u_pre = epi ? epi->wind_u_pre : nullptr, *wind_v_pre = epi ? epi->wind_v_pre : nullptr;
   const MPtr rarea = g.rarea, gdx = g.dx, gdy = g.dy;
   // The hot loop touches only these scalars; everything the rare paths need (cube-corner remaps,
   // tile-edge metric terms) is read through gp inside those paths, so it does not occupy SGPRs
@@ -536,6 +538,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real *const acc_x_ = C_ACC ? acc_x : nullptr, *const acc_y_ = C_ACC ? acc_y : nullptr;
     Real *const wind_u_ = C_WIND ? wind_u : nullptr, *const wind_v_ = C_WIND ? wind_v : nullptr;
     const Real *const wind_ke_ = C_WIND ? wind_ke : nullptr;
+    const Real *const wind_du_ = C_WIND ? wind_du : nullptr, *const wind_dv_ = C_WIND ? wind_dv : nullptr;
+    Real *const wind_u_pre_ = C_WIND ? wind_u_pre : nullptr, *const wind_v_pre_ = C_WIND ? wind_v_pre : nullptr;
     const bool wflux_ = C_WFLUX && wflux, area_form_ = C_AREA && area_form;
     const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
     const int fl = gp->flags[t];
@@ -577,6 +581,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
     const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
+    Real wdu[FV3_LPT], wdv[FV3_LPT];  // vorticity-damping increments of u (face r-2) / v (row r-3)
+    const bool wdamp = C_WIND && wind_du != nullptr && wind_don[k] > (Real)1.0e-5;
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real a1[FV3_LPT], a2[FV3_LPT], a3[FV3_LPT];  // area of rows r-1, r-2, r-3 (a delay line instead of a second load of the metric)
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
@@ -616,7 +622,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       w2[l] = w3[l] = w4[l] = w5[l] = al_q[l] = v2[l] = v3[l] = v4[l] = v5[l] = al_v[l] = (Real)0;
       a1[l] = a2[l] = a3[l] = (Real)1;  // (warm-up steps: outputs masked, keep the divisions finite)
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
-      wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = (Real)0;
+      wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = wdu[l] = wdv[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
@@ -674,6 +680,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               wv[l] = (wind_v_ + b)[p3];
               wdy[l] = (gdy + m2)[p3];
               wkr[l] = (wind_ke_ + b)[p3];      // ke(i, jr)
+              if (wdamp) {
+                wdu[l] = (wind_du_ + b)[pf];
+                wdv[l] = (wind_dv_ + b)[p3];
+              }
             }
           }
           cur[l] = nxt[l];
@@ -748,7 +758,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               (fx + b)[p] = v;
               if (acc_x_) (acc_x_ + b)[p] = o_ax[l] + v;
             }
-            if (wind_v_ && fx_row && own_x[l]) (wind_v_ + b)[pcol[l] + (unsigned)(jr * sj32)] = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
+            if (wind_v_ && fx_row && own_x[l]) {
+              const unsigned p = pcol[l] + (unsigned)(jr * sj32);
+              const Real vn = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
+              if (wind_v_pre_) (wind_v_pre_ + b)[p] = vn;
+              (wind_v_ + b)[p] = wdamp ? vn - wdv[l] : vn;
+            }
             if (epi_out_) {
               fxk[l] = v;
               exf[lane] = v;
@@ -803,7 +818,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               (fy + b)[p] = v;
               if (acc_y_) (acc_y_ + b)[p] = o_ay[l] + v;
             }
-            if (wind_u_ && fy_row && own_y[l]) (wind_u_ + b)[pcol[l] + (unsigned)(jf * sj32)] = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
+            if (wind_u_ && fy_row && own_y[l]) {
+              const unsigned p = pcol[l] + (unsigned)(jf * sj32);
+              const Real un = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
+              if (wind_u_pre_) (wind_u_pre_ + b)[p] = un;
+              (wind_u_ + b)[p] = wdamp ? un + wdu[l] : un;
+            }
             if (epi_out_) {
               // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
               if (fx_row && own_y[l]) {
@@ -907,13 +927,24 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
     const Real *zfx_ = epi->zfx, *zfy_ = epi->zfy, *zon_ = epi->zon;
     Real *wu_ = epi->wind_u, *wv_ = epi->wind_v;
     const Real *wk_ = epi->wind_ke;
+    const Real *wdu_ = epi->wind_du, *wdv_ = epi->wind_dv, *wdon_ = epi->wind_don;
+    Real *wup_ = epi->wind_u_pre, *wvp_ = epi->wind_v_pre;
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, k0, k1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long b = t * g.st + k * g.sk;
       const unsigned p = IX(i, j);
       if (wu_) {
         const long m2 = t * g.st2;
-        if (i <= g.nx) (wu_ + b)[p] = (wu_ + b)[p] * (g.dx + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i + 1, j)] + (fy + b)[p];
-        if (j <= g.ny) (wv_ + b)[p] = (wv_ + b)[p] * (g.dy + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i, j + 1)] - (fx + b)[p];
+        const bool wd = wdu_ && wdon_[k] > (Real)1.0e-5;
+        if (i <= g.nx) {
+          const Real un = (wu_ + b)[p] * (g.dx + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i + 1, j)] + (fy + b)[p];
+          if (wup_) (wup_ + b)[p] = un;
+          (wu_ + b)[p] = wd ? un + (wdu_ + b)[p] : un;
+        }
+        if (j <= g.ny) {
+          const Real vn = (wv_ + b)[p] * (g.dy + m2)[p] + (wk_ + b)[p] - (wk_ + b)[IX(i, j + 1)] - (fx + b)[p];
+          if (wvp_) (wvp_ + b)[p] = vn;
+          (wv_ + b)[p] = wd ? vn - (wdv_ + b)[p] : vn;
+        }
       }
       if (out && i <= g.nx && j <= g.ny) {
         const unsigned pe_ = IX(i + 1, j), pn = IX(i, j + 1);
