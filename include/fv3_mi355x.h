@@ -333,6 +333,18 @@ int fv3_tracer_2d_1l(fv3_ctx *, int n_tracers, const fv3_field *const *tracers, 
                      const fv3_field *mfxd, const fv3_field *mfyd, const fv3_field *cxd, const fv3_field *cyd,
                      int n_split, int hord, fv3_halo_plan *tracer_halo, void *stream);
 
+/* LagrangianToEulerian (the vertical remap that closes DynamicalCore.step_dynamics) [REF driver/pace/driver/driver.py:494-504,
+ * 639-644; savepoint Remapping: tests/savepoint/thresholds/fv_dynamics.yaml:227-326; kord_tm -9, kord_mt / kord_tr / kord_wz 9,
+ * consv_te 0: driver/examples/configs/baroclinic_c12.yaml:45,65-68].  In place: pt (the loop's theta_v / pkz form), delp, delz,
+ * u, v, w and the tracers go from the Lagrangian layers (interfaces = pe / peln as the last acoustic sub-step left them,
+ * pe's one-cell halo ring by edge_pe) to the Eulerian ones ak + bk * ps; pe, peln, pk, pkz and ps (2-D) are rebuilt.
+ * Configuration of the reference configs: non-hydrostatic, T_v remapped in log(p), kord 9 everywhere, moist-cappa pkz with
+ * the given cappa field, no energy fixer, no saturation adjustment, no fillz, omga untouched; nz >= 5. */
+int fv3_remap(fv3_ctx *, int n_tracers, const fv3_field *const *tracers, const fv3_field *pt, const fv3_field *delp,
+              const fv3_field *delz, const fv3_field *peln, const fv3_field *pe, const fv3_field *pk, const fv3_field *pkz,
+              const fv3_field *u, const fv3_field *v, const fv3_field *w, const fv3_field *cappa, const fv3_field *ps,
+              const fv3_field *wsd, void *stream);
+
 /* ---- per-operator timing (HIP events on the operators' stream) --------------------------------- */
 enum fv3_op {
   FV3_OP_C_SW = 0,

@@ -134,6 +134,7 @@ struct fv3_ctx {
   fv3_xfer_fn xfer = nullptr;
   void *xfer_user = nullptr;
   fv3_halo_plan *halo_plans[FV3_HALO_COUNT] = {nullptr};
+  Real *ak_dev = nullptr, *bk_dev = nullptr;  // hybrid-coordinate tables on the device (fv3_remap.hip)
   // per-operator profiling (fv3_step.hip)
   int profiling = 0;
   struct ProfEvent {

@@ -160,6 +160,7 @@ _PROTOS = {
     "fv3_ctx_set_halo_plans": (C.c_int, [C.c_void_p, P(C.c_void_p), _I]),
     "fv3_tracer_2d_1l_cmax": (C.c_int, [C.c_void_p, F, F, P(C.c_double), _S]),
     "fv3_tracer_2d_1l": (C.c_int, [C.c_void_p, _I, P(F), F, F, F, F, F, _I, _I, C.c_void_p, _S]),
+    "fv3_remap": (C.c_int, [C.c_void_p, _I, P(F)] + [F] * 13 + [_S]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

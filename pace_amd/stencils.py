@@ -209,3 +209,21 @@ class TracerAdvection(_Op):
                                      sf.stream_handle)
         if st != 0:
             raise _lib.Fv3Error(f"fv3_tracer_2d_1l failed ({st}): " + sf.lib.fv3_last_error(sf.ctx).decode())
+
+
+class LagrangianToEulerian(_Op):
+    """The vertical remap that closes ``DynamicalCore.step_dynamics`` (reference operator pyFV3
+    ``LagrangianToEulerian``, savepoint ``Remapping`` [REF tests/savepoint/thresholds/fv_dynamics.yaml:227-326]).  Call with the
+    state's quantities; everything is remapped in place (see ``fv3_remap`` in include/fv3_mi355x.h for the configuration)."""
+
+    def __call__(self, tracers, pt, delp, delz, peln, pe, pk, pkz, u, v, w, cappa, ps, wsd):
+        import ctypes as C
+
+        from . import lib as _lib
+
+        qs = list(tracers.values()) if tracers else []
+        arr = (_lib.F * max(len(qs), 1))(*[C.pointer(q.field) for q in qs])
+        st = self.sf.lib.fv3_remap(self.sf.ctx, len(qs), arr, pt.fref, delp.fref, delz.fref, peln.fref, pe.fref, pk.fref, pkz.fref, u.fref, v.fref, w.fref, cappa.fref,
+                                   ps.fref, wsd.fref, self.sf.stream_handle)
+        if st != 0:
+            raise _lib.Fv3Error(f"fv3_remap failed ({st}): " + self.sf.lib.fv3_last_error(self.sf.ctx).decode())

@@ -1,0 +1,101 @@
+"""the Lagrangian-to-Eulerian vertical remap -- properties of the C oracle (oracle/remap_oracle.c) and the library
+(fv3_remap) against it.  Reference operator: pyFV3 LagrangianToEulerian, savepoint Remapping
+[REF tests/savepoint/thresholds/fv_dynamics.yaml:227-326]; kord 9 / -9, consv_te 0 [REF driver/examples/configs/baroclinic_c12.yaml:45,65-68]."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, oracle_cube
+from pace_amd.constants import get_constants
+from pace_amd.context import StencilFactory
+from pace_amd.stencils import LagrangianToEulerian
+
+from fv3_oracle import remap as o_remap
+
+
+@pytest.fixture(params=["hostemu", pytest.param("hip:gfx950", marks=pytest.mark.gpu)])
+def backend(request):
+    request.getfixturevalue("hostemu" if request.param == "hostemu" else "gpu_backend")
+    return request.param
+
+
+def _column(km=40, seed=1):
+    rng = np.random.default_rng(seed)
+    dp = np.linspace(30.0, 1500.0, km) * (1.0 + 0.15 * rng.random(km))
+    pe1 = np.concatenate([[64.0], 64.0 + np.cumsum(dp)])
+    frac = np.linspace(0.0, 1.0, km + 1) ** 1.15
+    pe2 = pe1[0] + (pe1[-1] - pe1[0]) * frac
+    return rng, pe1, pe2
+
+
+@pytest.mark.parametrize("iv", [1, 0, -1])
+def test_oracle_remap_conserves_is_identity_and_bounded(iv):
+    """map1_ppm / map_scalar (kord 9): the column integral is conserved to round-off, remapping onto the same interfaces is the
+    identity, a constant stays constant, the result stays within the range of the input (monotone sub-grid profiles), and a
+    positive-definite scalar (iv = 0) stays positive next to a sharp front."""
+    rng, pe1, pe2 = _column()
+    km = len(pe1) - 1
+    q1 = 280.0 + 20.0 * np.sin(np.arange(km) / 3.0) + rng.random(km) if iv != 0 else np.where(np.arange(km) > km // 2, 1.0e-3, 0.0) + 1e-9 * rng.random(km)
+    if iv == -1:
+        q1 = q1 - 290.0
+    q2 = o_remap.remap_column(pe1, q1, pe2, iv=iv)
+    m1, m2 = (q1 * np.diff(pe1)).sum(), (q2 * np.diff(pe2)).sum()
+    assert abs(m1 - m2) <= 1e-13 * max(abs(m1), np.abs(q1 * np.diff(pe1)).sum())
+    assert np.abs(o_remap.remap_column(pe1, q1, pe1, iv=iv) - q1).max() <= 1e-12 * np.abs(q1).max()
+    assert np.abs(o_remap.remap_column(pe1, np.full(km, 3.5), pe2, iv=iv) - 3.5).max() < 1e-14
+    # kord 9 limits with Huynh's second constraint: no new extrema beyond a small fraction of the input's range (it is not the
+    # strictly monotone kord 7-8 family), and none at all for the positive-definite form
+    slack = 0.02 * (q1.max() - q1.min())
+    assert q2.min() >= q1.min() - slack and q2.max() <= q1.max() + slack
+    if iv == 0:
+        assert q2.min() >= 0.0
+
+
+def _inputs(n, layout, nz, n_tracers):
+    """State after one oracle acoustic call (so the levels are genuinely Lagrangian), plus smooth tracers."""
+    part, cfg, grids, ost, phis, odyn = oracle_cube(n, layout, nz, dict(n_split=2))
+    odyn(ost, 900.0, 1)
+    tr = []
+    for s in ost:
+        tr.append([np.ascontiguousarray(s["q_con"] * 1e3 * (t + 1) + 1e-3) for t in range(n_tracers)])
+    rng = np.random.default_rng(5)  # no topography in this case -> ws would be 0: perturb it so that the lower boundary of w is exercised
+    wsd = [t["wsd"].copy() + 1e-3 * (rng.random(t["wsd"].shape) - 0.5) for t in odyn.tmp]
+    for s in ost:  # pkz consistent with the state (the acoustic path does not maintain it)
+        s["pkz"][...] = 1.0
+    return part, cfg, grids, odyn, ost, tr, wsd
+
+
+@pytest.mark.parametrize("n, layout, n_tracers", [(12, (1, 1), 2), (12, (2, 2), 1)])
+def test_remap_matches_the_oracle(backend, n, layout, n_tracers):
+    nz = 12
+    part, cfg, grids, odyn, ost, tr, wsd = _inputs(n, layout, nz, n_tracers)
+    c = get_constants()
+    sf = StencilFactory(grids, cfg, c, backend=backend)
+    qf = sf.quantity_factory
+    names = ("pt", "delp", "delz", "peln", "pe", "pk", "pkz", "u", "v", "w", "cappa")
+    Q = {k: qf.from_array([s[k] for s in ost], ("x", "y", "z")) for k in names}
+    T = {f"q{t}": qf.from_array([tr[r][t] for r in range(len(ost))], ("x", "y", "z")) for t in range(n_tracers)}
+    ps = qf.zeros(("x", "y"))
+    W = qf.from_array([w_[:, :, 0] for w_ in wsd], ("x", "y"))
+    mass0 = [(s["delp"][3 : 3 + part.nx, 3 : 3 + part.ny, :nz]).sum(axis=2) for s in ost]
+    tm0 = [(tr[r][0][3 : 3 + part.nx, 3 : 3 + part.ny, :nz] * ost[r]["delp"][3 : 3 + part.nx, 3 : 3 + part.ny, :nz]).sum(axis=2) for r in range(len(ost))]
+    LagrangianToEulerian(sf, qf, grids)(T, *[Q[k] for k in names], ps, W)
+    for r, D in enumerate(odyn.doms):
+        o_ps = o_remap.lagrangian_to_eulerian(D, c, ost[r], wsd[r], tr[r])
+        C = D.sl(1, D.nx, 1, D.ny)
+        for k, tol in (("delp", 1e-13), ("pt", 1e-12), ("delz", 1e-12), ("w", 1e-11), ("pe", 1e-14), ("peln", 1e-14), ("pk", 1e-13), ("pkz", 1e-12)):
+            kk = nz + 1 if k in ("pe", "peln", "pk") else nz
+            assert_close(f"{k} rank {r}", Q[k].numpy(r)[C][:, :, :kk], ost[r][k][C][:, :, :kk], tol, 0.0)
+        assert_close("u", Q["u"].numpy(r)[D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz], ost[r]["u"][D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz], 1e-12, 0.0)
+        assert_close("v", Q["v"].numpy(r)[D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz], ost[r]["v"][D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz], 1e-12, 0.0)
+        for t in range(n_tracers):
+            assert_close(f"tracer {t}", T[f"q{t}"].numpy(r)[C][:, :, :nz], tr[r][t][C][:, :, :nz], 1e-12, 0.0)
+        assert_close("ps", ps.numpy(r)[C], o_ps[C], 1e-14, 0.0)
+        # properties of the result itself: column air mass and tracer mass conserved, levels Eulerian (ak + bk ps)
+        dp = Q["delp"].numpy(r)[3 : 3 + part.nx, 3 : 3 + part.ny, :nz]
+        assert np.abs(dp.sum(axis=2) - mass0[r]).max() <= 1e-12 * mass0[r].max()
+        tm1 = (T["q0"].numpy(r)[3 : 3 + part.nx, 3 : 3 + part.ny, :nz] * dp).sum(axis=2)
+        assert np.abs(tm1 - tm0[r]).max() <= 1e-12 * np.abs(tm0[r]).max()
+        g = grids[r]
+        pe_new = Q["pe"].numpy(r)[3 : 3 + part.nx, 3 : 3 + part.ny, : nz + 1]
+        want = g.ak[None, None, :] + g.bk[None, None, :] * pe_new[:, :, -1:]
+        assert np.abs(pe_new[:, :, 1:-1] - want[:, :, 1:-1]).max() <= 1e-12 * pe_new.max()
