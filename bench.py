@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--n-split", type=int, default=None, help="override (profiling runs only; changes the workload)")
     ap.add_argument("--tracers", type=int, default=0, help="also advect N tracers after every acoustic call (tracer_2d_1l, hord_tr 8): a separate, "
                     "clearly named workload -- the headline metric is the acoustic dynamics alone")
+    ap.add_argument("--remap", action="store_true", help="also run the Lagrangian-to-Eulerian vertical remap after every acoustic call (+ tracer advection): "
+                    "with --tracers the body of DynamicalCore.step_dynamics; a separate, clearly named workload")
     a = ap.parse_args()
 
     from pace_amd.harness import CONFIGS, DycoreHarness
@@ -161,7 +163,7 @@ def main():
     if (6 * kw["layout"][0] * kw["layout"][1]) % world:
         sys.exit(f"{a.config} has {6 * kw['layout'][0] * kw['layout'][1]} sub-domains: not divisible over {world} GPUs")
     dtype = torch.float64 if a.precision == 64 else torch.float32
-    h = DycoreHarness(world_size=world, proc=rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), n_tracers=a.tracers, **kw)
+    h = DycoreHarness(world_size=world, proc=rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), n_tracers=a.tracers, remap=a.remap, **kw)
 
     # ---- per-operator HIP-event timing: fv3_acoustic_step brackets every operator with an event
     #      pair on the stream it launches on (fv3_ctx_set_profiling / fv3_profile_read)
@@ -222,8 +224,10 @@ def main():
             "config": {
                 "workload": f"C{kw['nx_tile']} L{kw['nz']} layout {kw['layout'][0]}x{kw['layout'][1]} ({h.part.total_ranks} sub-domains of {h.part.nx}^2, {len(h.grids)} per GPU), "
                 f"dt_atmos {cfg.dt_atmos:g} s, k_split {cfg.k_split}, n_split {cfg.n_split}, "
-                + (f"acoustic dynamics + tracer advection of {a.tracers} tracers after every acoustic call (tracer_2d_1l, hord_tr 8; no vertical remap, no physics)" if a.tracers
-                   else "dycore-only acoustic dynamics (no tracer/remap/physics)"),
+                + ("acoustic dynamics"
+                   + (f" + tracer advection of {a.tracers} tracers after every acoustic call (tracer_2d_1l, hord_tr 8)" if a.tracers else "")
+                   + (" + Lagrangian-to-Eulerian remap (kord 9) after every acoustic call" if a.remap else "")
+                   + "; no physics" if (a.tracers or a.remap) else "dycore-only acoustic dynamics (no tracer/remap/physics)"),
                 "sub_steps_per_step": n_sub_steps,
                 "cells_global": h.cells_global,
             },

@@ -257,7 +257,8 @@ void remap_rank(const remap_geom *g, const double *ak, const double *bk, double 
       for (k = 0; k < nz; ++k) q1[k] = -AT(delz, i, j, k) / AT(delp, i, j, k);
       remap_column(nz, pe1, q1, pe2, q2, 1, 0.0, 0, 0.0);
       for (k = 0; k < nz; ++k) AT(delz, i, j, k) = -q2[k] * dp2[k];
-      /* Eulerian pressures; pkz from the remapped T_v; pt back to the loop's form */
+      /* Eulerian pressures; pkz = p^cappa of the full (non-hydrostatic) pressure rho R T_v from the remapped T_v [moist_pkz]; pt back to the
+       * loop's form T_v / pkz.  (The conversion at the top has the exponent cappa / (1 - cappa) because it starts from pt = T_v / pkz.) */
       for (k = 0; k <= nz; ++k) {
         AT(pe, i, j, k) = pe2[k];
         AT(peln, i, j, k) = pn2[k];
@@ -266,7 +267,7 @@ void remap_rank(const remap_geom *g, const double *ak, const double *bk, double 
       ps[(size_t)i * g->nj + j] = psv;
       for (k = 0; k < nz; ++k) {
         const double cp = AT(cappa, i, j, k);
-        const double pz = exp(cp / (1.0 - cp) * log(g->rrg * dp2[k] / AT(delz, i, j, k) * AT(pt, i, j, k)));
+        const double pz = exp(cp * log(g->rrg * dp2[k] / AT(delz, i, j, k) * AT(pt, i, j, k)));
         AT(pkz, i, j, k) = pz;
         AT(pt, i, j, k) = AT(pt, i, j, k) / pz;
       }

@@ -326,7 +326,7 @@ extern "C" int fv3_remap(fv3_ctx *c, int n_tracers, const fv3_field *const *trac
       const Real p1 = k + 1 == km ? psv : ak[k + 1] + bk[k + 1] * psv;
       const Real dp2 = p1 - p0;
       const Real cp = RK(cappa, k), tv = RK(TV, k);
-      const Real pz = exp(cp / ((Real)1.0 - cp) * log(rrg * dp2 / RK(delz, k) * tv));
+      const Real pz = exp(cp * log(rrg * dp2 / RK(delz, k) * tv));
       RK(pkz, k) = pz;
       RK(pt, k) = tv / pz;
       RK(delp, k) = dp2;

@@ -67,6 +67,8 @@ def main(argv=None):
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--restart", default=None, help="start from restart_dycore_state_<rank>.nc files in this directory [REF driver/pace/driver/state.py:154-172]")
     ap.add_argument("--save-restart", default=None, help="write restart_dycore_state_<rank>.nc files there after the last step [REF state.py:114-123]")
+    ap.add_argument("--tracers", type=int, default=0, help="advect N synthetic tracers after every acoustic call (TracerAdvection, hord_tr from the yaml)")
+    ap.add_argument("--remap", action="store_true", help="Lagrangian-to-Eulerian remap after every acoustic call (with --tracers: the body of DynamicalCore.step_dynamics)")
     a = ap.parse_args(argv)
     run, dy, ignored = load_config(a.config)
 
@@ -81,7 +83,9 @@ def main(argv=None):
     if run["backend"] not in ("hip:gfx950", "hip"):
         say(f"backend {run['backend']!r} requested by the yaml -> running 'hip:gfx950' (the only backend of this build)")
     if not (run["dycore_only"] and run["disable_step_physics"]):
-        say("physics / tracer advection / remapping are outside this build: running the dycore-only acoustic loop")
+        say("physics is outside this build: running the dycore-only loop")
+    say("step = k_split x [acoustic dynamics" + (f", advection of {a.tracers} tracers" if a.tracers else "") + (", vertical remap" if a.remap else "") + "]"
+        + ("" if (a.tracers and a.remap) else "  (--tracers N --remap add the rest of step_dynamics)"))
     if run["init"] == "analytic" and str(run["case"]).startswith("baroclinic"):
         init = "baroclinic"
         say("initialization: JW2006 baroclinic wave (pace_amd.init.baroclinic_state; restated from the paper, see its docstring)")
@@ -102,7 +106,8 @@ def main(argv=None):
     dtype = torch.float64 if a.precision == 64 else torch.float32
     kw = {k: dy[k] for k in ("k_split", "n_split") if k in dy}
     h = DycoreHarness(nx_tile=run["nx_tile"], nz=run["nz"], layout=run["layout"], dt_atmos=run["dt_atmos"], world_size=world, proc=rank,
-                      device=f"cuda:{local_rank}", dtype=dtype, verbose=(rank == 0), init=init, config_overrides={k: v for k, v in dy.items() if k not in ("k_split", "n_split")}, **kw)
+                      device=f"cuda:{local_rank}", dtype=dtype, verbose=(rank == 0), init=init, config_overrides={k: v for k, v in dy.items() if k not in ("k_split", "n_split")},
+                      n_tracers=a.tracers, hord_tr=int(dy.get("hord_tr", 8)), remap=a.remap, **kw)
     if run["device_sync"]:
         h.sf.set_device_sync(True)
     if a.restart:
@@ -141,7 +146,7 @@ def main(argv=None):
         sdpd = run["dt_atmos"] / mean
         out = a.out or f"{run['experiment']}_fv3_mi355x.json"
         json.dump({"setup": {"experiment": run["experiment"], "nx_tile": run["nx_tile"], "nz": run["nz"], "layout": list(run["layout"]), "dt_atmos": run["dt_atmos"],
-                             "k_split": h.cfg.k_split, "n_split": h.cfg.n_split, "n_gpus": world, "backend": "hip:gfx950", "dycore_only": True, "acoustic_only": True, "finite": ok,
+                             "k_split": h.cfg.k_split, "n_split": h.cfg.n_split, "n_gpus": world, "backend": "hip:gfx950", "dycore_only": True, "acoustic_only": not (a.tracers or a.remap), "tracers": a.tracers, "remap": bool(a.remap), "finite": ok,
                              "note": "a step here is k_split AcousticDynamics calls; the reference's dycore_only mainloop (DynamicalCore.step_dynamics) also runs tracer "
                                      "advection and the Lagrangian-to-Eulerian remap, which this build does not have: not comparable with the reference's 'mainloop' timer"},
                    # the reference collector's layout (times.<timer>.times per rank), under a timer name of its own

@@ -2,9 +2,10 @@
 one process owns and steps them -- the slice of ``Driver._critical_path_step_all`` that reaches
 the hot path with ``dycore_only: true, disable_step_physics: true``
 [REF driver/pace/driver/driver.py:627-662; .jenkins/driver_configs/baroclinic_c48_6ranks_dycore_only.yaml:1-2].
-One "step" = ``k_split`` calls of AcousticDynamics (no tracer advection / remapping / physics --
-out of scope), timed like the reference ("mainloop" timer, first step dropped
-[REF .jenkins/print_performance_number.py:13-14]).
+One "step" = ``k_split`` calls of AcousticDynamics, timed like the reference ("mainloop" timer, first step dropped
+[REF .jenkins/print_performance_number.py:13-14]).  The headline workload is the acoustic loop alone; ``n_tracers`` adds the
+sub-cycled tracer advection after every acoustic call and ``remap`` the Lagrangian-to-Eulerian remap after that (SURVEY §8f-3:
+together the body of ``DynamicalCore.step_dynamics``; no physics, no moist thermodynamics).
 """
 from __future__ import annotations
 
@@ -58,6 +59,7 @@ class DycoreHarness:
         init: str = "synthetic",
         n_tracers: int = 0,
         hord_tr: int = 8,
+        remap: bool = False,
     ):
         self.c = get_constants()
         self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
@@ -101,7 +103,6 @@ class DycoreHarness:
         # physical state; the per-rank white noise of the synthetic recipe breaks it)
         self.dyn._updaters["interface_u__v"].update()
         # tracers advected after every acoustic call with the mass fluxes / Courant numbers it accumulated
-        # (DynamicalCore.step_dynamics without the vertical remap, which this build does not have)
         self.tracers = {}
         if n_tracers:
             from .stencils import FiniteVolumeTransport, TracerAdvection
@@ -114,11 +115,18 @@ class DycoreHarness:
             self.dp1 = qf.zeros(("x", "y", "z"), "Pa")
             self.tracer_advection = TracerAdvection(self.sf, qf, FiniteVolumeTransport(self.sf, qf, self.grids, hord=hord_tr), self.grids, self.layout, self.tracers)
             self._tracer_halo = self.dyn.halo.updater("cell", [(q,) for q in self.tracers.values()])
+        self.remap = None
+        if remap:
+            from .stencils import LagrangianToEulerian
+
+            self.remap = LagrangianToEulerian(self.sf, self.sf.quantity_factory, self.grids)
+            self.ps = self.sf.quantity_factory.zeros(("x", "y"), "Pa")
         self.cells_local = self.part.nx * self.part.ny * nz * len(self.grids)
         self.cells_global = nx_tile * nx_tile * 6 * nz
 
     def step(self):
-        """One model step of the dycore-only driver: k_split acoustic-dynamics calls."""
+        """One model step of the dycore-only driver: k_split acoustic-dynamics calls (each followed by tracer advection and the
+        vertical remap where the harness was built with them)."""
         dt = self.cfg.dt_atmos / self.cfg.k_split
         for k in range(self.cfg.k_split):
             if self.tracers:
@@ -127,6 +135,9 @@ class DycoreHarness:
             if self.tracers:
                 self._tracer_halo.update()
                 self.tracer_advection(self.tracers, self.dp1, self.state.mfxd, self.state.mfyd, self.state.cxd, self.state.cyd)
+            if self.remap is not None:
+                s = self.state
+                self.remap(self.tracers, s.pt, s.delp, s.delz, s.peln, s.pe, s.pk, s.pkz, s.u, s.v, s.w, s.cappa, self.ps, self.dyn._wsd)
 
     def synchronize(self):
         if not self.sf.hostemu:
