@@ -11,6 +11,7 @@
 // against the oracle in the GPU-less build container.  The host-emulation build is test
 // infrastructure: the product loader refuses it (see pace_amd/lib.py).
 #pragma once
+#include <type_traits>
 #include <algorithm>
 
 #include <cmath>
@@ -560,6 +561,84 @@ FV3_DEV inline Real lane_shl_dev(Real v) {
 #else
 #define FV3_LANE_SHR(K, arr, l, lane) ((lane) >= (K) ? (arr)[(l) - (K)] : (Real)0)
 #define FV3_LANE_SHL(K, arr, l, lane) ((lane) + (K) < FV3_WAVE ? (arr)[(l) + (K)] : (Real)0)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Several adjacent columns per lane (CPL): a wave then covers FV3_WAVE * CPL "virtual lanes", virtual lane vl = lane * CPL + l.
+// Why: the marching kernels issue one 8-byte load / store per column and field, and at fp64 a CU retires such a wave
+// instruction only every ~30-45 cycles (measured: the interior c_sw march moved 2.8 TB/s with 76 % of its wave cycles
+// waiting to issue).  With two columns per lane the compiler merges the pair into one 16-byte access: half the vector-memory
+// instructions per point, half the shuffles (the neighbour of slot 1 is the lane's own slot 0).
+// Kernels declare per-lane state as arrays [FV3_VLPT(CPL)] and write phases as
+//   FV3_VLANES(CPL, blk, vl, l) ... state[l] ... FV3_VLANES_END
+// (on the device a compile-time loop over the CPL slots, so that `l` is a constant expression; the host emulation runs the
+// virtual lanes one after the other).  FV3_VSHR / FV3_VSHL(CPL, K, arr, l, vl) = the value virtual lane vl -/+ K holds in arr.
+// Bodies must not `continue` / `break` / `return` (the device form is a lambda).
+// ---------------------------------------------------------------------------------------------
+#ifdef FV3_HOST_EMU
+#define FV3_VLPT(CPL) (FV3_WAVE * (CPL))
+#define FV3_VLANES(CPL, blk, vl, l) for (int vl = 0; vl < FV3_WAVE * (CPL); ++vl) { const int l = vl; (void)l;
+#define FV3_VLANES_END }
+#define FV3_VSHR(CPL, K, arr, l, vl) ((vl) >= (K) ? (arr)[(l) - (K)] : (Real)0)
+#define FV3_VSHL(CPL, K, arr, l, vl) ((vl) + (K) < FV3_WAVE * (CPL) ? (arr)[(l) + (K)] : (Real)0)
+#else
+#define FV3_VLPT(CPL) (CPL)
+template <int N0, int N1, class F>
+FV3_HD inline void fv3_cpl_for(F &&f) {
+  if constexpr (N0 < N1) {
+    f(std::integral_constant<int, N0>{});
+    fv3_cpl_for<N0 + 1, N1>(f);
+  }
+}
+#define FV3_VLANES(CPL, blk, vl, l) fv3_cpl_for<0, CPL>([&](auto l##_c) { constexpr int l = decltype(l##_c)::value; const int vl = (blk).tid * (CPL) + l; (void)vl;
+#define FV3_VLANES_END });
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CPL, int K, int L>
+FV3_DEV inline Real fv3_vshr(const Real (&arr)[CPL]) {
+  constexpr int d = L - K;                                 // source slot, counted from this lane's slot 0
+  constexpr int sh = d >= 0 ? 0 : (-d + CPL - 1) / CPL;    // lanes to the left
+  return lane_shr_dev<sh>(arr[d + sh * CPL]);
+}
+template <int CPL, int K, int L>
+FV3_DEV inline Real fv3_vshl(const Real (&arr)[CPL]) {
+  constexpr int d = L + K, sh = d / CPL;                   // lanes to the right
+  return lane_shl_dev<sh>(arr[d - sh * CPL]);
+}
+#define FV3_VSHR(CPL, K, arr, l, vl) fv3_vshr<CPL, K, l>(arr)
+#define FV3_VSHL(CPL, K, arr, l, vl) fv3_vshl<CPL, K, l>(arr)
+#else
+#define FV3_VSHR(CPL, K, arr, l, vl) ((arr)[0])  // (host pass of hipcc: never executed)
+#define FV3_VSHL(CPL, K, arr, l, vl) ((arr)[0])
+#endif
+// the CPL adjacent values of a lane as ONE access (16 bytes for two fp64 columns; only element alignment is promised)
+typedef Real fv3_real2 __attribute__((ext_vector_type(2)));
+typedef fv3_real2 fv3_real2u __attribute__((aligned(sizeof(Real))));
+template <int CPL>
+FV3_HD inline void fv3_ld_cpl(Real (&dst)[CPL], const Real *p) {
+  if constexpr (CPL == 2) {
+    const fv3_real2 v = *(const fv3_real2u *)p;
+    dst[0] = v.x;
+    dst[1] = v.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) dst[q] = p[q];
+  }
+}
+template <int CPL>
+FV3_HD inline void fv3_st_cpl(Real *p, const Real (&src)[CPL], const bool (&own)[CPL]) {
+  if constexpr (CPL == 2) {
+    if (own[0] && own[1]) {
+      fv3_real2 v;
+      v.x = src[0];
+      v.y = src[1];
+      *(fv3_real2u *)p = v;
+      return;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < CPL; ++q)
+    if (own[q]) p[q] = src[q];
+}
 #endif
 
 // Rows a marching wave owns (FV3_SEG overrides for experiments).  A segment costs 6 warm-up steps, so longer

@@ -66,6 +66,266 @@ FV3_HD inline Real edge_interp4(Real u1, Real u2, Real u3, Real u4, Real d1, Rea
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Stages A + B + C on the interior rectangle of every sub-domain as ONE marching wave kernel.
+// The three stages read nothing but (u, v): utmp (4-point in j) lives in a 4-row register window of u, vtmp
+// (4-point in i) comes from wavefront shuffles of the v row, uc is a shuffle of utmp, vc a window of vtmp, and the corner
+// divergence needs the 2 x 2 block of ua / va around the corner -- the row before from registers, the column before by
+// shuffle.  A lane therefore loads 2 values per point where the two-row stage kernel loaded 20 and the divergence kernel
+// re-read u, v, ua, va; ua / va / uc / vc / ut / vt / divgd are each written once.
+// Geometry: a lane carries CSW_CPL = 2 adjacent columns (one 16-byte access per field row: FV3_VLANES in fv3_common.h), a
+// strip owns CSW_OUT = 124 columns (virtual lanes 2..125; 0, 1, 126, 127 are the reach of the shuffles), a segment `seg`
+// rows; step R loads row R and finishes ua / va / uc / ut and the corner divergence of row R-2, vc / vt of row R-1.
+// Only points whose whole stencil uses the interior formulas are produced here (the same rectangle as before:
+// 6 cells away from a cube-tile edge); the generic stage kernels keep the four windows along the sub-domain boundary.
+// ---------------------------------------------------------------------------------------------
+#ifndef CSW_CPL
+#define CSW_CPL 2
+#endif
+#define CSW_NV (FV3_WAVE * CSW_CPL)
+#define CSW_OUT (CSW_NV - 4)
+#ifndef CSW_WPE
+#define CSW_WPE 2
+#endif
+#define CSW_LPT FV3_VLPT(CSW_CPL)
+#define CSW_LANES(vl, l) FV3_VLANES(CSW_CPL, blk, vl, l)
+#define CSW_SHR(K, arr) FV3_VSHR(CSW_CPL, K, arr, l, vl)
+#define CSW_SHL(K, arr) FV3_VSHL(CSW_CPL, K, arr, l, vl)
+struct CswRect {
+  int i_lo, i_hi, j_lo, j_hi;
+};
+FV3_HD inline CswRect csw_rect(int fl, int nx, int ny, int npx, int npy) {
+  CswRect r;
+  r.i_lo = (fl & FV3_W) ? 6 : 0;
+  r.i_hi = (fl & FV3_E) ? npx - 5 : nx + 1;
+  r.j_lo = (fl & FV3_S) ? 6 : 0;
+  r.j_hi = (fl & FV3_N) ? npy - 5 : ny + 1;
+  return r;
+}
+
+static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, Real *ua, Real *va, Real *uc, Real *vc, Real *ut, Real *vt, Real *divgd,
+                           Real dt2, bool do_div) {
+  const Geo g = c->g;
+  const Geo *gp = c->g_dev;
+  const int nk = g.nz;
+  const int nstrip = (g.nx + 2 + CSW_OUT - 1) / CSW_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * CSW_CPL * ((g.ny + 63) / 64) * g.nsub * nk, CSW_WPE);
+  const int nseg = (g.ny + 2 + seg - 1) / seg;
+  const int sj32 = g.sj32, go = g.o, nx = g.nx, ny = g.ny, npx = g.npx, npy = g.npy, nh = g.nh;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const MPtr m_cosa_s = g.cosa_s, m_rsin2 = g.rsin2, m_cosa_u = g.cosa_u, m_rsin_u = g.rsin_u, m_dy = g.dy, m_sin3 = g.sin_sg3, m_sin1 = g.sin_sg1;
+  const MPtr m_cosa_v = g.cosa_v, m_rsin_v = g.rsin_v, m_dx = g.dx, m_sin4 = g.sin_sg4, m_sin2 = g.sin_sg2;
+  const MPtr m_cos4 = g.cos_sg4, m_cos2 = g.cos_sg2, m_dyc = g.dyc, m_cos3 = g.cos_sg3, m_cos1 = g.cos_sg1, m_dxc = g.dxc, m_rac = g.rarea_c;
+  // Launch geometry: the "plane" an XCD walks (fv3_grid) is one (sub-domain, strip, segment) tile and the tiles of the plane are
+  // its levels, so the waves resident on an XCD are all the levels of a few tiles and share the metric rows in that XCD's L2.
+  const int ntile = nstrip * nseg;
+#ifdef CSW_EXP_PLANE
+  launch_waves<CSW_WPE>(c, s, nstrip, nseg, nk * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
+    const int t = blk.bz / nk, k = blk.bz - t * nk, tby = blk.by, tbx = blk.bx;
+    (void)ntile;
+#else
+  launch_waves<CSW_WPE>(c, s, nk, 1, ntile * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
+    const int k = blk.bx, t = blk.bz / ntile, tile = blk.bz - t * ntile;
+    const int tby = tile / nstrip, tbx = tile - tby * nstrip;
+#endif
+    const CswRect rc = csw_rect(gp->flags[t], nx, ny, npx, npy);
+    const int c0 = rc.i_lo + tbx * CSW_OUT;
+    const int ja = rc.j_lo + tby * seg;
+    if (c0 > rc.i_hi || ja > rc.j_hi) return;
+    const int jb = ja + seg - 1 < rc.j_hi ? ja + seg - 1 : rc.j_hi;
+    const long b = t * st + k * sk, m2 = t * st2;
+    const Real *ub = u + b, *vb = v + b;
+    const int Led = nx + nh, Msd = 1 - nh;
+    const unsigned pbase = (unsigned)(go * sj32 + go);
+    const int r_end = jb + 2;
+
+    // per (virtual) lane: windows of u / v (rows R-3 .. R) and vtmp, rows R+1 / R+2 in flight, the metric terms of the
+    // step (rows R-2: cs .. c4, R-1: cv .. s2) and of the next one, values carried from the step before
+    Real u0[CSW_LPT], u1[CSW_LPT], u2[CSW_LPT], u3[CSW_LPT], v0[CSW_LPT], v1[CSW_LPT], v2[CSW_LPT], v3[CSW_LPT];
+    Real t0[CSW_LPT], t1[CSW_LPT], t2[CSW_LPT], t3[CSW_LPT];
+    Real nu1[CSW_LPT], nv1[CSW_LPT], nu2[CSW_LPT], nv2[CSW_LPT];
+    Real s_ut[CSW_LPT], s_v[CSW_LPT], s_ua[CSW_LPT], s_uf[CSW_LPT];  // values the neighbouring lanes read
+    Real uav[CSW_LPT], ufv[CSW_LPT], va_prev[CSW_LPT], vf_prev[CSW_LPT], s4_prev[CSW_LPT], c4_prev[CSW_LPT], s2_prev[CSW_LPT];
+#define CSW_MET(X) X(cs) X(r2) X(cu) X(ru) X(dy) X(s3) X(s1) X(c2) X(dyc) X(c3) X(c1) X(dxc) X(rac) X(s4) X(c4) X(cv) X(rv) X(dx) X(s2)
+#define CSW_DECL(n) Real mc_##n[CSW_LPT], mn_##n[CSW_LPT];
+    CSW_MET(CSW_DECL)
+#undef CSW_DECL
+    Real o_a[CSW_LPT], o_b[CSW_LPT], o_c[CSW_LPT], o_d[CSW_LPT], o_e[CSW_LPT], o_f[CSW_LPT];  // results of a step on their way out
+    bool own[CSW_LPT], own_d[CSW_LPT];
+    // Row accesses: the CPL columns of a lane are one 16-byte access (device); slot l sits at pcol0 + l.  The strips' last
+    // lanes are clamped as a pair (their columns are not owned).
+#ifdef FV3_HOST_EMU
+    unsigned pcolv[CSW_LPT];
+    for (int q_ = 0; q_ < CSW_NV; ++q_) {
+      const int lc0 = c0 - 2 + (q_ / CSW_CPL) * CSW_CPL;
+      pcolv[q_] = pbase + (unsigned)(lc0 + CSW_CPL - 1 <= Led ? lc0 : Led - (CSW_CPL - 1)) + (unsigned)(q_ % CSW_CPL);
+    }
+#define CSW_ROW(dst, ptr, rowoff) \
+  for (int q_ = 0; q_ < CSW_NV; ++q_) dst[q_] = (ptr)[pcolv[q_] + (unsigned)(rowoff)];
+#define CSW_STORE(ptr, rowoff, src, ownarr) \
+  for (int q_ = 0; q_ < CSW_NV; ++q_)       \
+    if (ownarr[q_]) (ptr)[pcolv[q_] + (unsigned)(rowoff)] = src[q_];
+#else
+    unsigned pcol0;
+    {
+      const int lc0 = c0 - 2 + blk.tid * CSW_CPL;
+      pcol0 = pbase + (unsigned)(lc0 + CSW_CPL - 1 <= Led ? lc0 : Led - (CSW_CPL - 1));
+    }
+#define CSW_ROW(dst, ptr, rowoff) fv3_ld_cpl<CSW_CPL>(dst, (ptr) + (pcol0 + (unsigned)(rowoff)));
+#ifdef CSW_EXP_UNCOND
+#define CSW_STORE(ptr, rowoff, src, ownarr) { const bool all_[2] = {true, true}; (void)ownarr; fv3_st_cpl<CSW_CPL>((ptr) + (pcol0 + (unsigned)(rowoff)), src, all_); }
+#else
+#define CSW_STORE(ptr, rowoff, src, ownarr) fv3_st_cpl<CSW_CPL>((ptr) + (pcol0 + (unsigned)(rowoff)), src, ownarr);
+#endif
+#endif
+    // the metric terms of step R_: rows R_-2 (cs .. c4) and R_-1 (cv .. s2) of the lane's own columns (sin_sg3 / cos_sg3 of the
+    // column to the west come from the neighbouring slot)
+#define CSW_LOAD_MET(R_)                                                                      \
+  {                                                                                           \
+    const int ra_ = ((R_) - 2 < Msd ? Msd : (R_) - 2) * sj32, rb_ = ((R_) - 1 < Msd ? Msd : (R_) - 1) * sj32; \
+    CSW_ROW(mn_cs, m_cosa_s + m2, ra_)                                                        \
+    CSW_ROW(mn_r2, m_rsin2 + m2, ra_)                                                         \
+    CSW_ROW(mn_cu, m_cosa_u + m2, ra_)                                                        \
+    CSW_ROW(mn_ru, m_rsin_u + m2, ra_)                                                        \
+    CSW_ROW(mn_dy, m_dy + m2, ra_)                                                            \
+    CSW_ROW(mn_s3, m_sin3 + m2, ra_)                                                          \
+    CSW_ROW(mn_s1, m_sin1 + m2, ra_)                                                          \
+    CSW_ROW(mn_c2, m_cos2 + m2, ra_)                                                          \
+    CSW_ROW(mn_dyc, m_dyc + m2, ra_)                                                          \
+    CSW_ROW(mn_c3, m_cos3 + m2, ra_)                                                          \
+    CSW_ROW(mn_c1, m_cos1 + m2, ra_)                                                          \
+    CSW_ROW(mn_dxc, m_dxc + m2, ra_)                                                          \
+    CSW_ROW(mn_rac, m_rac + m2, ra_)                                                          \
+    CSW_ROW(mn_s4, m_sin4 + m2, ra_)                                                          \
+    CSW_ROW(mn_c4, m_cos4 + m2, ra_)                                                          \
+    CSW_ROW(mn_cv, m_cosa_v + m2, rb_)                                                        \
+    CSW_ROW(mn_rv, m_rsin_v + m2, rb_)                                                        \
+    CSW_ROW(mn_dx, m_dx + m2, rb_)                                                            \
+    CSW_ROW(mn_s2, m_sin2 + m2, rb_)                                                          \
+  }
+    CSW_LANES(vl, l)
+      const int lc = c0 - 2 + vl;
+      own[l] = vl >= 2 && vl <= CSW_OUT + 1 && lc <= rc.i_hi;
+      own_d[l] = own[l] && lc >= 1;
+      u0[l] = u1[l] = u2[l] = u3[l] = v0[l] = v1[l] = v2[l] = v3[l] = t0[l] = t1[l] = t2[l] = t3[l] = (Real)0;
+      s_ut[l] = s_v[l] = s_ua[l] = s_uf[l] = uav[l] = ufv[l] = va_prev[l] = vf_prev[l] = s4_prev[l] = c4_prev[l] = s2_prev[l] = (Real)0;
+      o_a[l] = o_b[l] = o_c[l] = o_d[l] = o_e[l] = o_f[l] = (Real)0;
+#define CSW_ZERO(n) mc_##n[l] = (Real)0;
+      CSW_MET(CSW_ZERO)
+#undef CSW_ZERO
+    FV3_VLANES_END
+    {
+      const int ra = (ja - 2) * sj32, rb = (ja - 1 < r_end ? ja - 1 : r_end) * sj32;
+      CSW_ROW(nu1, ub, ra)
+      CSW_ROW(nv1, vb, ra)
+      CSW_ROW(nu2, ub, rb)
+      CSW_ROW(nv2, vb, rb)
+      CSW_LOAD_MET(ja - 2)
+    }
+    for (int R = ja - 2; R <= r_end; ++R) {
+      const int rn = (R + 2 < r_end ? R + 2 : r_end) * sj32;
+      const int jr = R - 2, jv = R - 1;
+      const bool row_r = jr >= ja && jr <= jb, row_v = jv >= ja && jv <= jb;
+      // ---- phase 1: rotate the rows in flight, the u / v windows, the metric terms; fetch ahead; utmp of row R-2
+      CSW_LANES(vl, l)
+        u0[l] = u1[l];
+        u1[l] = u2[l];
+        u2[l] = u3[l];
+        u3[l] = nu1[l];
+        v0[l] = v1[l];
+        v1[l] = v2[l];
+        v2[l] = v3[l];
+        v3[l] = nv1[l];
+        nu1[l] = nu2[l];
+        nv1[l] = nv2[l];
+#define CSW_ROT(n) mc_##n[l] = mn_##n[l];
+        CSW_MET(CSW_ROT)
+#undef CSW_ROT
+        s_ut[l] = CSW_A2 * (u0[l] + u3[l]) + CSW_A1 * (u1[l] + u2[l]);
+        s_v[l] = v3[l];
+      FV3_VLANES_END
+      CSW_ROW(nu2, ub, rn)
+      CSW_ROW(nv2, vb, rn)
+#ifndef CSW_EXP_NOMET
+      CSW_LOAD_MET(R + 1)
+#endif
+      // ---- phase 2: vtmp of row R; ua / va / uc / ut of row R-2, vc / vt of row R-1; the u-face term of the divergence
+      CSW_LANES(vl, l)
+        const Real vt_new = CSW_A2 * (CSW_SHR(1, s_v) + CSW_SHL(2, s_v)) + CSW_A1 * (s_v[l] + CSW_SHL(1, s_v));
+        t0[l] = t1[l];
+        t1[l] = t2[l];
+        t2[l] = t3[l];
+        t3[l] = vt_new;
+        const Real ut0 = s_ut[l], vt0 = t1[l];
+        const Real ua_ = (ut0 - vt0 * mc_cs[l]) * mc_r2[l], va_ = (vt0 - ut0 * mc_cs[l]) * mc_r2[l];
+        const Real ucv = CSW_A2 * (CSW_SHR(2, s_ut) + CSW_SHL(1, s_ut)) + CSW_A1 * (CSW_SHR(1, s_ut) + ut0);
+        const Real utv = (ucv - v1[l] * mc_cu[l]) * mc_ru[l];
+        const Real vcv = CSW_A2 * (t0[l] + t3[l]) + CSW_A1 * (t1[l] + t2[l]);
+        const Real vtv = (vcv - u2[l] * mc_cv[l]) * mc_rv[l];
+        const Real s3w = CSW_SHR(1, mc_s3);  // sin_sg3 of the column to the west
+        o_a[l] = ua_;
+        o_b[l] = va_;
+        o_c[l] = ucv;
+        o_d[l] = utv > (Real)0 ? dt2 * utv * mc_dy[l] * s3w : dt2 * utv * mc_dy[l] * mc_s1[l];
+        o_e[l] = vcv;
+        o_f[l] = vtv > (Real)0 ? dt2 * vtv * mc_dx[l] * mc_s4[l] : dt2 * vtv * mc_dx[l] * mc_s2[l];
+        // u-face term of the corner divergence at (lc, R-2): cos / sin sums over the rows R-3 and R-2
+        ufv[l] = (u1[l] - (Real)0.25 * (va_prev[l] + va_) * (c4_prev[l] + mc_c2[l])) * mc_dyc[l] * (Real)0.5 * (s4_prev[l] + s2_prev[l]);
+        s_uf[l] = ufv[l];
+        uav[l] = ua_;
+        s_ua[l] = ua_;
+        va_prev[l] = va_;
+        c4_prev[l] = mc_c4[l];
+        s4_prev[l] = mc_s4[l];
+        s2_prev[l] = mc_s2[l];
+      FV3_VLANES_END
+#ifdef CSW_EXP_UNCOND
+      {
+        const int jrc = (jr < ja ? ja : jr > jb ? jb : jr) * sj32, jvc = (jv < ja ? ja : jv > jb ? jb : jv) * sj32;
+        CSW_STORE(ua + b, jrc, o_a, own)
+#ifndef CSW_EXP_FEWST
+        CSW_STORE(va + b, jrc, o_b, own)
+        CSW_STORE(uc + b, jrc, o_c, own)
+        CSW_STORE(ut + b, jrc, o_d, own)
+        CSW_STORE(vc + b, jvc, o_e, own)
+        CSW_STORE(vt + b, jvc, o_f, own)
+#endif
+      }
+#else
+      if (row_r) {
+        CSW_STORE(ua + b, jr * sj32, o_a, own)
+        CSW_STORE(va + b, jr * sj32, o_b, own)
+        CSW_STORE(uc + b, jr * sj32, o_c, own)
+        CSW_STORE(ut + b, jr * sj32, o_d, own)
+      }
+      if (row_v) {
+        CSW_STORE(vc + b, jv * sj32, o_e, own)
+        CSW_STORE(vt + b, jv * sj32, o_f, own)
+      }
+#endif
+      // ---- phase 3: the v-face term and the divergence of the corner (lc, R-2)
+      if (do_div) {
+        CSW_LANES(vl, l)
+          const Real s3w = CSW_SHR(1, mc_s3), c3w = CSW_SHR(1, mc_c3);
+          const Real vf = (v1[l] - (Real)0.25 * (CSW_SHR(1, s_ua) + uav[l]) * (c3w + mc_c1[l])) * mc_dxc[l] * (Real)0.5 * (s3w + mc_s1[l]);
+          const Real dv = vf_prev[l] - vf + CSW_SHR(1, s_uf) - ufv[l];
+          o_a[l] = mc_rac[l] * dv;
+          vf_prev[l] = vf;
+        FV3_VLANES_END
+#ifdef CSW_EXP_UNCOND
+        CSW_STORE(divgd + b, (jr < ja ? ja : jr > jb ? jb : jr) * sj32, o_a, own_d)
+#else
+        if (row_r && jr >= 1) CSW_STORE(divgd + b, jr * sj32, o_a, own_d)
+#endif
+      }
+    }
+#undef CSW_ROW
+#undef CSW_STORE
+#undef CSW_LOAD_MET
+#undef CSW_MET
+  });
+}
+
 extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_, const fv3_field *w_,
                         const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_, const fv3_field *ut_, const fv3_field *vt_,
                         const fv3_field *divgd_, const fv3_field *omga_, const fv3_field *delpc_, const fv3_field *ptc_, double dt2d, void *stream) {
@@ -84,25 +344,22 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   const int nkc = (nz1 + FV3_KC) / FV3_KC;  // level chunks of the kernels that walk FV3_KC levels per thread
   // Where stage B's two-row interior kernel runs (below) it also produces ua / va -- it holds utmp(i, j) and vtmp(i, j)
   // of its points anyway -- so this per-point form then only covers the boundary windows and the outer ring.
+  // FV3_CSW_B_GENERIC: every point by the generic per-point stage kernels; FV3_CSW_MARCH=0: the round-1 form (two-row stage-B
+  // kernel on the interior rectangle, the divergence as a full stage kernel) -- A/B switches, same results
   const bool b_split = g.nx >= 16 && g.ny >= 16 && !getenv("FV3_CSW_B_GENERIC");
-  // interior rectangle of sub-domain t: columns [i_lo, i_hi], rows [j_lo, j_lo + 2 * n_pairs - 1]
-  struct BRect {
-    int i_lo, i_hi, j_lo, n_pairs;
-  };
+  const char *march_env = getenv("FV3_CSW_MARCH");
+  const bool march = b_split && !(march_env && atoi(march_env) == 0);
+  // interior rectangle of sub-domain t: columns [i_lo, i_hi], rows [j_lo, j_hi] (the two-row kernel needs an even row count)
   auto b_rect = [=] FV3_HD(int fl) {
-    BRect r;
-    r.i_lo = (fl & FV3_W) ? 6 : 0;
-    r.i_hi = (fl & FV3_E) ? g.npx - 5 : g.nx + 1;
-    r.j_lo = (fl & FV3_S) ? 6 : 0;
-    const int j_hi = (fl & FV3_N) ? g.npy - 5 : g.ny + 1;
-    r.n_pairs = (j_hi - r.j_lo + 1) / 2;
+    CswRect r = csw_rect(fl, g.nx, g.ny, g.npx, g.npy);
+    if (!march) r.j_hi = r.j_lo + 2 * ((r.j_hi - r.j_lo + 1) / 2) - 1;
     return r;
   };
   auto stage_a = [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
     if (b_split) {
-      const BRect rc = b_rect(fl);
-      if (i >= rc.i_lo && i <= rc.i_hi && j >= rc.j_lo && j < rc.j_lo + 2 * rc.n_pairs) return;  // done by the two-row kernel
+      const CswRect rc = b_rect(fl);
+      if (i >= rc.i_lo && i <= rc.i_hi && j >= rc.j_lo && j <= rc.j_hi) return;  // done by the interior kernel
     }
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j);
@@ -134,10 +391,12 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // experiment took 2.5 ms off c_sw).  Points whose whole stencil uses the interior formulas are therefore done by
   // a lean kernel in which a thread owns TWO rows and shares the utmp / vtmp rows between them (20 loads per point);
   // the generic form then only runs on four windows along the sub-domain boundary (and skips the interior).
-  if (b_split) {
+  if (march) {
+    csw_abc_stream(c, s, u, v, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0);
+  } else if (b_split) {
     launch3(c, s, Box{0, g.nx + 1, 0, (g.ny + 2) / 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int jp) {
-      const BRect rc = b_rect(g.flags[t]);
-      if (i_ < rc.i_lo || i_ > rc.i_hi || jp >= rc.n_pairs) return;
+      const CswRect rc = b_rect(g.flags[t]);
+      if (i_ < rc.i_lo || i_ > rc.i_hi || jp >= (rc.j_hi - rc.j_lo + 1) / 2) return;
       const long m2 = t * g.st2;
       int i = i_, j = rc.j_lo + 2 * jp;
       const int j_base = j;
@@ -215,8 +474,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   auto stage_b = [=] FV3_HD(int t, int kp, int i_, int j_) {
     const int fl = g.flags[t];
     if (b_split) {
-      const BRect rc = b_rect(fl);
-      if (i_ >= rc.i_lo && i_ <= rc.i_hi && j_ >= rc.j_lo && j_ < rc.j_lo + 2 * rc.n_pairs) return;  // done by the two-row kernel
+      const CswRect rc = b_rect(fl);
+      if (i_ >= rc.i_lo && i_ <= rc.i_hi && j_ >= rc.j_lo && j_ <= rc.j_hi) return;  // done by the interior kernel
     }
     const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
@@ -371,8 +630,12 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // used for both levels (they are 2/3 of this kernel's bytes).
   if (nord > 0) {
     const int npair = (nz1 + FV3_KC) / FV3_KC;
-    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, npair - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+    auto stage_c = [=] FV3_HD(int t, int kp, int i, int j) {
       const int fl = g.flags[t];
+      if (march) {  // the corners whose 2 x 2 block of ua / va the marching kernel holds are done there
+        const CswRect rc = b_rect(fl);
+        if (i >= rc.i_lo && i >= 1 && i <= rc.i_hi && j >= rc.j_lo && j >= 1 && j <= rc.j_hi) return;
+      }
       const long m2 = t * g.st2;
       const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
       const int npx = g.npx, npy = g.npy;
@@ -432,7 +695,16 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         if (cNW) dv += VF(1, npy, mvc);
         (divgd + b)[IX(i, j)] = rac * dv;
       }
-    });
+    };
+    if (march) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
+      const int e0 = g.nx - 3;
+      launch3(c, s, Box{1, g.ny + 1, 1, 5, 0, npair - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_c(t, kp, b_, a); });
+      launch3(c, s, Box{1, g.ny + 1, 0, 4, 0, npair - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_c(t, kp, e0 + b_, a); });
+      launch3(c, s, Box{6, g.nx - 4, 1, 5, 0, npair - 1}, stage_c);
+      launch3(c, s, Box{6, g.nx - 4, g.ny - 3, g.ny + 1, 0, npair - 1}, stage_c);
+    } else {
+      launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, npair - 1}, stage_c);
+    }
   }
 
   // (D) upwind transport (delpc, ptc, wc), kinetic energy, absolute vorticity

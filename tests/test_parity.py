@@ -106,10 +106,15 @@ def test_a2b_ord4(backend, n, layout, ranks):
         assert_close("qout", O.numpy(r)[:, :, :nz][R], want[R], 1e-13, 1e-13)
 
 
-@pytest.mark.parametrize("layout, ranks", [((1, 1), (0, 3)), ((2, 2), (0, 5, 10, 15))])
-def test_c_sw(backend, layout, ranks):
+# n = 12: the generic per-point stage kernels everywhere; n >= 16 per sub-domain: the marching interior kernel (stages A + B + C) +
+# the boundary windows -- 24 / 48: one strip, sub-domains with 0-2 cube-tile edges; 72 with 16-row segments: 2 strips x 5 segments
+@pytest.mark.parametrize("n, layout, ranks, seg", [(12, (1, 1), (0, 3), None), (12, (2, 2), (0, 5, 10, 15), None), (24, (1, 1), (0, 4), None),
+                                                   (48, (2, 2), (0, 5, 10, 15), "8"), (72, (1, 1), (2,), "16")])
+def test_c_sw(backend, n, layout, ranks, seg, monkeypatch):
     nz = 4
-    cs = Case(12, layout, ranks, nz=nz, backend=backend)
+    if seg:
+        monkeypatch.setenv("FV3_SEG", seg)
+    cs = Case(n, layout, ranks, nz=nz, backend=backend)
     names = ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "omga")
     Q = {n: cs.q([s[n] for s in cs.states]) for n in names}
     ut, vt, divgd, delpc, ptc = cs.q(), cs.q(), cs.q(), cs.q(), cs.q()
@@ -203,6 +208,27 @@ def test_riem_solver3_and_column_ops(backend):
     assert_close("pk3 ring", pk3.numpy(0)[R2][:, :, 1:], e_pk3[R2][:, :, 1:], 1e-13, 1e-13)
     R1 = D.sl(0, D.nx + 1, 0, D.ny + 1)
     assert_close("pe ring", Q["pe"].numpy(0)[R1], x["pe"][R1], 1e-14, 1e-14)
+
+
+def test_c_sw_forms_are_bitwise_equal(backend, monkeypatch):
+    """The three forms of c_sw's stages A - C (marching interior kernel / two-row stage kernel + divergence stage kernel /
+    generic stage kernels everywhere) evaluate the same expressions in the same order: every output is bitwise equal."""
+    nz, outs = 3, {}
+    for form, env in (("march", {}), ("two_row", {"FV3_CSW_MARCH": "0"}), ("generic", {"FV3_CSW_B_GENERIC": "1"})):
+        for k in ("FV3_CSW_MARCH", "FV3_CSW_B_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v_ in env.items():
+            monkeypatch.setenv(k, v_)
+        monkeypatch.setenv("FV3_SEG", "8")
+        cs = Case(48, (2, 2), (0, 5, 10, 15), nz=nz, backend=backend)
+        names = ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "omga")
+        Q = {n: cs.q([s[n] for s in cs.states]) for n in names}
+        extra = [cs.q() for _ in range(5)]
+        cs.sf.call("c_sw", *[Q[n].fref for n in names[:9]], extra[0].fref, extra[1].fref, extra[2].fref, Q["omga"].fref, extra[3].fref, extra[4].fref, 56.25)
+        outs[form] = [Q[n].numpy(r).copy() for n in ("uc", "vc", "ua", "va", "omga") for r in range(4)] + [e.numpy(r).copy() for e in extra for r in range(4)]
+    for form in ("two_row", "generic"):
+        for a, b in zip(outs["march"], outs[form]):
+            assert np.array_equal(a, b), form
 
 
 @pytest.mark.parametrize("layout, n_split", [((1, 1), 2), ((2, 2), 1)])
