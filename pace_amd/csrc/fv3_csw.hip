@@ -326,6 +326,318 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole of c_sw (stages A - E) on the interior rectangle as ONE marching wave kernel: besides (u, v) a lane reads
+// delp / pt / w of its column once and writes the ten outputs once (35 GB at C768 where the stage kernels moved 97).
+// The intermediate C-grid winds uc0 / vc0, the kinetic energy and the corner vorticity live in the march: step R loads row R
+// and finishes, in this order, ua / va / uc0 / ut / the divergence / the upwind transport / ke / the vorticity of row R-2
+// and vc0 / vt of row R-1 (as csw_abc_stream), the time-centred vc of row R-2 and the time-centred uc of row R-3 (which
+// needs the vorticity of the row above).  Regions, with R0 = [i_lo, i_hi] x [j_lo, j_hi] the interior rectangle:
+//   ua va ut vt           R0                              divgd   corners of R0 from (1, 1)
+//   delpc ptc omga, ke    RD = R0 minus its last column / row (the east / north face values come from the neighbour)
+//   vorticity             VR = corners of R0 from (i_lo + 1, j_lo + 1)
+//   final uc / vc         RE = R0 minus a one-cell rim (ke of the cell to the west / south, vorticity of the corner above)
+// On the rim R0 \ RE the march stores the intermediate uc0 / vc0 instead, and ke / vorticity on the two cells next to
+// the rectangle's boundary: exactly what the generic stage D / E kernels -- which now only run on the windows along the
+// sub-domain boundary -- read from the interior.  One lane per column here (CSW_CPL = 1): 58 owned columns per strip.
+// ---------------------------------------------------------------------------------------------
+#define CSWF_OUT (FV3_WAVE - 6)
+#ifndef CSWF_WPE
+#define CSWF_WPE 2
+#endif
+static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *delp, const Real *pt, const Real *w, Real *ua, Real *va, Real *uc,
+                             Real *vc, Real *ut, Real *vt, Real *divgd, Real *delpc, Real *ptc, Real *omga, Real *ke, Real *vort, Real dt2, bool do_div) {
+  const Geo g = c->g;
+  const Geo *gp = c->g_dev;
+  const int nk = g.nz;
+  const int nstrip = (g.nx + 2 + CSWF_OUT - 1) / CSWF_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, CSWF_WPE);
+  const int nseg = (g.ny + 2 + seg - 1) / seg;
+  const int sj32 = g.sj32, go = g.o, nx = g.nx, ny = g.ny, npx = g.npx, npy = g.npy, nh = g.nh;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const MPtr m_cosa_s = g.cosa_s, m_rsin2 = g.rsin2, m_cosa_u = g.cosa_u, m_rsin_u = g.rsin_u, m_dy = g.dy, m_sin3 = g.sin_sg3, m_sin1 = g.sin_sg1;
+  const MPtr m_cosa_v = g.cosa_v, m_rsin_v = g.rsin_v, m_dx = g.dx, m_sin4 = g.sin_sg4, m_sin2 = g.sin_sg2;
+  const MPtr m_cos4 = g.cos_sg4, m_cos2 = g.cos_sg2, m_dyc = g.dyc, m_cos3 = g.cos_sg3, m_cos1 = g.cos_sg1, m_dxc = g.dxc, m_rac = g.rarea_c;
+  const MPtr m_rarea = g.rarea, m_fC = g.fC, m_sina_u = g.sina_u, m_rdxc = g.rdxc, m_sina_v = g.sina_v, m_rdyc = g.rdyc;
+  const int ntile = nstrip * nseg;
+  // (level-major launch geometry: see csw_abc_stream)
+  launch_waves<CSWF_WPE>(c, s, nk, 1, ntile * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
+    const int k = blk.bx, t = blk.bz / ntile, tile = blk.bz - t * ntile;
+    const int tby = tile / nstrip, tbx = tile - tby * nstrip;
+    const CswRect rc = csw_rect(gp->flags[t], nx, ny, npx, npy);
+    const int c0 = rc.i_lo + tbx * CSWF_OUT;
+    const int ja = rc.j_lo + tby * seg;
+    if (c0 > rc.i_hi || ja > rc.j_hi) return;
+    const int jb = ja + seg - 1 < rc.j_hi ? ja + seg - 1 : rc.j_hi;
+    const long b = t * st + k * sk, m2 = t * st2;
+    const Real *ub = u + b, *vb = v + b, *db = delp + b, *pb_ = pt + b, *wb = w + b;
+    const int Led = nx + nh, Msd = 1 - nh;
+    const unsigned pbase = (unsigned)(go * sj32 + go);
+    const int r_end = jb + 3 < rc.j_hi + 2 ? jb + 3 : rc.j_hi + 2;
+    const int re_i0 = rc.i_lo + 1 > 1 ? rc.i_lo + 1 : 1, re_j0 = rc.j_lo + 1 > 1 ? rc.j_lo + 1 : 1;  // first column / row of RE (and of VR)
+
+    Real u0[FV3_LPT], u1[FV3_LPT], u2[FV3_LPT], u3[FV3_LPT], v0[FV3_LPT], v1[FV3_LPT], v2[FV3_LPT], v3[FV3_LPT];
+    Real t0[FV3_LPT], t1[FV3_LPT], t2[FV3_LPT], t3[FV3_LPT];
+    Real d0[FV3_LPT], d1[FV3_LPT], d2[FV3_LPT], p0[FV3_LPT], p1[FV3_LPT], p2[FV3_LPT], w0[FV3_LPT], w1[FV3_LPT], w2[FV3_LPT];  // delp / pt / w rows R-3 .. R-1
+    Real nu1[FV3_LPT], nv1[FV3_LPT], nu2[FV3_LPT], nv2[FV3_LPT];                                                              // rows R+1, R+2 of u / v
+    Real nd1[FV3_LPT], np1[FV3_LPT], nw1[FV3_LPT], nd2[FV3_LPT], np2[FV3_LPT], nw2[FV3_LPT];                                  // rows R, R+1 of delp / pt / w
+    // values the neighbouring lanes read
+    Real s_ut[FV3_LPT], s_v[FV3_LPT], s_ua[FV3_LPT], s_uf[FV3_LPT], s_uc[FV3_LPT], s_d[FV3_LPT], s_p[FV3_LPT], s_w[FV3_LPT];
+    Real s_f1[FV3_LPT], s_f[FV3_LPT], s_f2[FV3_LPT], s_pvd[FV3_LPT], s_ke[FV3_LPT], s_vo[FV3_LPT], s_s3[FV3_LPT], s_c3[FV3_LPT];
+    // carried from the step before
+    Real va_prev[FV3_LPT], vf_prev[FV3_LPT], s4_prev[FV3_LPT], c4_prev[FV3_LPT], s2_prev[FV3_LPT];
+    Real vt_prev[FV3_LPT], vc_prev[FV3_LPT], cv_prev[FV3_LPT], cu_prev[FV3_LPT], uc_prev[FV3_LPT], dxc_prev[FV3_LPT];
+    Real g1_lo[FV3_LPT], g_lo[FV3_LPT], g2_lo[FV3_LPT], ke_prev[FV3_LPT], vo_prev[FV3_LPT];
+    // within a step
+    Real uav[FV3_LPT], vav[FV3_LPT], ucv_[FV3_LPT], vcv_[FV3_LPT], ufv[FV3_LPT], utq[FV3_LPT], vtq[FV3_LPT], ke_w[FV3_LPT], kev_[FV3_LPT], vov_[FV3_LPT];
+#define CSW_MET(X)                                                                                                                              \
+  X(cs) X(r2) X(cu) X(ru) X(dy) X(s3) X(s1) X(c2) X(dyc) X(c3) X(c1) X(dxc) X(rac) X(s4) X(c4) X(ra) X(fc) X(sv) X(rdy) X(cv) X(rv) X(dx) X(s2) \
+      X(su) X(rdx)
+#define CSW_DECL(n) Real mc_##n[FV3_LPT], mn_##n[FV3_LPT];
+    CSW_MET(CSW_DECL)
+#undef CSW_DECL
+    unsigned pcol[FV3_LPT];
+    bool c_r0[FV3_LPT], c_rd[FV3_LPT], c_vr[FV3_LPT], c_div[FV3_LPT], c_re[FV3_LPT], c_kb[FV3_LPT], c_vb[FV3_LPT];
+    // metric terms of step R_: rows R_-2 (cs .. rdy), R_-1 (cv .. s2), R_-3 (su, rdx)
+#define CSW_LOAD_MET(R_)                                                                                                                   \
+  {                                                                                                                                        \
+    const unsigned pa = pcol[l] + (unsigned)(((R_) - 2 < Msd ? Msd : (R_) - 2) * sj32), pb = pcol[l] + (unsigned)(((R_) - 1 < Msd ? Msd : (R_) - 1) * sj32), \
+                   pc = pcol[l] + (unsigned)(((R_) - 3 < Msd ? Msd : (R_) - 3) * sj32);                                                    \
+    mn_cs[l] = (m_cosa_s + m2)[pa];                                                                                                        \
+    mn_r2[l] = (m_rsin2 + m2)[pa];                                                                                                         \
+    mn_cu[l] = (m_cosa_u + m2)[pa];                                                                                                        \
+    mn_ru[l] = (m_rsin_u + m2)[pa];                                                                                                        \
+    mn_dy[l] = (m_dy + m2)[pa];                                                                                                            \
+    mn_s3[l] = (m_sin3 + m2)[pa];                                                                                                          \
+    mn_s1[l] = (m_sin1 + m2)[pa];                                                                                                          \
+    mn_c2[l] = (m_cos2 + m2)[pa];                                                                                                          \
+    mn_dyc[l] = (m_dyc + m2)[pa];                                                                                                          \
+    mn_c3[l] = (m_cos3 + m2)[pa];                                                                                                          \
+    mn_c1[l] = (m_cos1 + m2)[pa];                                                                                                          \
+    mn_dxc[l] = (m_dxc + m2)[pa];                                                                                                          \
+    mn_rac[l] = (m_rac + m2)[pa];                                                                                                          \
+    mn_s4[l] = (m_sin4 + m2)[pa];                                                                                                          \
+    mn_c4[l] = (m_cos4 + m2)[pa];                                                                                                          \
+    mn_ra[l] = (m_rarea + m2)[pa];                                                                                                         \
+    mn_fc[l] = (m_fC + m2)[pa];                                                                                                            \
+    mn_sv[l] = (m_sina_v + m2)[pa];                                                                                                        \
+    mn_rdy[l] = (m_rdyc + m2)[pa];                                                                                                         \
+    mn_cv[l] = (m_cosa_v + m2)[pb];                                                                                                        \
+    mn_rv[l] = (m_rsin_v + m2)[pb];                                                                                                        \
+    mn_dx[l] = (m_dx + m2)[pb];                                                                                                            \
+    mn_s2[l] = (m_sin2 + m2)[pb];                                                                                                          \
+    mn_su[l] = (m_sina_u + m2)[pc];                                                                                                        \
+    mn_rdx[l] = (m_rdxc + m2)[pc];                                                                                                         \
+  }
+    FV3_LANES(blk, lane, l) {
+      const int lc = c0 - 3 + lane, lcc = lc < Msd ? Msd : lc < Led ? lc : Led;  // (lane 0 of a first strip: no such column, and nothing owned reads it)
+      pcol[l] = pbase + (unsigned)lcc;
+      const bool own = lane >= 3 && lane <= CSWF_OUT + 2;
+      c_r0[l] = own && lc <= rc.i_hi;
+      c_rd[l] = own && lc <= rc.i_hi - 1;
+      c_vr[l] = own && lc >= re_i0 && lc <= rc.i_hi;
+      c_div[l] = own && lc >= 1 && lc <= rc.i_hi;
+      c_re[l] = own && lc >= re_i0 && lc <= rc.i_hi - 1;
+      c_kb[l] = lc <= rc.i_lo + 1 || lc >= rc.i_hi - 2;
+      c_vb[l] = lc <= rc.i_lo + 2 || lc >= rc.i_hi - 1;
+      u0[l] = u1[l] = u2[l] = u3[l] = v0[l] = v1[l] = v2[l] = v3[l] = t0[l] = t1[l] = t2[l] = t3[l] = (Real)0;
+      d0[l] = d1[l] = d2[l] = p0[l] = p1[l] = p2[l] = w0[l] = w1[l] = w2[l] = (Real)0;
+      s_ut[l] = s_v[l] = s_ua[l] = s_uf[l] = s_uc[l] = s_d[l] = s_p[l] = s_w[l] = s_f1[l] = s_f[l] = s_f2[l] = s_pvd[l] = s_ke[l] = s_vo[l] = s_s3[l] = s_c3[l] = (Real)0;
+      va_prev[l] = vf_prev[l] = s4_prev[l] = c4_prev[l] = s2_prev[l] = vt_prev[l] = vc_prev[l] = cv_prev[l] = cu_prev[l] = uc_prev[l] = dxc_prev[l] = (Real)0;
+      g1_lo[l] = g_lo[l] = g2_lo[l] = ke_prev[l] = vo_prev[l] = (Real)0;
+      uav[l] = vav[l] = ucv_[l] = vcv_[l] = ufv[l] = utq[l] = vtq[l] = ke_w[l] = kev_[l] = vov_[l] = (Real)0;
+#define CSW_ZERO(n) mc_##n[l] = (Real)0;
+      CSW_MET(CSW_ZERO)
+#undef CSW_ZERO
+      // (delp = 1 in the rows not yet loaded: the warm-up steps divide by the transported air mass)
+      d0[l] = d1[l] = d2[l] = (Real)1;
+      const int R0_ = ja - 3;
+      auto row = [&](int r) { return (unsigned)((r < Msd ? Msd : r > r_end ? r_end : r) * sj32); };
+      nu1[l] = ub[pcol[l] + row(R0_)];
+      nv1[l] = vb[pcol[l] + row(R0_)];
+      nu2[l] = ub[pcol[l] + row(R0_ + 1)];
+      nv2[l] = vb[pcol[l] + row(R0_ + 1)];
+      nd1[l] = db[pcol[l] + row(R0_ - 1)];
+      np1[l] = pb_[pcol[l] + row(R0_ - 1)];
+      nw1[l] = wb[pcol[l] + row(R0_ - 1)];
+      nd2[l] = db[pcol[l] + row(R0_)];
+      np2[l] = pb_[pcol[l] + row(R0_)];
+      nw2[l] = wb[pcol[l] + row(R0_)];
+      CSW_LOAD_MET(R0_)
+    }
+    for (int R = ja - 3; R <= r_end; ++R) {
+      const unsigned rn2 = (unsigned)((R + 2 < r_end ? R + 2 : r_end) * sj32), rn1 = (unsigned)((R + 1 < r_end ? R + 1 : r_end) * sj32);
+      const int jd = R - 2, jv = R - 1, je = R - 3;
+      const bool seg_d = jd >= ja && jd <= jb, seg_v = jv >= ja && jv <= jb, seg_e = je >= ja && je <= jb;
+      const bool r_rd = seg_d && jd <= rc.j_hi - 1, r_vr = seg_d && jd >= re_j0, r_div = seg_d && jd >= 1;
+      const bool r_re_d = seg_d && jd >= re_j0 && jd <= rc.j_hi - 1, r_re_v = seg_v && jv >= re_j0 && jv <= rc.j_hi - 1, r_re_e = seg_e && je >= re_j0 && je <= rc.j_hi - 1;
+      const bool kb_row = jd <= rc.j_lo + 1 || jd >= rc.j_hi - 2, vb_row = jd <= rc.j_lo + 2 || jd >= rc.j_hi - 1;
+      // ---- phase 1: rotate the windows, the rows in flight, the metric terms; fetch ahead; utmp of row R-2
+      FV3_LANES(blk, lane, l) {
+        u0[l] = u1[l];
+        u1[l] = u2[l];
+        u2[l] = u3[l];
+        u3[l] = nu1[l];
+        v0[l] = v1[l];
+        v1[l] = v2[l];
+        v2[l] = v3[l];
+        v3[l] = nv1[l];
+        d0[l] = d1[l];
+        d1[l] = d2[l];
+        d2[l] = nd1[l];
+        p0[l] = p1[l];
+        p1[l] = p2[l];
+        p2[l] = np1[l];
+        w0[l] = w1[l];
+        w1[l] = w2[l];
+        w2[l] = nw1[l];
+        nu1[l] = nu2[l];
+        nv1[l] = nv2[l];
+        nd1[l] = nd2[l];
+        np1[l] = np2[l];
+        nw1[l] = nw2[l];
+        nu2[l] = ub[pcol[l] + rn2];
+        nv2[l] = vb[pcol[l] + rn2];
+        nd2[l] = db[pcol[l] + rn1];
+        np2[l] = pb_[pcol[l] + rn1];
+        nw2[l] = wb[pcol[l] + rn1];
+#define CSW_ROT(n) mc_##n[l] = mn_##n[l];
+        CSW_MET(CSW_ROT)
+#undef CSW_ROT
+        CSW_LOAD_MET(R + 1)
+        s_ut[l] = CSW_A2 * (u0[l] + u3[l]) + CSW_A1 * (u1[l] + u2[l]);
+        s_v[l] = v3[l];
+        s_d[l] = d1[l];
+        s_p[l] = p1[l];
+        s_w[l] = w1[l];
+        s_s3[l] = mc_s3[l];
+        s_c3[l] = mc_c3[l];
+      }
+      // ---- phase 2: vtmp of row R; ua / va / uc0 / ut of row R-2, vc0 / vt of row R-1; the west-face fluxes of the transport
+      FV3_LANES(blk, lane, l) {
+        const Real vt_new = CSW_A2 * (FV3_LANE_SHR(1, s_v, l, lane) + FV3_LANE_SHL(2, s_v, l, lane)) + CSW_A1 * (s_v[l] + FV3_LANE_SHL(1, s_v, l, lane));
+        t0[l] = t1[l];
+        t1[l] = t2[l];
+        t2[l] = t3[l];
+        t3[l] = vt_new;
+        const Real ut0 = s_ut[l], vt0 = t1[l];
+        const Real ua_ = (ut0 - vt0 * mc_cs[l]) * mc_r2[l], va_ = (vt0 - ut0 * mc_cs[l]) * mc_r2[l];
+        const Real ucv = CSW_A2 * (FV3_LANE_SHR(2, s_ut, l, lane) + FV3_LANE_SHL(1, s_ut, l, lane)) + CSW_A1 * (FV3_LANE_SHR(1, s_ut, l, lane) + ut0);
+        const Real utv = (ucv - v1[l] * mc_cu[l]) * mc_ru[l];
+        const Real vcv = CSW_A2 * (t0[l] + t3[l]) + CSW_A1 * (t1[l] + t2[l]);
+        const Real vtv = (vcv - u2[l] * mc_cv[l]) * mc_rv[l];
+        const Real s3w = FV3_LANE_SHR(1, s_s3, l, lane);
+        const Real ut_o = utv > (Real)0 ? dt2 * utv * mc_dy[l] * s3w : dt2 * utv * mc_dy[l] * mc_s1[l];
+        const Real vt_o = vtv > (Real)0 ? dt2 * vtv * mc_dx[l] * mc_s4[l] : dt2 * vtv * mc_dx[l] * mc_s2[l];
+        const unsigned pd = pcol[l] + (unsigned)(jd * sj32), pv = pcol[l] + (unsigned)(jv * sj32);
+        if (c_r0[l] && seg_d) {
+          (ua + b)[pd] = ua_;
+          (va + b)[pd] = va_;
+          (ut + b)[pd] = ut_o;
+          if (!(c_re[l] && r_re_d)) (uc + b)[pd] = ucv;  // the rim of the rectangle: the stage E kernel finishes it
+        }
+        if (c_r0[l] && seg_v) {
+          (vt + b)[pv] = vt_o;
+          if (!(c_re[l] && r_re_v)) (vc + b)[pv] = vcv;
+        }
+        // west-face fluxes of the cell (lc, R-2): upwind cell lc-1 or lc
+        {
+          const Real dw = FV3_LANE_SHR(1, s_d, l, lane), pw = FV3_LANE_SHR(1, s_p, l, lane), ww = FV3_LANE_SHR(1, s_w, l, lane);
+          const bool up = ut_o > (Real)0;
+          const Real f1 = ut_o * (up ? dw : d1[l]);
+          s_f1[l] = f1;
+          s_f[l] = f1 * (up ? pw : p1[l]);
+          s_f2[l] = f1 * (up ? ww : w1[l]);
+        }
+        // u-face term of the corner divergence at (lc, R-2): cos / sin sums over the rows R-3 and R-2
+        ufv[l] = (u1[l] - (Real)0.25 * (va_prev[l] + va_) * (c4_prev[l] + mc_c2[l])) * mc_dyc[l] * (Real)0.5 * (s4_prev[l] + s2_prev[l]);
+        s_uf[l] = ufv[l];
+        uav[l] = ua_;
+        vav[l] = va_;
+        s_ua[l] = ua_;
+        ucv_[l] = ucv;
+        s_uc[l] = ucv;
+        vcv_[l] = vcv;
+        utq[l] = ut_o;
+        vtq[l] = vt_o;
+        s_pvd[l] = vc_prev[l] * mc_dyc[l];
+        ke_w[l] = FV3_LANE_SHR(1, s_ke, l, lane);  // ke(lc-1, R-3) (before phase 3 overwrites the row)
+        va_prev[l] = va_;
+        c4_prev[l] = mc_c4[l];
+        s4_prev[l] = mc_s4[l];
+        s2_prev[l] = mc_s2[l];
+      }
+      // ---- phase 3: the divergence, the transport, the kinetic energy and the vorticity of row R-2
+      FV3_LANES(blk, lane, l) {
+        const unsigned pd = pcol[l] + (unsigned)(jd * sj32);
+        if (do_div) {
+          const Real s3w = FV3_LANE_SHR(1, s_s3, l, lane), c3w = FV3_LANE_SHR(1, s_c3, l, lane);
+          const Real vf = (v1[l] - (Real)0.25 * (FV3_LANE_SHR(1, s_ua, l, lane) + uav[l]) * (c3w + mc_c1[l])) * mc_dxc[l] * (Real)0.5 * (s3w + mc_s1[l]);
+          const Real dv = vf_prev[l] - vf + FV3_LANE_SHR(1, s_uf, l, lane) - ufv[l];
+          if (c_div[l] && r_div) (divgd + b)[pd] = mc_rac[l] * dv;
+          vf_prev[l] = vf;
+        }
+        // transport: x fluxes at the faces lc (own) and lc + 1 (the neighbouring lane's), y fluxes at the faces R-2 (carried) and R-1
+        const Real fx1e = FV3_LANE_SHL(1, s_f1, l, lane), fxe = FV3_LANE_SHL(1, s_f, l, lane), fx2e = FV3_LANE_SHL(1, s_f2, l, lane);
+        const Real vth = vtq[l];
+        const bool upn = vth > (Real)0;
+        const Real g1_hi = vth * (upn ? d1[l] : d2[l]);
+        const Real g_hi = g1_hi * (upn ? p1[l] : p2[l]);
+        const Real g2_hi = g1_hi * (upn ? w1[l] : w2[l]);
+        const Real dpc = d1[l] + (s_f1[l] - fx1e + g1_lo[l] - g1_hi) * mc_ra[l];
+        if (c_rd[l] && r_rd) {
+          (delpc + b)[pd] = dpc;
+          (ptc + b)[pd] = (p1[l] * d1[l] + (s_f[l] - fxe + g_lo[l] - g_hi) * mc_ra[l]) / dpc;
+          (omga + b)[pd] = (w1[l] * d1[l] + (s_f2[l] - fx2e + g2_lo[l] - g2_hi) * mc_ra[l]) / dpc;
+        }
+        g1_lo[l] = g1_hi;
+        g_lo[l] = g_hi;
+        g2_lo[l] = g2_hi;
+        // kinetic energy of the cell, absolute vorticity of the corner
+        const Real kev = uav[l] > (Real)0 ? ucv_[l] : FV3_LANE_SHL(1, s_uc, l, lane);
+        const Real vov = vav[l] > (Real)0 ? vc_prev[l] : vcv_[l];
+        const Real kv = (Real)0.5 * dt2 * (uav[l] * kev + vav[l] * vov);
+        const Real vo = uc_prev[l] * dxc_prev[l] - ucv_[l] * mc_dxc[l] - FV3_LANE_SHR(1, s_pvd, l, lane) + vc_prev[l] * mc_dyc[l];
+        const Real vr = mc_fc[l] + mc_rac[l] * vo;
+        if (c_rd[l] && r_rd && (c_kb[l] || kb_row)) (ke + b)[pd] = kv;
+        if (c_vr[l] && r_vr && (c_vb[l] || vb_row)) (vort + b)[pd] = vr;
+        kev_[l] = kv;
+        vov_[l] = vr;
+        s_vo[l] = vr;
+      }
+      // ---- phase 4: the time-centred vc of row R-2 and uc of row R-3
+      FV3_LANES(blk, lane, l) {
+        const Real kv = kev_[l], vr = vov_[l];
+        {
+          const Real ucp = uc_prev[l];
+          const Real fy1 = dt2 * (v0[l] - ucp * cu_prev[l]) / mc_su[l];
+          const Real fyv = fy1 > (Real)0 ? vo_prev[l] : vr;
+          const Real un = ucp + fy1 * fyv + mc_rdx[l] * (ke_w[l] - ke_prev[l]);
+          if (c_re[l] && r_re_e) (uc + b)[pcol[l] + (unsigned)(je * sj32)] = un;
+        }
+        {
+          const Real vcp = vc_prev[l];
+          const Real fx1 = dt2 * (u1[l] - vcp * cv_prev[l]) / mc_sv[l];
+          const Real vre = FV3_LANE_SHL(1, s_vo, l, lane);
+          const Real fxv = fx1 > (Real)0 ? vr : vre;
+          const Real vn = vcp - fx1 * fxv + mc_rdy[l] * (ke_prev[l] - kv);
+          if (c_re[l] && r_re_d) (vc + b)[pcol[l] + (unsigned)(jd * sj32)] = vn;
+        }
+        s_ke[l] = kv;
+        ke_prev[l] = kv;
+        vo_prev[l] = vr;
+        uc_prev[l] = ucv_[l];
+        dxc_prev[l] = mc_dxc[l];
+        cu_prev[l] = mc_cu[l];
+        vc_prev[l] = vcv_[l];
+        cv_prev[l] = mc_cv[l];
+      }
+    }
+#undef CSW_LOAD_MET
+#undef CSW_MET
+  });
+}
+
 extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_, const fv3_field *w_,
                         const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_, const fv3_field *ut_, const fv3_field *vt_,
                         const fv3_field *divgd_, const fv3_field *omga_, const fv3_field *delpc_, const fv3_field *ptc_, double dt2d, void *stream) {
@@ -344,11 +656,13 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   const int nkc = (nz1 + FV3_KC) / FV3_KC;  // level chunks of the kernels that walk FV3_KC levels per thread
   // Where stage B's two-row interior kernel runs (below) it also produces ua / va -- it holds utmp(i, j) and vtmp(i, j)
   // of its points anyway -- so this per-point form then only covers the boundary windows and the outer ring.
-  // FV3_CSW_B_GENERIC: every point by the generic per-point stage kernels; FV3_CSW_MARCH=0: the round-1 form (two-row stage-B
-  // kernel on the interior rectangle, the divergence as a full stage kernel) -- A/B switches, same results
+  // A/B switches, same results: FV3_CSW_B_GENERIC: every point by the generic per-point stage kernels; FV3_CSW_MARCH=0: the round-1
+  // form (two-row stage-B kernel on the interior rectangle, the other stages as full stage kernels); FV3_CSW_MARCH=abc: stages
+  // A - C of the interior as a marching kernel, D and E as stage kernels; default: the whole interior as one marching kernel
   const bool b_split = g.nx >= 16 && g.ny >= 16 && !getenv("FV3_CSW_B_GENERIC");
   const char *march_env = getenv("FV3_CSW_MARCH");
-  const bool march = b_split && !(march_env && atoi(march_env) == 0);
+  const bool march = b_split && !(march_env && !strcmp(march_env, "0"));
+  const bool fused = march && !(march_env && !strcmp(march_env, "abc"));
   // interior rectangle of sub-domain t: columns [i_lo, i_hi], rows [j_lo, j_hi] (the two-row kernel needs an even row count)
   auto b_rect = [=] FV3_HD(int fl) {
     CswRect r = csw_rect(fl, g.nx, g.ny, g.npx, g.npy);
@@ -391,7 +705,9 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // experiment took 2.5 ms off c_sw).  Points whose whole stencil uses the interior formulas are therefore done by
   // a lean kernel in which a thread owns TWO rows and shares the utmp / vtmp rows between them (20 loads per point);
   // the generic form then only runs on four windows along the sub-domain boundary (and skips the interior).
-  if (march) {
+  if (fused) {
+    csw_fused_stream(c, s, u, v, delp, pt, w, ua, va, uc, vc, ut, vt, divgd, delpc, ptc, omga, ke, vort, dt2, nord > 0);
+  } else if (march) {
     csw_abc_stream(c, s, u, v, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0);
   } else if (b_split) {
     launch3(c, s, Box{0, g.nx + 1, 0, (g.ny + 2) / 2, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int jp) {
@@ -708,15 +1024,23 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   }
 
   // (D) upwind transport (delpc, ptc, wc), kinetic energy, absolute vorticity
-  launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int j_) {
+  auto stage_d = [=] FV3_HD(int t, int kp, int i_, int j_) {
     const int fl = g.flags[t];
+    // (fused form: the cells of RD and the corners of VR are done by the marching kernel -- see csw_fused_stream)
+    bool do_cell = true, do_vort = true;
+    if (fused) {
+      const CswRect rc = b_rect(fl);
+      do_cell = !(i_ >= rc.i_lo && i_ <= rc.i_hi - 1 && j_ >= rc.j_lo && j_ <= rc.j_hi - 1);
+      do_vort = !(i_ >= rc.i_lo + 1 && i_ <= rc.i_hi && j_ >= rc.j_lo + 1 && j_ <= rc.j_hi);
+      if (!do_cell && !do_vort) return;
+    }
     const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
     int i = i_, j = j_;
     unsigned p = IX(i, j);
     // metric terms of the point, shared by the levels of the chunk (tile-edge clauses read their own)
-    const bool corner_pt = i >= 1 && j >= 1;
+    const bool corner_pt = i >= 1 && j >= 1 && do_vort;
     const Real ra = (g.rarea + m2)[p];
     const Real m_dxc_s = corner_pt ? (g.dxc + m2)[IX(i, j - 1)] : (Real)0, m_dxc = (g.dxc + m2)[p];
     const Real m_dyc_w = corner_pt ? (g.dyc + m2)[IX(i - 1, j)] : (Real)0, m_dyc = (g.dyc + m2)[p];
@@ -731,7 +1055,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     FV3_LAUNDER(j);
     p = IX(i, j);
     const long b = t * g.st + k * g.sk;
-    {
+    if (do_cell) {
       // x fluxes at faces i and i+1 (fill_4corners x), y fluxes at j and j+1 (fill_4corners y)
       Real fx1[2], fx[2], fx2[2], fy1[2], fy[2], fy2[2];
       for (int a = 0; a < 2; ++a) {
@@ -753,7 +1077,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       (ptc + b)[p] = ((pt + b)[p] * (delp + b)[p] + (fx[0] - fx[1] + fy[0] - fy[1]) * ra) / dpc;
       (omga + b)[p] = ((w + b)[p] * (delp + b)[p] + (fx2[0] - fx2[1] + fy2[0] - fy2[1]) * ra) / dpc;
     }
-    {
+    if (do_cell) {
       const Real uav = (ua + b)[p], vav = (va + b)[p];
       Real kev = uav > (Real)0 ? (uc + b)[p] : (uc + b)[IX(i + 1, j)];
       Real vov = vav > (Real)0 ? (vc + b)[p] : (vc + b)[IX(i, j + 1)];
@@ -781,11 +1105,24 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       (vort + b)[p] = m_fc + m_rac * vo;
     }
     }
-  });
+  };
+  if (fused) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
+    const int e0 = g.nx - 4;
+    launch3(c, s, Box{0, g.ny + 1, 0, 6, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_d(t, kp, b_, a); });
+    launch3(c, s, Box{0, g.ny + 1, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_d(t, kp, e0 + b_, a); });
+    launch3(c, s, Box{7, g.nx - 5, 0, 6, 0, nkc - 1}, stage_d);
+    launch3(c, s, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, nkc - 1}, stage_d);
+  } else {
+    launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nkc - 1}, stage_d);
+  }
 
   // (E) time-centred C-grid winds (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  auto stage_e = [=] FV3_HD(int t, int kp, int i, int j) {
     const int fl = g.flags[t];
+    if (fused) {  // the cells of RE are done by the marching kernel
+      const CswRect rc = b_rect(fl);
+      if (i >= rc.i_lo + 1 && i <= rc.i_hi - 1 && j >= rc.j_lo + 1 && j <= rc.j_hi - 1) return;
+    }
     const long m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
     const int npx = g.npx, npy = g.npy;
@@ -811,6 +1148,18 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         (vc + b)[p] = vcv - fx1 * fxv + rdyc * ((ke + b)[IX(i, j - 1)] - (ke + b)[p]);
       }
     }
-  });
+  };
+  {
+    const int nke = (nz1 + FV3_KC) / FV3_KC - 1;
+    if (fused) {
+      const int e0 = g.nx - 4;
+      launch3(c, s, Box{1, g.ny + 1, 1, 6, 0, nke}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_e(t, kp, b_, a); });
+      launch3(c, s, Box{1, g.ny + 1, 0, 5, 0, nke}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_e(t, kp, e0 + b_, a); });
+      launch3(c, s, Box{7, g.nx - 5, 1, 6, 0, nke}, stage_e);
+      launch3(c, s, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, nke}, stage_e);
+    } else {
+      launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nke}, stage_e);
+    }
+  }
   return fv3_post(c, s, "c_sw");
 }

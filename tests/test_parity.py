@@ -211,10 +211,11 @@ def test_riem_solver3_and_column_ops(backend):
 
 
 def test_c_sw_forms_are_bitwise_equal(backend, monkeypatch):
-    """The three forms of c_sw's stages A - C (marching interior kernel / two-row stage kernel + divergence stage kernel /
-    generic stage kernels everywhere) evaluate the same expressions in the same order: every output is bitwise equal."""
+    """The four forms of c_sw (the whole interior as one marching kernel / stages A - C as a marching kernel + stage kernels /
+    two-row stage kernel + stage kernels / generic stage kernels everywhere) evaluate the same expressions in the same order:
+    every output is bitwise equal."""
     nz, outs = 3, {}
-    for form, env in (("march", {}), ("two_row", {"FV3_CSW_MARCH": "0"}), ("generic", {"FV3_CSW_B_GENERIC": "1"})):
+    for form, env in (("march", {}), ("abc", {"FV3_CSW_MARCH": "abc"}), ("two_row", {"FV3_CSW_MARCH": "0"}), ("generic", {"FV3_CSW_B_GENERIC": "1"})):
         for k in ("FV3_CSW_MARCH", "FV3_CSW_B_GENERIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v_ in env.items():
@@ -226,7 +227,7 @@ def test_c_sw_forms_are_bitwise_equal(backend, monkeypatch):
         extra = [cs.q() for _ in range(5)]
         cs.sf.call("c_sw", *[Q[n].fref for n in names[:9]], extra[0].fref, extra[1].fref, extra[2].fref, Q["omga"].fref, extra[3].fref, extra[4].fref, 56.25)
         outs[form] = [Q[n].numpy(r).copy() for n in ("uc", "vc", "ua", "va", "omga") for r in range(4)] + [e.numpy(r).copy() for e in extra for r in range(4)]
-    for form in ("two_row", "generic"):
+    for form in ("abc", "two_row", "generic"):
         for a, b in zip(outs["march"], outs[form]):
             assert np.array_equal(a, b), form
 
