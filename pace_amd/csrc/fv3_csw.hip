@@ -345,6 +345,12 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
 #ifndef CSWF_WPE
 #define CSWF_WPE 2
 #endif
+// (the outputs are written once and not read again by this kernel: non-temporal stores, 6 % faster at C768)
+#if !defined(CSWF_NO_NT) && !defined(FV3_HOST_EMU)
+#define CSWF_ST(ptr, val) __builtin_nontemporal_store((Real)(val), (ptr))
+#else
+#define CSWF_ST(ptr, val) (*(ptr) = (val))
+#endif
 static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *delp, const Real *pt, const Real *w, Real *ua, Real *va, Real *uc,
                              Real *vc, Real *ut, Real *vt, Real *divgd, Real *delpc, Real *ptc, Real *omga, Real *ke, Real *vort, Real dt2, bool do_div) {
   const Geo g = c->g;
@@ -531,14 +537,14 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real vt_o = vtv > (Real)0 ? dt2 * vtv * mc_dx[l] * mc_s4[l] : dt2 * vtv * mc_dx[l] * mc_s2[l];
         const unsigned pd = pcol[l] + (unsigned)(jd * sj32), pv = pcol[l] + (unsigned)(jv * sj32);
         if (c_r0[l] && seg_d) {
-          (ua + b)[pd] = ua_;
-          (va + b)[pd] = va_;
-          (ut + b)[pd] = ut_o;
-          if (!(c_re[l] && r_re_d)) (uc + b)[pd] = ucv;  // the rim of the rectangle: the stage E kernel finishes it
+          CSWF_ST((ua + b) + (pd), ua_);
+          CSWF_ST((va + b) + (pd), va_);
+          CSWF_ST((ut + b) + (pd), ut_o);
+          if (!(c_re[l] && r_re_d)) CSWF_ST((uc + b) + (pd), ucv);  // the rim of the rectangle: the stage E kernel finishes it
         }
         if (c_r0[l] && seg_v) {
-          (vt + b)[pv] = vt_o;
-          if (!(c_re[l] && r_re_v)) (vc + b)[pv] = vcv;
+          CSWF_ST((vt + b) + (pv), vt_o);
+          if (!(c_re[l] && r_re_v)) CSWF_ST((vc + b) + (pv), vcv);
         }
         // west-face fluxes of the cell (lc, R-2): upwind cell lc-1 or lc
         {
@@ -574,7 +580,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real s3w = FV3_LANE_SHR(1, s_s3, l, lane), c3w = FV3_LANE_SHR(1, s_c3, l, lane);
           const Real vf = (v1[l] - (Real)0.25 * (FV3_LANE_SHR(1, s_ua, l, lane) + uav[l]) * (c3w + mc_c1[l])) * mc_dxc[l] * (Real)0.5 * (s3w + mc_s1[l]);
           const Real dv = vf_prev[l] - vf + FV3_LANE_SHR(1, s_uf, l, lane) - ufv[l];
-          if (c_div[l] && r_div) (divgd + b)[pd] = mc_rac[l] * dv;
+          if (c_div[l] && r_div) CSWF_ST((divgd + b) + (pd), mc_rac[l] * dv);
           vf_prev[l] = vf;
         }
         // transport: x fluxes at the faces lc (own) and lc + 1 (the neighbouring lane's), y fluxes at the faces R-2 (carried) and R-1
@@ -586,21 +592,22 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real g2_hi = g1_hi * (upn ? w1[l] : w2[l]);
         const Real dpc = d1[l] + (s_f1[l] - fx1e + g1_lo[l] - g1_hi) * mc_ra[l];
         if (c_rd[l] && r_rd) {
-          (delpc + b)[pd] = dpc;
-          (ptc + b)[pd] = (p1[l] * d1[l] + (s_f[l] - fxe + g_lo[l] - g_hi) * mc_ra[l]) / dpc;
-          (omga + b)[pd] = (w1[l] * d1[l] + (s_f2[l] - fx2e + g2_lo[l] - g2_hi) * mc_ra[l]) / dpc;
+          CSWF_ST((delpc + b) + (pd), dpc);
+          CSWF_ST((ptc + b) + (pd), (p1[l] * d1[l] + (s_f[l] - fxe + g_lo[l] - g_hi) * mc_ra[l]) / dpc);
+          CSWF_ST((omga + b) + (pd), (w1[l] * d1[l] + (s_f2[l] - fx2e + g2_lo[l] - g2_hi) * mc_ra[l]) / dpc);
         }
         g1_lo[l] = g1_hi;
         g_lo[l] = g_hi;
         g2_lo[l] = g2_hi;
         // kinetic energy of the cell, absolute vorticity of the corner
-        const Real kev = uav[l] > (Real)0 ? ucv_[l] : FV3_LANE_SHL(1, s_uc, l, lane);
+        const Real uce = FV3_LANE_SHL(1, s_uc, l, lane);  // (read outside the selection: a shuffle needs every source lane active)
+        const Real kev = uav[l] > (Real)0 ? ucv_[l] : uce;
         const Real vov = vav[l] > (Real)0 ? vc_prev[l] : vcv_[l];
         const Real kv = (Real)0.5 * dt2 * (uav[l] * kev + vav[l] * vov);
         const Real vo = uc_prev[l] * dxc_prev[l] - ucv_[l] * mc_dxc[l] - FV3_LANE_SHR(1, s_pvd, l, lane) + vc_prev[l] * mc_dyc[l];
         const Real vr = mc_fc[l] + mc_rac[l] * vo;
-        if (c_rd[l] && r_rd && (c_kb[l] || kb_row)) (ke + b)[pd] = kv;
-        if (c_vr[l] && r_vr && (c_vb[l] || vb_row)) (vort + b)[pd] = vr;
+        if (c_rd[l] && r_rd && (c_kb[l] || kb_row)) CSWF_ST((ke + b) + (pd), kv);
+        if (c_vr[l] && r_vr && (c_vb[l] || vb_row)) CSWF_ST((vort + b) + (pd), vr);
         kev_[l] = kv;
         vov_[l] = vr;
         s_vo[l] = vr;
@@ -613,7 +620,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real fy1 = dt2 * (v0[l] - ucp * cu_prev[l]) / mc_su[l];
           const Real fyv = fy1 > (Real)0 ? vo_prev[l] : vr;
           const Real un = ucp + fy1 * fyv + mc_rdx[l] * (ke_w[l] - ke_prev[l]);
-          if (c_re[l] && r_re_e) (uc + b)[pcol[l] + (unsigned)(je * sj32)] = un;
+          if (c_re[l] && r_re_e) CSWF_ST((uc + b) + (pcol[l] + (unsigned)(je * sj32)), un);
         }
         {
           const Real vcp = vc_prev[l];
@@ -621,7 +628,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real vre = FV3_LANE_SHL(1, s_vo, l, lane);
           const Real fxv = fx1 > (Real)0 ? vr : vre;
           const Real vn = vcp - fx1 * fxv + mc_rdy[l] * (ke_prev[l] - kv);
-          if (c_re[l] && r_re_d) (vc + b)[pcol[l] + (unsigned)(jd * sj32)] = vn;
+          if (c_re[l] && r_re_d) CSWF_ST((vc + b) + (pcol[l] + (unsigned)(jd * sj32)), vn);
         }
         s_ke[l] = kv;
         ke_prev[l] = kv;
@@ -653,7 +660,6 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   Real *ke = c->scratch[SC_A], *vort = c->scratch[SC_B];
 
   // (A) contravariant A-grid winds on is-2..ie+2
-  const int nkc = (nz1 + FV3_KC) / FV3_KC;  // level chunks of the kernels that walk FV3_KC levels per thread
   // Where stage B's two-row interior kernel runs (below) it also produces ua / va -- it holds utmp(i, j) and vtmp(i, j)
   // of its points anyway -- so this per-point form then only covers the boundary windows and the outer ring.
   // A/B switches, same results: FV3_CSW_B_GENERIC: every point by the generic per-point stage kernels; FV3_CSW_MARCH=0: the round-1
@@ -663,6 +669,11 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   const char *march_env = getenv("FV3_CSW_MARCH");
   const bool march = b_split && !(march_env && !strcmp(march_env, "0"));
   const bool fused = march && !(march_env && !strcmp(march_env, "abc"));
+  // levels one thread of the stage kernels walks (the metric terms of its point are read once for them): FV3_KC for launches
+  // over whole sub-domains; 2 when they only cover the boundary windows, which are too few points to fill the chip otherwise
+  static const int win_kc = getenv("FV3_CSW_WIN_KC") ? atoi(getenv("FV3_CSW_WIN_KC")) : 2;
+  const int KC = fused ? win_kc : FV3_KC;
+  const int nkc = (nz1 + KC) / KC;
   // interior rectangle of sub-domain t: columns [i_lo, i_hi], rows [j_lo, j_hi] (the two-row kernel needs an even row count)
   auto b_rect = [=] FV3_HD(int fl) {
     CswRect r = csw_rect(fl, g.nx, g.ny, g.npx, g.npy);
@@ -679,8 +690,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const unsigned p = IX(i, j);
     const Real cs = (g.cosa_s + m2)[p], rs2 = (g.rsin2 + m2)[p];
 #pragma unroll 1
-    for (int kk = 0; kk < FV3_KC; ++kk) {
-      const int k = FV3_KC * kp + kk;
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = KC * kp + kk;
       if (k > nz1) break;
       const long b = t * g.st + k * g.sk;
       D2A d{g, u + b, v + b, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0};
@@ -735,8 +746,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         mr2[r] = (g.rsin2 + m2)[q];
       }
 #pragma unroll 1
-      for (int kk = 0; kk < FV3_KC; ++kk) {
-        const int k = FV3_KC * kp + kk;
+      for (int kk = 0; kk < KC; ++kk) {
+        const int k = KC * kp + kk;
         if (k > nz1) break;
         i = i_;
         j = j_base;
@@ -802,8 +813,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const Real m_cosa_u = (g.cosa_u + m2)[p], m_rsin_u = (g.rsin_u + m2)[p], m_dy = (g.dy + m2)[p], m_s3w = (g.sin_sg3 + m2)[IX(i - 1, j)], m_s1 = (g.sin_sg1 + m2)[p];
     const Real m_cosa_v = (g.cosa_v + m2)[p], m_rsin_v = (g.rsin_v + m2)[p], m_dx = (g.dx + m2)[p], m_s4s = (g.sin_sg4 + m2)[IX(i, j - 1)], m_s2 = (g.sin_sg2 + m2)[p];
 #pragma unroll 1
-    for (int kk = 0; kk < FV3_KC; ++kk) {
-    const int k = FV3_KC * kp + kk;
+    for (int kk = 0; kk < KC; ++kk) {
+    const int k = KC * kp + kk;
     if (k > nz1) break;
     i = i_;
     j = j_;
@@ -945,7 +956,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // (C) divergence on corners.  Two levels per thread: the ten metric terms of a corner are read once and
   // used for both levels (they are 2/3 of this kernel's bytes).
   if (nord > 0) {
-    const int npair = (nz1 + FV3_KC) / FV3_KC;
+    const int npair = (nz1 + KC) / KC;
     auto stage_c = [=] FV3_HD(int t, int kp, int i, int j) {
       const int fl = g.flags[t];
       if (march) {  // the corners whose 2 x 2 block of ua / va the marching kernel holds are done there
@@ -990,8 +1001,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       if (cNW) mvc = VFm(1, npy);
       const Real rac = (g.rarea_c + m2)[IX(i, j)];
 #pragma unroll 1
-      for (int kk = 0; kk < FV3_KC; ++kk) {
-        const int k = FV3_KC * kp + kk;
+      for (int kk = 0; kk < KC; ++kk) {
+        const int k = KC * kp + kk;
         if (k > nz1) break;
         const long b = t * g.st + k * g.sk;
         auto UF = [&](int ii, int jj, const Face &m) -> Real {
@@ -1046,8 +1057,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const Real m_dyc_w = corner_pt ? (g.dyc + m2)[IX(i - 1, j)] : (Real)0, m_dyc = (g.dyc + m2)[p];
     const Real m_fc = (g.fC + m2)[p], m_rac = (g.rarea_c + m2)[p];
 #pragma unroll 1
-    for (int kk = 0; kk < FV3_KC; ++kk) {
-    const int k = FV3_KC * kp + kk;
+    for (int kk = 0; kk < KC; ++kk) {
+    const int k = KC * kp + kk;
     if (k > nz1) break;
     i = i_;
     j = j_;
@@ -1131,8 +1142,8 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const Real cau = (g.cosa_u + m2)[p], sau = (g.sina_u + m2)[p], rdxc = (g.rdxc + m2)[p];
     const Real cav = (g.cosa_v + m2)[p], sav = (g.sina_v + m2)[p], rdyc = (g.rdyc + m2)[p];
 #pragma unroll 1
-    for (int kk = 0; kk < FV3_KC; ++kk) {
-      const int k = FV3_KC * kp + kk;
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = KC * kp + kk;
       if (k > nz1) break;
       const long b = t * g.st + k * g.sk;
       if (j <= g.ny) {
@@ -1150,7 +1161,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
   };
   {
-    const int nke = (nz1 + FV3_KC) / FV3_KC - 1;
+    const int nke = (nz1 + KC) / KC - 1;
     if (fused) {
       const int e0 = g.nx - 4;
       launch3(c, s, Box{1, g.ny + 1, 1, 6, 0, nke}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_e(t, kp, b_, a); });

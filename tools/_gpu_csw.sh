@@ -5,5 +5,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_
 cd $GRAFT_REPO_ROOT
 python tools/summarize_rocprof.py gpurun_out/csw1/stats/s_kernel_stats.csv 60 > gpurun_out/csw1/kernel_stats.md
 find gpurun_out/csw1 -name "*kernel_trace.csv" -delete
-grep -i "c_sw\|csw" gpurun_out/csw1/kernel_stats.md
+grep -i "c_sw\|csw" gpurun_out/csw1/kernel_stats.md | head -12
 tail -1 gpurun_out/csw1/stats.log | cut -c1-300
