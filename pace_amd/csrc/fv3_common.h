@@ -453,6 +453,13 @@ struct Blk {
   // instructions execute in issue order, so only the compiler has to be kept from moving the
   // reads above the writes -- no s_barrier, and outstanding global prefetches stay in flight
   // (a full __syncthreads() would drain vmcnt to 0).
+  // workgroup barrier of the wave-group kernels: LDS traffic of this wave complete, then s_barrier -- WITHOUT draining the
+  // vector-memory counter (a __syncthreads() would wait for every prefetched row)
+  FV3_HD inline void group_sync() const {
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+  }
   FV3_HD inline void wave_sync() const {
 #if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -670,6 +677,32 @@ inline void launch_waves(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int g
     }
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kw<WPE, F>), grid, dim3(FV3_WAVE, 1, 1), smem_bytes, s, m, f);
+#endif
+}
+
+// Wave kernels launched as workgroups of NW waves: blk.by = the wave's index in its group, blk.group_sync() = the workgroup
+// barrier for the LDS hand-offs between them (c_sw's interior march: the waves walk the same rows of NW levels and share the
+// 25 metric terms of a row through LDS, each wave fetching a quarter of them).
+#ifndef FV3_HOST_EMU
+template <int WPE, int NW, class F>
+__global__ void __launch_bounds__(FV3_WAVE * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) fv3_kwg(GridMap m, F f) {
+  extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
+  int bx, by, bz;
+  if (!fv3_tile(m, bx, by, bz)) return;
+  Blk b{(int)(threadIdx.x & (FV3_WAVE - 1)), FV3_WAVE, bx, __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FV3_WAVE)), bz};
+  f(b, fv3_smem);
+}
+#endif
+template <int WPE, int NW, class F>
+inline void launch_wave_groups(const fv3_ctx *c, fv3_stream_t s, int gx, int gz, size_t smem_bytes, F f) {
+  if (gx <= 0 || gz <= 0) return;
+#ifdef FV3_HOST_EMU
+  launch_blocks(c, s, gx, NW, gz, FV3_WAVE, smem_bytes, f);
+#else
+  (void)c;
+  dim3 grid;
+  const GridMap m = fv3_grid(gx, 1, gz, &grid);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kwg<WPE, NW, F>), grid, dim3(FV3_WAVE * NW, 1, 1), smem_bytes, s, m, f);
 #endif
 }
 

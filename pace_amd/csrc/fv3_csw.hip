@@ -345,6 +345,9 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
 #ifndef CSWF_WPE
 #define CSWF_WPE 2
 #endif
+#ifndef CSWF_NW
+#define CSWF_NW 4  // waves (= levels) per workgroup
+#endif
 // (the outputs are written once and not read again by this kernel: non-temporal stores, 6 % faster at C768)
 #if !defined(CSWF_NO_NT) && !defined(FV3_HOST_EMU)
 #define CSWF_ST(ptr, val) __builtin_nontemporal_store((Real)(val), (ptr))
@@ -366,9 +369,12 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
   const MPtr m_cos4 = g.cos_sg4, m_cos2 = g.cos_sg2, m_dyc = g.dyc, m_cos3 = g.cos_sg3, m_cos1 = g.cos_sg1, m_dxc = g.dxc, m_rac = g.rarea_c;
   const MPtr m_rarea = g.rarea, m_fC = g.fC, m_sina_u = g.sina_u, m_rdxc = g.rdxc, m_sina_v = g.sina_v, m_rdyc = g.rdyc;
   const int ntile = nstrip * nseg;
-  // (level-major launch geometry: see csw_abc_stream)
-  launch_waves<CSWF_WPE>(c, s, nk, 1, ntile * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
-    const int k = blk.bx, t = blk.bz / ntile, tile = blk.bz - t * ntile;
+  // (level-major launch geometry: see csw_abc_stream; CSWF_NW consecutive levels of a tile form one workgroup = run on one CU)
+  launch_wave_groups<CSWF_WPE, CSWF_NW>(c, s, (nk + CSWF_NW - 1) / CSWF_NW, ntile * g.nsub, sizeof(Real) * 2 * 25 * FV3_WAVE, [=] FV3_HD(const Blk &blk, char *smem_) {
+    // (a wave beyond the last level stays: the others need its share of the metric terms; it repeats the last level and stores nothing)
+    const int k_ = blk.bx * CSWF_NW + blk.by, t = blk.bz / ntile, tile = blk.bz - t * ntile;
+    const bool live = k_ < nk;
+    const int k = live ? k_ : nk - 1;
     const int tby = tile / nstrip, tbx = tile - tby * nstrip;
     const CswRect rc = csw_rect(gp->flags[t], nx, ny, npx, npy);
     const int c0 = rc.i_lo + tbx * CSWF_OUT;
@@ -396,49 +402,50 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
     Real g1_lo[FV3_LPT], g_lo[FV3_LPT], g2_lo[FV3_LPT], ke_prev[FV3_LPT], vo_prev[FV3_LPT];
     // within a step
     Real uav[FV3_LPT], vav[FV3_LPT], ucv_[FV3_LPT], vcv_[FV3_LPT], ufv[FV3_LPT], utq[FV3_LPT], vtq[FV3_LPT], ke_w[FV3_LPT], kev_[FV3_LPT], vov_[FV3_LPT];
-#define CSW_MET(X)                                                                                                                              \
-  X(cs) X(r2) X(cu) X(ru) X(dy) X(s3) X(s1) X(c2) X(dyc) X(c3) X(c1) X(dxc) X(rac) X(s4) X(c4) X(ra) X(fc) X(sv) X(rdy) X(cv) X(rv) X(dx) X(s2) \
-      X(su) X(rdx)
-#define CSW_DECL(n) Real mc_##n[FV3_LPT], mn_##n[FV3_LPT];
-    CSW_MET(CSW_DECL)
+#define CSW_METT(X)                                                                                                                          \
+  X(0, cs, m_cosa_s, pa) X(1, r2, m_rsin2, pa) X(2, cu, m_cosa_u, pa) X(3, ru, m_rsin_u, pa) X(4, dy, m_dy, pa) X(5, s3, m_sin3, pa)              \
+  X(6, s1, m_sin1, pa) X(7, c2, m_cos2, pa) X(8, dyc, m_dyc, pa) X(9, c3, m_cos3, pa) X(10, c1, m_cos1, pa) X(11, dxc, m_dxc, pa)                 \
+  X(12, rac, m_rac, pa) X(13, s4, m_sin4, pa) X(14, c4, m_cos4, pa) X(15, ra, m_rarea, pa) X(16, fc, m_fC, pa) X(17, sv, m_sina_v, pa)            \
+  X(18, rdy, m_rdyc, pa) X(19, cv, m_cosa_v, pb) X(20, rv, m_rsin_v, pb) X(21, dx, m_dx, pb) X(22, s2, m_sin2, pb) X(23, su, m_sina_u, pc)        \
+  X(24, rdx, m_rdxc, pc)
+#define CSWF_NMET 25
+#define CSW_DECL(i, n, ptr, pp) Real mc_##n[FV3_LPT], mn_##n[FV3_LPT];
+    CSW_METT(CSW_DECL)
 #undef CSW_DECL
     unsigned pcol[FV3_LPT];
     bool c_r0[FV3_LPT], c_rd[FV3_LPT], c_vr[FV3_LPT], c_div[FV3_LPT], c_re[FV3_LPT], c_kb[FV3_LPT], c_vb[FV3_LPT];
-    // metric terms of step R_: rows R_-2 (cs .. rdy), R_-1 (cv .. s2), R_-3 (su, rdx)
-#define CSW_LOAD_MET(R_)                                                                                                                   \
-  {                                                                                                                                        \
-    const unsigned pa = pcol[l] + (unsigned)(((R_) - 2 < Msd ? Msd : (R_) - 2) * sj32), pb = pcol[l] + (unsigned)(((R_) - 1 < Msd ? Msd : (R_) - 1) * sj32), \
-                   pc = pcol[l] + (unsigned)(((R_) - 3 < Msd ? Msd : (R_) - 3) * sj32);                                                    \
-    mn_cs[l] = (m_cosa_s + m2)[pa];                                                                                                        \
-    mn_r2[l] = (m_rsin2 + m2)[pa];                                                                                                         \
-    mn_cu[l] = (m_cosa_u + m2)[pa];                                                                                                        \
-    mn_ru[l] = (m_rsin_u + m2)[pa];                                                                                                        \
-    mn_dy[l] = (m_dy + m2)[pa];                                                                                                            \
-    mn_s3[l] = (m_sin3 + m2)[pa];                                                                                                          \
-    mn_s1[l] = (m_sin1 + m2)[pa];                                                                                                          \
-    mn_c2[l] = (m_cos2 + m2)[pa];                                                                                                          \
-    mn_dyc[l] = (m_dyc + m2)[pa];                                                                                                          \
-    mn_c3[l] = (m_cos3 + m2)[pa];                                                                                                          \
-    mn_c1[l] = (m_cos1 + m2)[pa];                                                                                                          \
-    mn_dxc[l] = (m_dxc + m2)[pa];                                                                                                          \
-    mn_rac[l] = (m_rac + m2)[pa];                                                                                                          \
-    mn_s4[l] = (m_sin4 + m2)[pa];                                                                                                          \
-    mn_c4[l] = (m_cos4 + m2)[pa];                                                                                                          \
-    mn_ra[l] = (m_rarea + m2)[pa];                                                                                                         \
-    mn_fc[l] = (m_fC + m2)[pa];                                                                                                            \
-    mn_sv[l] = (m_sina_v + m2)[pa];                                                                                                        \
-    mn_rdy[l] = (m_rdyc + m2)[pa];                                                                                                         \
-    mn_cv[l] = (m_cosa_v + m2)[pb];                                                                                                        \
-    mn_rv[l] = (m_rsin_v + m2)[pb];                                                                                                        \
-    mn_dx[l] = (m_dx + m2)[pb];                                                                                                            \
-    mn_s2[l] = (m_sin2 + m2)[pb];                                                                                                          \
-    mn_su[l] = (m_sina_u + m2)[pc];                                                                                                        \
-    mn_rdx[l] = (m_rdxc + m2)[pc];                                                                                                         \
+    // metric terms of step R_: rows R_-2 (cs .. rdy), R_-1 (cv .. s2), R_-3 (su, rdx) of the lane's column
+#define CSW_ROWS(R_)                                                                                                                          \
+  const unsigned pa = pcol[l] + (unsigned)(((R_) - 2 < Msd ? Msd : (R_) - 2) * sj32), pb = pcol[l] + (unsigned)(((R_) - 1 < Msd ? Msd : (R_) - 1) * sj32), \
+                 pc = pcol[l] + (unsigned)(((R_) - 3 < Msd ? Msd : (R_) - 3) * sj32);
+#define CSW_LD1(i, n, ptr, pp) mn_##n[l] = (ptr + m2)[pp];
+#define CSW_LOAD_MET(R_) \
+  {                      \
+    CSW_ROWS(R_)         \
+    CSW_METT(CSW_LD1)    \
   }
+    // Device: the CSWF_NW waves of the workgroup walk the same rows of CSWF_NW levels.  Wave wv fetches the terms i = wv (mod
+    // CSWF_NW) of step R+2 during step R, hands them over through LDS during step R+1 (one barrier per step, two slots), and
+    // every wave reads the 25 terms of its next step from LDS: a quarter of the metric bytes cross the L2 -> CU fabric, which is
+    // what bounds this kernel (25 metric terms against 5 field values per point).
+#if !defined(FV3_HOST_EMU)
+    constexpr bool SHARE = CSWF_NW > 1;
+#else
+    constexpr bool SHARE = false;
+#endif
+    const int wv = blk.by;
+    (void)wv;
+    Real *lds = (Real *)smem_;
+    Real sh[(CSWF_NMET + CSWF_NW - 1) / CSWF_NW][FV3_LPT];
+#define CSW_LDSH(i, n, ptr, pp) \
+  if ((i % CSWF_NW) == wv) sh[i / CSWF_NW][l] = (ptr + m2)[pp];
+#define CSW_WRSH(i, n, ptr, pp) \
+  if ((i % CSWF_NW) == wv) lds[(slot_ * CSWF_NMET + i) * FV3_WAVE + lane] = sh[i / CSWF_NW][l];
+#define CSW_RDSH(i, n, ptr, pp) mn_##n[l] = lds[(slot_ * CSWF_NMET + i) * FV3_WAVE + lane];
     FV3_LANES(blk, lane, l) {
       const int lc = c0 - 3 + lane, lcc = lc < Msd ? Msd : lc < Led ? lc : Led;  // (lane 0 of a first strip: no such column, and nothing owned reads it)
       pcol[l] = pbase + (unsigned)lcc;
-      const bool own = lane >= 3 && lane <= CSWF_OUT + 2;
+      const bool own = live && lane >= 3 && lane <= CSWF_OUT + 2;
       c_r0[l] = own && lc <= rc.i_hi;
       c_rd[l] = own && lc <= rc.i_hi - 1;
       c_vr[l] = own && lc >= re_i0 && lc <= rc.i_hi;
@@ -452,8 +459,8 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
       va_prev[l] = vf_prev[l] = s4_prev[l] = c4_prev[l] = s2_prev[l] = vt_prev[l] = vc_prev[l] = cv_prev[l] = cu_prev[l] = uc_prev[l] = dxc_prev[l] = (Real)0;
       g1_lo[l] = g_lo[l] = g2_lo[l] = ke_prev[l] = vo_prev[l] = (Real)0;
       uav[l] = vav[l] = ucv_[l] = vcv_[l] = ufv[l] = utq[l] = vtq[l] = ke_w[l] = kev_[l] = vov_[l] = (Real)0;
-#define CSW_ZERO(n) mc_##n[l] = (Real)0;
-      CSW_MET(CSW_ZERO)
+#define CSW_ZERO(i, n, ptr, pp) mc_##n[l] = (Real)0;
+      CSW_METT(CSW_ZERO)
 #undef CSW_ZERO
       // (delp = 1 in the rows not yet loaded: the warm-up steps divide by the transported air mass)
       d0[l] = d1[l] = d2[l] = (Real)1;
@@ -470,6 +477,10 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
       np2[l] = pb_[pcol[l] + row(R0_)];
       nw2[l] = wb[pcol[l] + row(R0_)];
       CSW_LOAD_MET(R0_)
+      if constexpr (SHARE) {
+        CSW_ROWS(R0_ + 1)
+        CSW_METT(CSW_LDSH)
+      }
     }
     for (int R = ja - 3; R <= r_end; ++R) {
       const unsigned rn2 = (unsigned)((R + 2 < r_end ? R + 2 : r_end) * sj32), rn1 = (unsigned)((R + 1 < r_end ? R + 1 : r_end) * sj32);
@@ -507,10 +518,21 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         nd2[l] = db[pcol[l] + rn1];
         np2[l] = pb_[pcol[l] + rn1];
         nw2[l] = wb[pcol[l] + rn1];
-#define CSW_ROT(n) mc_##n[l] = mn_##n[l];
-        CSW_MET(CSW_ROT)
+#define CSW_ROT(i, n, ptr, pp) mc_##n[l] = mn_##n[l];
+        CSW_METT(CSW_ROT)
 #undef CSW_ROT
-        CSW_LOAD_MET(R + 1)
+        if constexpr (SHARE) {
+          const int slot_ = (R + 1) & 1;
+          CSW_METT(CSW_WRSH)  // this wave's share of step R+1 (fetched during step R-1)
+          {
+            CSW_ROWS(R + 2)
+            CSW_METT(CSW_LDSH)
+          }
+          blk.group_sync();
+          CSW_METT(CSW_RDSH)
+        } else {
+          CSW_LOAD_MET(R + 1)
+        }
         s_ut[l] = CSW_A2 * (u0[l] + u3[l]) + CSW_A1 * (u1[l] + u2[l]);
         s_v[l] = v3[l];
         s_d[l] = d1[l];
@@ -641,7 +663,12 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
       }
     }
 #undef CSW_LOAD_MET
-#undef CSW_MET
+#undef CSW_ROWS
+#undef CSW_LD1
+#undef CSW_LDSH
+#undef CSW_WRSH
+#undef CSW_RDSH
+#undef CSW_METT
   });
 }
 
