@@ -63,163 +63,235 @@ FV3_HD inline void cs_limiters(bool extm, Prof &p, int iv) {
 
 // One column.  PE1(l): source interface coordinate (l = 0 .. km), PE2(k): target one; Q1(k): source layer mean;
 // GAM / QE: per-column scratch accessors (km + 1 levels); OUT(k, value): receives the remapped means.
+//
+// Three sweeps, each streaming (every accessor is called once per level and sweep, with the neighbouring levels kept in a
+// sliding register window and the next level's loads issued a step ahead -- the first form of this routine called the
+// accessors where the formulas name them, ~40 dependent loads per level, and ran at 0.3 TB/s):
+//   1 (down the column) forward elimination of the edge-value system            reads Q1, PE1        writes QE, GAM
+//   2 (up)              back substitution + the large-scale constraints         reads QE, GAM, Q1    writes QE
+//   3 (down)            the limited parabola of each source layer as the conservative integration reaches it
+//                                                                               reads Q1, QE, PE1    writes OUT
+// The arithmetic is expression for expression the one of oracle/remap_oracle.c.
 template <class PE1, class PE2, class Q1F, class GAMF, class QEF, class OUTF>
 FV3_HD inline void remap_col(int km, PE1 pe1, PE2 pe2, Q1F Q1, GAMF GAM, QEF QE, OUTF OUT, int iv, Real qs, bool use_qmin, Real qmin) {
-  auto DP = [&](int k) { return pe1(k + 1) - pe1(k); };
-  // ---- edge values: tridiagonal solve (cs_profile)
-  if (iv == -2) {
-    GAM(1) = (Real)0.5;
-    Real qp = (Real)1.5 * Q1(0);
-    QE(0) = qp;
-    for (int k = 1; k < km - 1; ++k) {
-      const Real grat = DP(k - 1) / DP(k);
-      const Real bet = (Real)2.0 + grat + grat - GAM(k);
-      qp = ((Real)3.0 * (Q1(k - 1) + Q1(k)) - qp) / bet;
-      QE(k) = qp;
-      GAM(k + 1) = grat / bet;
-    }
-    const Real grat = DP(km - 2) / DP(km - 1);
-    qp = ((Real)3.0 * (Q1(km - 2) + Q1(km - 1)) - grat * qs - qp) / ((Real)2.0 + grat + grat - GAM(km - 1));
-    QE(km - 1) = qp;
-    QE(km) = qs;
-    Real qn = qs;
-    qn = qp;  // q(km-1) needs no back substitution of its own: it was solved against the boundary value
-    for (int k = km - 2; k >= 0; --k) {
-      qn = QE(k) - GAM(k + 1) * qn;
-      QE(k) = qn;
-    }
-  } else {
-    const Real grat = DP(1) / DP(0);
-    Real bet = grat * (grat + (Real)0.5);
-    Real qp = ((grat + grat) * (grat + (Real)1.0) * Q1(0) + Q1(1)) / bet;
-    QE(0) = qp;
-    Real gp = ((Real)1.0 + grat * (grat + (Real)1.5)) / bet;
-    GAM(0) = gp;
-    Real d4 = (Real)0;
-    for (int k = 1; k < km; ++k) {
-      d4 = DP(k - 1) / DP(k);
-      bet = (Real)2.0 + d4 + d4 - gp;
-      qp = ((Real)3.0 * (Q1(k - 1) + d4 * Q1(k)) - qp) / bet;
-      QE(k) = qp;
-      gp = d4 / bet;
-      GAM(k) = gp;
-    }
-    const Real a_bot = (Real)1.0 + d4 * (d4 + (Real)1.5);
-    Real qn = ((Real)2.0 * d4 * (d4 + (Real)1.0) * Q1(km - 1) + Q1(km - 2) - a_bot * qp) / (d4 * (d4 + (Real)0.5) - a_bot * gp);
-    QE(km) = qn;
-    for (int k = km - 1; k >= 0; --k) {
-      qn = QE(k) - GAM(k) * qn;
-      QE(k) = qn;
-    }
-  }
-  // ---- large-scale constraints on the edge values
-  auto GD = [&](int k) { return Q1(k) - Q1(k - 1); };  // difference of the means across interface k (1 .. km-1)
+  // ---- sweep 1: forward elimination (cs_profile).  q_a / q_b = Q1(k-1) / Q1(k), dp_a / dp_b = the layer thicknesses
+  Real qp, gp = (Real)0, d4 = (Real)0, q_last2, q_last1;  // (q_last2 / q_last1 = Q1(km-2) / Q1(km-1) for the closure)
   {
-    Real q = QE(1);
-    q = fv3_min(q, fv3_max(Q1(0), Q1(1)));
-    q = fv3_max(q, fv3_min(Q1(0), Q1(1)));
-    QE(1) = q;
-  }
-  for (int k = 2; k < km - 1; ++k) {
-    Real q = QE(k);
-    const Real lo = fv3_min(Q1(k - 1), Q1(k)), hi = fv3_max(Q1(k - 1), Q1(k));
-    const Real gm = GD(k - 1), gp = GD(k + 1);
-    if (gm * gp > (Real)0) {
-      q = fv3_min(q, hi);
-      q = fv3_max(q, lo);
-    } else if (gm > (Real)0) {
-      q = fv3_max(q, lo);
+    Real pe_a = pe1(0), pe_b = pe1(1), pe_c = pe1(2);
+    Real q_a = Q1(0), q_b = Q1(1);
+    Real dp_a = pe_b - pe_a, dp_b = pe_c - pe_b;
+    if (iv == -2) {
+      Real gam_k = (Real)0.5;  // GAM(1)
+      GAM(1) = gam_k;
+      qp = (Real)1.5 * q_a;
+      QE(0) = qp;
+      for (int k = 1; k < km - 1; ++k) {
+        // prefetch of the next level
+        const Real pe_n = pe1(k + 2), q_n = Q1(k + 1);
+        const Real grat = dp_a / dp_b;
+        const Real bet = (Real)2.0 + grat + grat - gam_k;
+        qp = ((Real)3.0 * (q_a + q_b) - qp) / bet;
+        QE(k) = qp;
+        gam_k = grat / bet;
+        GAM(k + 1) = gam_k;
+        dp_a = dp_b;
+        dp_b = pe_n - pe_c;
+        pe_c = pe_n;
+        q_a = q_b;
+        q_b = q_n;
+      }
+      const Real grat = dp_a / dp_b;
+      qp = ((Real)3.0 * (q_a + q_b) - grat * qs - qp) / ((Real)2.0 + grat + grat - gam_k);
+      q_last2 = q_a;
+      q_last1 = q_b;
     } else {
-      q = fv3_min(q, hi);
-      if (iv == 0) q = fv3_max((Real)0, q);
-    }
-    QE(k) = q;
-  }
-  {
-    Real q = QE(km - 1);
-    q = fv3_min(q, fv3_max(Q1(km - 2), Q1(km - 1)));
-    q = fv3_max(q, fv3_min(Q1(km - 2), Q1(km - 1)));
-    QE(km - 1) = q;
-  }
-  // ---- the limited parabola of source layer l, rebuilt on demand
-  auto EXTM = [&](int m) { return GD(m) * GD(m + 1) < (Real)0; };  // 1 <= m <= km - 2
-  auto profile = [&](int l) {
-    Prof p;
-    p.a1 = Q1(l);
-    p.a2 = QE(l);
-    p.a3 = QE(l + 1);
-    if (l == 0) {
-      if (iv == 0)
-        p.a2 = fv3_max((Real)0, p.a2);
-      else if (iv == -1 && p.a2 * p.a1 <= (Real)0)
-        p.a2 = (Real)0;
-      p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
-      cs_limiters(false, p, 1);
-    } else if (l == km - 1) {
-      if (iv == 0)
-        p.a3 = fv3_max((Real)0, p.a3);
-      else if (iv == -1 && p.a3 * p.a1 <= (Real)0)
-        p.a3 = (Real)0;
-      p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
-      cs_limiters(false, p, 1);
-    } else if (l == 1 || l == km - 2) {
-      p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
-      cs_limiters(EXTM(l), p, 2);
-    } else {
-      const bool e = EXTM(l);
-      if ((e && EXTM(l - 1)) || (e && EXTM(l + 1)) || (use_qmin && e && p.a1 < qmin)) {
-        p.a2 = p.a1, p.a3 = p.a1, p.a4 = (Real)0;
-      } else {
-        p.a4 = (Real)6.0 * p.a1 - (Real)3.0 * (p.a2 + p.a3);
-        if (fabs(p.a4) > fabs(p.a2 - p.a3)) {
-          const Real pmp_1 = p.a1 - (Real)2.0 * GD(l + 1), lac_1 = pmp_1 + (Real)1.5 * GD(l + 2);
-          p.a2 = fv3_min(fv3_max(p.a2, rmin3(p.a1, pmp_1, lac_1)), rmax3(p.a1, pmp_1, lac_1));
-          const Real pmp_2 = p.a1 + (Real)2.0 * GD(l), lac_2 = pmp_2 - (Real)1.5 * GD(l - 1);
-          p.a3 = fv3_min(fv3_max(p.a3, rmin3(p.a1, pmp_2, lac_2)), rmax3(p.a1, pmp_2, lac_2));
-          p.a4 = (Real)6.0 * p.a1 - (Real)3.0 * (p.a2 + p.a3);
+      const Real grat = dp_b / dp_a;
+      Real bet = grat * (grat + (Real)0.5);
+      qp = ((grat + grat) * (grat + (Real)1.0) * q_a + q_b) / bet;
+      QE(0) = qp;
+      gp = ((Real)1.0 + grat * (grat + (Real)1.5)) / bet;
+      GAM(0) = gp;
+      for (int k = 1; k < km; ++k) {
+        const int kn = k + 2 <= km ? k + 2 : km, qn_ = k + 1 <= km - 1 ? k + 1 : km - 1;
+        const Real pe_n = pe1(kn), q_n = Q1(qn_);
+        d4 = dp_a / dp_b;
+        bet = (Real)2.0 + d4 + d4 - gp;
+        qp = ((Real)3.0 * (q_a + d4 * q_b) - qp) / bet;
+        QE(k) = qp;
+        gp = d4 / bet;
+        GAM(k) = gp;
+        if (k + 1 < km) {
+          dp_a = dp_b;
+          dp_b = pe_n - pe_c;
+          pe_c = pe_n;
+          q_a = q_b;
+          q_b = q_n;
         }
       }
-      if (iv == 0) cs_limiters(e, p, 0);
+      q_last2 = q_a;
+      q_last1 = q_b;
     }
-    return p;
-  };
-  // ---- conservative integration over the target layers
-  int k0 = 0;
-  Real t_lo = pe2(0);
-  for (int k = 0; k < km; ++k) {
-    const Real t_hi = pe2(k + 1);
-    Real val = Q1(k);
-    for (int l = k0; l < km; ++l) {
-      const Real s_lo = pe1(l), s_hi = pe1(l + 1);
-      if (t_lo >= s_lo && t_lo <= s_hi) {
+  }
+  // ---- sweep 2: back substitution (the recurrence runs on the unconstrained values), the large-scale constraints on the way
+  {
+    // constrained edge value of interface k (1 .. km-1) from the four means around it: qm2 = Q1(k-2) .. qp1 = Q1(k+1)
+    auto constrain = [&](int k, Real q, Real qm2, Real qm1, Real q0, Real qp1) {
+      if (k == 1 || k == km - 1) {
+        q = fv3_min(q, fv3_max(qm1, q0));
+        q = fv3_max(q, fv3_min(qm1, q0));
+        return q;
+      }
+      const Real lo = fv3_min(qm1, q0), hi = fv3_max(qm1, q0);
+      const Real gm = qm1 - qm2, gpl = qp1 - q0;
+      if (gm * gpl > (Real)0) {
+        q = fv3_min(q, hi);
+        q = fv3_max(q, lo);
+      } else if (gm > (Real)0) {
+        q = fv3_max(q, lo);
+      } else {
+        q = fv3_min(q, hi);
+        if (iv == 0) q = fv3_max((Real)0, q);
+      }
+      return q;
+    };
+    Real qn;
+    int kstart;
+    if (iv == -2) {
+      QE(km) = qs;
+      QE(km - 1) = constrain(km - 1, qp, (Real)0, q_last2, q_last1, (Real)0);
+      qn = qp;
+      kstart = km - 2;
+    } else {
+      const Real a_bot = (Real)1.0 + d4 * (d4 + (Real)1.5);
+      qn = ((Real)2.0 * d4 * (d4 + (Real)1.0) * q_last1 + q_last2 - a_bot * qp) / (d4 * (d4 + (Real)0.5) - a_bot * gp);
+      QE(km) = qn;
+      kstart = km - 1;
+    }
+    // window of the means around interface k: w_m2 = Q1(k-2), w_m1 = Q1(k-1), w_0 = Q1(k), w_p1 = Q1(k+1)
+    auto Qc = [&](int k) { return Q1(k < 0 ? 0 : k > km - 1 ? km - 1 : k); };
+    Real w_p1 = Qc(kstart + 1), w_0 = Qc(kstart), w_m1 = Qc(kstart - 1), w_m2 = Qc(kstart - 2);
+    Real e_k = QE(kstart), g_k = iv == -2 ? GAM(kstart + 1) : GAM(kstart);
+    for (int k = kstart; k >= 0; --k) {
+      // the level below in the sweep, a step ahead
+      const int kb = k - 1 >= 0 ? k - 1 : 0;
+      const Real e_n = QE(kb), g_n = iv == -2 ? GAM(kb + 1) : GAM(kb), w_n = Qc(k - 3);
+      qn = e_k - g_k * qn;
+      QE(k) = (k >= 1 && k <= km - 1) ? constrain(k, qn, w_m2, w_m1, w_0, w_p1) : qn;
+      e_k = e_n;
+      g_k = g_n;
+      w_p1 = w_0;
+      w_0 = w_m1;
+      w_m1 = w_m2;
+      w_m2 = w_n;
+    }
+  }
+  // ---- sweep 3: conservative integration over the target layers; a cursor walks the source layers, holding the five means
+  //      around the layer (qw[0 .. 4] = Q1(c-2 .. c+2)), its two constrained edge values and its interfaces
+  {
+    int c = 0;
+    Real qw0 = (Real)0, qw1 = (Real)0, qw2 = Q1(0), qw3 = Q1(1), qw4 = Q1(2);
+    Real ec = QE(0), ec1 = QE(1);
+    Real s_lo = pe1(0), s_hi = pe1(1);
+    // one level ahead: Q1(c+3), QE(c+2), pe1(c+2)
+    Real q_n = Q1(3 <= km - 1 ? 3 : km - 1), e_n = QE(2), p_n = pe1(2);
+    bool have = false;
+    Prof cur{(Real)0, (Real)0, (Real)0, (Real)0};
+    auto advance = [&]() {
+      ++c;
+      s_lo = s_hi;
+      s_hi = p_n;
+      qw0 = qw1;
+      qw1 = qw2;
+      qw2 = qw3;
+      qw3 = qw4;
+      qw4 = q_n;
+      ec = ec1;
+      ec1 = e_n;
+      have = false;
+      const int qi = c + 3 <= km - 1 ? c + 3 : km - 1, ei = c + 2 <= km ? c + 2 : km;
+      q_n = Q1(qi);
+      e_n = QE(ei);
+      p_n = pe1(ei);
+    };
+    // the limited parabola of the cursor's layer (cs_profile, kord 9)
+    auto profile = [&]() {
+      if (have) return;
+      have = true;
+      const int l = c;
+      Prof p;
+      p.a1 = qw2;
+      p.a2 = ec;
+      p.a3 = ec1;
+      const Real g0 = qw1 - qw0, g1 = qw2 - qw1, g2 = qw3 - qw2, g3 = qw4 - qw3;  // GD(l-1), GD(l), GD(l+1), GD(l+2)
+      if (l == 0) {
+        if (iv == 0)
+          p.a2 = fv3_max((Real)0, p.a2);
+        else if (iv == -1 && p.a2 * p.a1 <= (Real)0)
+          p.a2 = (Real)0;
+        p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
+        cs_limiters(false, p, 1);
+      } else if (l == km - 1) {
+        if (iv == 0)
+          p.a3 = fv3_max((Real)0, p.a3);
+        else if (iv == -1 && p.a3 * p.a1 <= (Real)0)
+          p.a3 = (Real)0;
+        p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
+        cs_limiters(false, p, 1);
+      } else if (l == 1 || l == km - 2) {
+        p.a4 = (Real)3.0 * ((Real)2.0 * p.a1 - (p.a2 + p.a3));
+        cs_limiters(g1 * g2 < (Real)0, p, 2);
+      } else {
+        const bool e = g1 * g2 < (Real)0;
+        if ((e && g0 * g1 < (Real)0) || (e && g2 * g3 < (Real)0) || (use_qmin && e && p.a1 < qmin)) {
+          p.a2 = p.a1, p.a3 = p.a1, p.a4 = (Real)0;
+        } else {
+          p.a4 = (Real)6.0 * p.a1 - (Real)3.0 * (p.a2 + p.a3);
+          if (fabs(p.a4) > fabs(p.a2 - p.a3)) {
+            const Real pmp_1 = p.a1 - (Real)2.0 * g2, lac_1 = pmp_1 + (Real)1.5 * g3;
+            p.a2 = fv3_min(fv3_max(p.a2, rmin3(p.a1, pmp_1, lac_1)), rmax3(p.a1, pmp_1, lac_1));
+            const Real pmp_2 = p.a1 + (Real)2.0 * g1, lac_2 = pmp_2 - (Real)1.5 * g0;
+            p.a3 = fv3_min(fv3_max(p.a3, rmin3(p.a1, pmp_2, lac_2)), rmax3(p.a1, pmp_2, lac_2));
+            p.a4 = (Real)6.0 * p.a1 - (Real)3.0 * (p.a2 + p.a3);
+          }
+        }
+        if (iv == 0) cs_limiters(e, p, 0);
+      }
+      cur = p;
+    };
+    Real t_lo = pe2(0);
+    for (int k = 0; k < km; ++k) {
+      const Real t_hi = pe2(k + 1);
+      // the source layer that holds the upper interface of the target layer
+      while (!(t_lo >= s_lo && t_lo <= s_hi) && c < km - 1) advance();
+      Real val;
+      if (!(t_lo >= s_lo && t_lo <= s_hi)) {
+        val = Q1(k);  // (not reached for interface sets that share their end points)
+      } else {
         const Real dl = s_hi - s_lo;
         const Real pl = (t_lo - s_lo) / dl;
-        const Prof a = profile(l);
+        profile();
         if (t_hi <= s_hi) {
           const Real pr = (t_hi - s_lo) / dl;
-          val = a.a2 + (Real)0.5 * (a.a4 + a.a3 - a.a2) * (pr + pl) - a.a4 * RM_R3 * (pr * (pr + pl) + pl * pl);
-          k0 = l;
+          val = cur.a2 + (Real)0.5 * (cur.a4 + cur.a3 - cur.a2) * (pr + pl) - cur.a4 * RM_R3 * (pr * (pr + pl) + pl * pl);
         } else {
-          Real qsum = (s_hi - t_lo) * (a.a2 + (Real)0.5 * (a.a4 + a.a3 - a.a2) * ((Real)1.0 + pl) - a.a4 * (RM_R3 * ((Real)1.0 + pl * ((Real)1.0 + pl))));
-          for (int m = l + 1; m < km; ++m) {
-            const Real m_lo = pe1(m), m_hi = pe1(m + 1);
-            if (t_hi > m_hi) {
-              qsum = qsum + (m_hi - m_lo) * Q1(m);
+          Real qsum = (s_hi - t_lo) * (cur.a2 + (Real)0.5 * (cur.a4 + cur.a3 - cur.a2) * ((Real)1.0 + pl) - cur.a4 * (RM_R3 * ((Real)1.0 + pl * ((Real)1.0 + pl))));
+          while (c < km - 1) {
+            advance();
+            if (t_hi > s_hi) {
+              qsum = qsum + (s_hi - s_lo) * qw2;
             } else {
-              const Real dp = t_hi - m_lo, esl = dp / (m_hi - m_lo);
-              const Prof b = profile(m);
-              qsum = qsum + dp * (b.a2 + (Real)0.5 * esl * (b.a3 - b.a2 + b.a4 * ((Real)1.0 - RM_R23 * esl)));
-              k0 = m;
+              const Real dp = t_hi - s_lo, esl = dp / (s_hi - s_lo);
+              profile();
+              qsum = qsum + dp * (cur.a2 + (Real)0.5 * esl * (cur.a3 - cur.a2 + cur.a4 * ((Real)1.0 - RM_R23 * esl)));
               break;
             }
           }
           val = qsum / (t_hi - t_lo);
         }
-        break;
       }
+      OUT(k, val);
+      t_lo = t_hi;
     }
-    OUT(k, val);
-    t_lo = t_hi;
   }
 }
 
