@@ -730,10 +730,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   if (b_split) {
     // W / E windows transposed (lanes along j), then S / N
     const int e0 = g.nx - 3;
-    launch3(c, s, Box{-1, g.ny + 2, 0, 6, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_a(t, kp, b_ - 1, a); });
-    launch3(c, s, Box{-1, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_a(t, kp, e0 + b_, a); });
-    launch3(c, s, Box{6, g.nx - 4, -1, 5, 0, nkc - 1}, stage_a);
-    launch3(c, s, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, nkc - 1}, stage_a);
+    launch_frame(c, s, Frame{{Box{-1, 5, -1, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, -1, g.ny + 2, 0, 0}, Box{6, g.nx - 4, -1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_a);
   } else {
     launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nkc - 1}, stage_a);
   }
@@ -944,10 +941,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       // (one right-sized launch per window: launch3w sizes every window's grid for the largest one)
       // (the 6-column W / E windows run transposed -- lanes along j -- so that a wave has 64 busy lanes instead of 6)
       const int e0 = g.nx - 3;
-      launch3(c, s, Box{0, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_b(t, kp, b_, a); });
-      launch3(c, s, Box{0, g.ny + 2, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_b(t, kp, e0 + b_, a); });
-      launch3(c, s, Box{6, g.nx - 4, 0, 5, 0, nkc - 1}, stage_b);
-      launch3(c, s, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, nkc - 1}, stage_b);
+      launch_frame(c, s, Frame{{Box{0, 5, 0, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 2, 0, 0}, Box{6, g.nx - 4, 0, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_b);
     } else {
       launch3(c, s, nat, stage_b);
     }
@@ -1052,10 +1046,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     };
     if (march) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
       const int e0 = g.nx - 3;
-      launch3(c, s, Box{1, g.ny + 1, 1, 5, 0, npair - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_c(t, kp, b_, a); });
-      launch3(c, s, Box{1, g.ny + 1, 0, 4, 0, npair - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_c(t, kp, e0 + b_, a); });
-      launch3(c, s, Box{6, g.nx - 4, 1, 5, 0, npair - 1}, stage_c);
-      launch3(c, s, Box{6, g.nx - 4, g.ny - 3, g.ny + 1, 0, npair - 1}, stage_c);
+      launch_frame(c, s, Frame{{Box{1, 5, 1, g.ny + 1, 0, npair - 1}, Box{e0, e0 + 4, 1, g.ny + 1, 0, 0}, Box{6, g.nx - 4, 1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 3, g.ny + 1, 0, 0}}}, stage_c);
     } else {
       launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, npair - 1}, stage_c);
     }
@@ -1146,10 +1137,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   };
   if (fused) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
     const int e0 = g.nx - 4;
-    launch3(c, s, Box{0, g.ny + 1, 0, 6, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_d(t, kp, b_, a); });
-    launch3(c, s, Box{0, g.ny + 1, 0, 5, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_d(t, kp, e0 + b_, a); });
-    launch3(c, s, Box{7, g.nx - 5, 0, 6, 0, nkc - 1}, stage_d);
-    launch3(c, s, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, nkc - 1}, stage_d);
+    launch_frame(c, s, Frame{{Box{0, 6, 0, g.ny + 1, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 0, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_d);
   } else {
     launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nkc - 1}, stage_d);
   }
@@ -1191,10 +1179,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const int nke = (nz1 + KC) / KC - 1;
     if (fused) {
       const int e0 = g.nx - 4;
-      launch3(c, s, Box{1, g.ny + 1, 1, 6, 0, nke}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_e(t, kp, b_, a); });
-      launch3(c, s, Box{1, g.ny + 1, 0, 5, 0, nke}, [=] FV3_HD(int t, int kp, int a, int b_) { stage_e(t, kp, e0 + b_, a); });
-      launch3(c, s, Box{7, g.nx - 5, 1, 6, 0, nke}, stage_e);
-      launch3(c, s, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, nke}, stage_e);
+      launch_frame(c, s, Frame{{Box{1, 6, 1, g.ny + 1, 0, nke}, Box{e0, e0 + 5, 1, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 1, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_e);
     } else {
       launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nke}, stage_e);
     }
