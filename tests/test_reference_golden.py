@@ -1,9 +1,9 @@
 """Parity against savepoints of the REFERENCE (pyFV3 numpy backend), when they exist.
 
-`tools/gen_golden.py` writes them inside an environment where pyFV3 imports; none exists in this
-tree's containers, so `test_c_sw_against_reference_savepoints` skips with "reference parity unpinned"
-(SURVEY §8c).  `test_savepoint_checker_on_oracle_generated_files` runs the very same checker on
-savepoint files written from the numpy oracle, so the checker itself is exercised.
+`tools/gen_golden.py` writes them (C_SW-In/Out, D_SW-In/Out of the first acoustic sub-step) inside an environment where
+pyFV3 imports; none exists in this tree's containers, so the `*_against_reference_savepoints` tests skip with "reference
+parity unpinned" (SURVEY §8c).  The `test_*_checker_on_oracle_generated_files` tests run the very same checkers on savepoint
+files written from the numpy oracle, so the checkers themselves are exercised.
 """
 import glob
 import os
@@ -71,6 +71,95 @@ def check_c_sw_savepoints(path, backend, rank=0, nx=12, grid_file=True):
         sc = np.abs(want).max()
         errs[var] = float(np.abs(got - want).max() / (sc if sc > 0 else 1.0))
     return errs, grid_diffs
+
+
+# D_SW savepoint variable -> (our name, region offsets as above); variable list [REF tests/savepoint/thresholds/fv_dynamics.yaml:76-170]
+DSW_OUT = {"delpd": ("delp", (1, 0, 1, 0)), "ptd": ("pt", (1, 0, 1, 0)), "wd": ("w", (1, 0, 1, 0)), "ud": ("u", (1, 0, 1, 1)), "vd": ("v", (1, 1, 1, 0)),
+           "mfxd": ("mfxd", (1, 1, 1, 0)), "mfyd": ("mfyd", (1, 0, 1, 1)), "xfxd": ("xfx", (1, 1, 1, 0)), "yfxd": ("yfx", (1, 0, 1, 1)),
+           "divgdd": ("divgd", (1, 1, 1, 1))}
+
+
+def check_d_sw_savepoints(path, backend, rank=0, nx=12, grid_file=True):
+    """Feed D_SW-In of call 0 to fv3_d_sw and compare with D_SW-Out; returns {var: max field-relative error}.  The reference's
+    checkpoint carries no q_con / cx / cy (dry run: q_con = 0; the accumulated Courant numbers are not compared)."""
+    inp = dict(np.load(os.path.join(path, f"D_SW-In_call0_rank{rank}.npz")))
+    out = dict(np.load(os.path.join(path, f"D_SW-Out_call0_rank{rank}.npz")))
+    nz = inp["delpd"].shape[2] - 1
+    part = CubedSpherePartitioner(nx, (1, 1))
+    g = make_grid(part, rank, nz=nz)
+    gf = os.path.join(path, f"grid_rank{rank}.npz")
+    if grid_file and os.path.exists(gf):
+        ref = np.load(gf)
+        for name in ref.files:
+            if name in g.fields and ref[name].shape == g.fields[name].shape:
+                g.fields[name] = np.array(ref[name])
+        for name in ("ak", "bk"):
+            if name in ref.files:
+                setattr(g, name, np.array(ref[name]).ravel())
+    cfg = AcousticDynamicsConfig(npx=nx + 1, npy=nx + 1, npz=nz, layout=(1, 1))
+    sf = StencilFactory([g], cfg, get_constants(), backend=backend)
+    qf = sf.quantity_factory
+    nzp = nz + 1
+    src = {"delpc": "delpcd", "delp": "delpd", "pt": "ptd", "u": "ud", "v": "vd", "w": "wd", "uc": "ucd", "vc": "vcd", "ua": "uad", "va": "vad", "divgd": "divgdd",
+           "mfxd": "mfxd", "mfyd": "mfyd", "zh": "zhd"}
+    Q = {n: qf.from_array([_pad(inp[v], nzp)], ("x", "y", "z")) for n, v in src.items() if v in inp}
+    for n in ("zh", "delpc"):
+        Q.setdefault(n, qf.zeros(("x", "y", "z")))
+    T = {n: qf.zeros(("x", "y", "z")) for n in ("cxd", "cyd", "crx", "cry", "xfx", "yfx", "q_con", "heat", "diss")}
+    dt = cfg.dt_atmos / cfg.k_split / cfg.n_split
+    sf.call("d_sw", Q["delpc"].fref, *[Q[n].fref for n in ("delp", "pt", "u", "v", "w", "uc", "vc", "ua", "va", "divgd", "mfxd", "mfyd")], T["cxd"].fref, T["cyd"].fref,
+            T["crx"].fref, T["cry"].fref, T["xfx"].fref, T["yfx"].fref, T["q_con"].fref, Q["zh"].fref, T["heat"].fref, T["diss"].fref, dt)
+    Q.update(T)
+    errs = {}
+    o = 2
+    for var, (ours, (i0, di, j0, dj)) in DSW_OUT.items():
+        if var not in out:
+            continue
+        sl = (slice(i0 + o, nx + di + o + 1), slice(j0 + o, nx + dj + o + 1), slice(0, nz))
+        got, want = Q[ours].numpy(0)[sl], out[var][sl]
+        sc = np.abs(want).max()
+        errs[var] = float(np.abs(got - want).max() / (sc if sc > 0 else 1.0))
+    return errs
+
+
+def test_d_sw_against_reference_savepoints(hostemu):
+    if not glob.glob(os.path.join(GOLDEN, "D_SW-In_call0_rank*.npz")):
+        pytest.skip("reference parity unpinned: tests/golden/golden_c12 is absent (generate it with tools/gen_golden.py where pyFV3 imports)")
+    errs = check_d_sw_savepoints(GOLDEN, "hostemu")
+    # magnitudes of the reference's own thresholds [REF tests/savepoint/thresholds/fv_dynamics.yaml:125-170]
+    bad = {k: v for k, v in errs.items() if v > 1e-9}
+    assert not bad, f"d_sw differs from the reference savepoints: {bad} (all: {errs})"
+
+
+def test_d_sw_checker_on_oracle_generated_files(hostemu, tmp_path):
+    """Write D_SW-In/Out files in the generator's format from the numpy oracle and run the checker on them."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle"))
+    from fv3_oracle import d_sw as o_dsw
+    from fv3_oracle.util import Dom
+    from pace_amd.init import synthetic_state
+
+    nx, nz = 12, 5
+    part = CubedSpherePartitioner(nx, (1, 1))
+    g = make_grid(part, 0, nz=nz)
+    cfg = AcousticDynamicsConfig(npx=nx + 1, npy=nx + 1, npz=nz, layout=(1, 1))
+    D = Dom(g, get_constants())
+    x = {k: v[:, :, :nz].copy() for k, v in synthetic_state(g, seed=5, rank=0).items() if k != "phis"}
+    x["uc"], x["vc"] = 0.7 * x["v"], 0.7 * x["u"]
+    x["ua"], x["va"] = 0.9 * np.roll(x["u"], 1, 1), 0.9 * np.roll(x["v"], 1, 0)
+    x["divgd"], x["q_con"] = 1e-6 * x["w"], np.zeros_like(x["u"])
+    x["mfxd"], x["mfyd"], x["cxd"], x["cyd"] = (np.zeros_like(x["u"]) for _ in range(4))
+    pad = lambda a: _pad(a, nz + 1)  # noqa: E731
+    z = lambda: np.zeros_like(x["u"])  # noqa: E731
+    np.savez(tmp_path / "D_SW-In_call0_rank0.npz", delpcd=pad(z()), zhd=pad(z()), **{v: pad(x[n]) for n, v in (("delp", "delpd"), ("pt", "ptd"), ("u", "ud"), ("v", "vd"),
+             ("w", "wd"), ("uc", "ucd"), ("vc", "vcd"), ("ua", "uad"), ("va", "vad"), ("divgd", "divgdd"), ("mfxd", "mfxd"), ("mfyd", "mfyd"))})
+    o = dict(delpc=z(), crx=z(), cry=z(), xfx=z(), yfx=z(), heat=z(), diss=z())
+    dt = cfg.dt_atmos / cfg.k_split / cfg.n_split
+    o_dsw.d_sw(D, cfg, o_dsw.get_column_namelist(cfg, nz), o["delpc"], x["delp"], x["pt"], x["u"], x["v"], x["w"], x["uc"], x["vc"], x["ua"], x["va"], x["divgd"], x["mfxd"],
+               x["mfyd"], x["cxd"], x["cyd"], o["crx"], o["cry"], o["xfx"], o["yfx"], x["q_con"], None, o["heat"], o["diss"], dt)
+    np.savez(tmp_path / "D_SW-Out_call0_rank0.npz", delpd=pad(x["delp"]), ptd=pad(x["pt"]), wd=pad(x["w"]), ud=pad(x["u"]), vd=pad(x["v"]), mfxd=pad(x["mfxd"]),
+             mfyd=pad(x["mfyd"]), xfxd=pad(o["xfx"]), yfxd=pad(o["yfx"]), divgdd=pad(x["divgd"]))
+    errs = check_d_sw_savepoints(str(tmp_path), "hostemu", grid_file=False)
+    assert set(errs) == set(DSW_OUT) and max(errs.values()) < 1e-11, errs
 
 
 def test_c_sw_against_reference_savepoints(hostemu):
