@@ -152,7 +152,7 @@ def main(argv=None):
                    # the reference collector's layout (times.<timer>.times per rank), under a timer name of its own
                    "times": {"acoustic_mainloop": {"times": per_rank, "hits": [len(t) for t in per_rank]}},
                    "acoustic_simulated_days_per_day": sdpd}, open(out, "w"))
-        say(f"{n_steps} steps of dt_atmos={run['dt_atmos']:g}s: acoustic mainloop mean (first step dropped) {mean * 1e3:.2f} ms -> {sdpd:.2f} simulated-days/day (acoustic dynamics only); state finite: {ok}; wrote {out}")
+        say(f"{n_steps} steps of dt_atmos={run['dt_atmos']:g}s: acoustic mainloop mean (first step dropped) {mean * 1e3:.2f} ms -> {sdpd:.2f} simulated-days/day ({'acoustic dynamics only' if not (a.tracers or a.remap) else 'acoustic dynamics' + (f' + {a.tracers} tracers' if a.tracers else '') + (' + remap' if a.remap else '')}); state finite: {ok}; wrote {out}")
     return 0
 
 
