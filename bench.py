@@ -151,8 +151,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (test hooks for a 1-GPU box: FV3_FORCE_DEVICE=0 puts every rank on GPU 0, FV3_DIST_BACKEND=gloo exchanges through
+        #  pinned host memory -- RCCL needs one device per rank; tests/test_gpu_invariants.py runs the N = 2 path this way)
+        backend = os.environ.get("FV3_DIST_BACKEND", "nccl")
+        if "FV3_FORCE_DEVICE" in os.environ:
+            local_rank = int(os.environ["FV3_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     kw = dict(CONFIGS[a.config])
     if a.nz:
         kw["nz"] = a.nz
@@ -195,6 +203,21 @@ def main():
         elapsed = float(tt.item())
     sanity = h.sanity()
     ok = all(v[2] for v in sanity.values())
+
+    def gather_parts(mine):
+        import torch.distributed as dist
+
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        return every
+
+    checksum = h.checksum(gather_parts if world > 1 else None)
+    if world > 1:
+        import torch.distributed as dist
+
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        ok = all(flags)
     if rank == 0:
         cfg = h.cfg
         s_per_step = elapsed / a.steps
@@ -232,7 +255,7 @@ def main():
                 "cells_global": h.cells_global,
             },
             "finite": ok,
-            "state_checksum": h.checksum(),
+            "state_checksum": checksum,
         }
         if "d_sw" in op_ms:
             alg = D_SW_PASSES * (8 if a.precision == 64 else 4) * h.cells_local

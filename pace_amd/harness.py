@@ -143,12 +143,26 @@ class DycoreHarness:
         if not self.sf.hostemu:
             torch.cuda.synchronize(self.sf.device)
 
-    def checksum(self):
-        """Order-fixed float64 sums of the prognostic fields (bitwise comparable between runs of one build)."""
+    def checksum_parts(self):
+        """Per-sub-domain float64 sums of the prognostic fields (local sub-domains, in rank order)."""
         out = {}
         for n in ("delp", "pt", "u", "v", "w", "delz", "q_con"):
             q = getattr(self.state, n)
-            out[n] = float(sum(q.sub(i).view[...][..., : self.cfg.npz].double().sum().item() for i in range(q.n_sub)))
+            out[n] = [float(q.sub(i).view[...][..., : self.cfg.npz].double().sum().item()) for i in range(q.n_sub)]
+        return out
+
+    def checksum(self, gather=None):
+        """Order-fixed float64 sums of the prognostic fields: the per-sub-domain sums added in global rank order, so the value is
+        bitwise comparable between runs of one build whatever the number of processes (`gather`: a callable that returns the
+        list of every process's `checksum_parts()` in process order; None = single process)."""
+        parts = [self.checksum_parts()] if gather is None else gather(self.checksum_parts())
+        out = {}
+        for n in parts[0]:
+            tot = 0.0
+            for p in parts:
+                for v in p[n]:
+                    tot += v
+            out[n] = tot
         return out
 
     def sanity(self):

@@ -141,3 +141,29 @@ def test_alternative_kernel_forms_agree(tmp_path, toggle):
     name, val = toggle.split("=")
     subprocess.run([sys.executable, tool, "--out", alt] + size, check=True, env=dict(env, **{name: val}), timeout=600)
     subprocess.run([sys.executable, tool, "--compare", base, alt, "--rtol", "1e-11"], check=True, timeout=60)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_reproduce_the_single_process_state(tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU", barrier + max-over-ranks timing,
+    rank 0 prints the line) -- on this 1-GPU box both ranks share GPU 0 and exchange over gloo (test hooks of bench.py; with one
+    device per rank the same plans run over RCCL).  The line carries n_gpus = 2 and the SAME state checksum as the one-process
+    run: the decomposition over processes does not change a bit of the result."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--config", "c48", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-op-timing"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, check=True, env=env, timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
+    two = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+         os.path.join(root, "bench.py"), "--gpus", "2"] + args,
+        check=True, env=dict(env, FV3_FORCE_DEVICE="0", FV3_DIST_BACKEND="gloo"), timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["finite"] and l2["scaling"] == "strong"
+    assert l2["metric"] == l1["metric"] and l2["config"]["workload"].split(",")[0] == l1["config"]["workload"].split(",")[0]
+    assert l2["state_checksum"] == l1["state_checksum"], (l1["state_checksum"], l2["state_checksum"])
