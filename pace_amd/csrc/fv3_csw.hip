@@ -119,15 +119,9 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
   // Launch geometry: the "plane" an XCD walks (fv3_grid) is one (sub-domain, strip, segment) tile and the tiles of the plane are
   // its levels, so the waves resident on an XCD are all the levels of a few tiles and share the metric rows in that XCD's L2.
   const int ntile = nstrip * nseg;
-#ifdef CSW_EXP_PLANE
-  launch_waves<CSW_WPE>(c, s, nstrip, nseg, nk * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
-    const int t = blk.bz / nk, k = blk.bz - t * nk, tby = blk.by, tbx = blk.bx;
-    (void)ntile;
-#else
   launch_waves<CSW_WPE>(c, s, nk, 1, ntile * g.nsub, 0, [=] FV3_HD(const Blk &blk, char *) {
     const int k = blk.bx, t = blk.bz / ntile, tile = blk.bz - t * ntile;
     const int tby = tile / nstrip, tbx = tile - tby * nstrip;
-#endif
     const CswRect rc = csw_rect(gp->flags[t], nx, ny, npx, npy);
     const int c0 = rc.i_lo + tbx * CSW_OUT;
     const int ja = rc.j_lo + tby * seg;
@@ -172,11 +166,7 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
       pcol0 = pbase + (unsigned)(lc0 + CSW_CPL - 1 <= Led ? lc0 : Led - (CSW_CPL - 1));
     }
 #define CSW_ROW(dst, ptr, rowoff) fv3_ld_cpl<CSW_CPL>(dst, (ptr) + (pcol0 + (unsigned)(rowoff)));
-#ifdef CSW_EXP_UNCOND
-#define CSW_STORE(ptr, rowoff, src, ownarr) { const bool all_[2] = {true, true}; (void)ownarr; fv3_st_cpl<CSW_CPL>((ptr) + (pcol0 + (unsigned)(rowoff)), src, all_); }
-#else
 #define CSW_STORE(ptr, rowoff, src, ownarr) fv3_st_cpl<CSW_CPL>((ptr) + (pcol0 + (unsigned)(rowoff)), src, ownarr);
-#endif
 #endif
     // the metric terms of step R_: rows R_-2 (cs .. c4) and R_-1 (cv .. s2) of the lane's own columns (sin_sg3 / cos_sg3 of the
     // column to the west come from the neighbouring slot)
@@ -246,9 +236,7 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
       FV3_VLANES_END
       CSW_ROW(nu2, ub, rn)
       CSW_ROW(nv2, vb, rn)
-#ifndef CSW_EXP_NOMET
       CSW_LOAD_MET(R + 1)
-#endif
       // ---- phase 2: vtmp of row R; ua / va / uc / ut of row R-2, vc / vt of row R-1; the u-face term of the divergence
       CSW_LANES(vl, l)
         const Real vt_new = CSW_A2 * (CSW_SHR(1, s_v) + CSW_SHL(2, s_v)) + CSW_A1 * (s_v[l] + CSW_SHL(1, s_v));
@@ -279,19 +267,6 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
         s4_prev[l] = mc_s4[l];
         s2_prev[l] = mc_s2[l];
       FV3_VLANES_END
-#ifdef CSW_EXP_UNCOND
-      {
-        const int jrc = (jr < ja ? ja : jr > jb ? jb : jr) * sj32, jvc = (jv < ja ? ja : jv > jb ? jb : jv) * sj32;
-        CSW_STORE(ua + b, jrc, o_a, own)
-#ifndef CSW_EXP_FEWST
-        CSW_STORE(va + b, jrc, o_b, own)
-        CSW_STORE(uc + b, jrc, o_c, own)
-        CSW_STORE(ut + b, jrc, o_d, own)
-        CSW_STORE(vc + b, jvc, o_e, own)
-        CSW_STORE(vt + b, jvc, o_f, own)
-#endif
-      }
-#else
       if (row_r) {
         CSW_STORE(ua + b, jr * sj32, o_a, own)
         CSW_STORE(va + b, jr * sj32, o_b, own)
@@ -302,7 +277,6 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
         CSW_STORE(vc + b, jv * sj32, o_e, own)
         CSW_STORE(vt + b, jv * sj32, o_f, own)
       }
-#endif
       // ---- phase 3: the v-face term and the divergence of the corner (lc, R-2)
       if (do_div) {
         CSW_LANES(vl, l)
@@ -312,11 +286,7 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
           o_a[l] = mc_rac[l] * dv;
           vf_prev[l] = vf;
         FV3_VLANES_END
-#ifdef CSW_EXP_UNCOND
-        CSW_STORE(divgd + b, (jr < ja ? ja : jr > jb ? jb : jr) * sj32, o_a, own_d)
-#else
         if (row_r && jr >= 1) CSW_STORE(divgd + b, jr * sj32, o_a, own_d)
-#endif
       }
     }
 #undef CSW_ROW
