@@ -299,14 +299,25 @@ inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
 
 // ---------------------------------------------------------------------------------------------
 // The frame of a sub-domain (the windows along its W / E / S / N boundary that the interior marching kernels leave to the
-// generic per-point stage kernels): f(t, k, i, j) on w[0], w[1] (W / E: a few columns wide, run TRANSPOSED -- the 64 lanes of
-// a wave along j, or a wave would have 6 busy lanes) and on w[2], w[3] (S / N: lanes along i).  k runs over b.k0 .. b.k1 of
+// generic per-point stage kernels): f(t, k, i, j) on w[0], w[1] (W / E: a few columns wide: 8 x 32 workgroups, fv3_k3n) and on
+// w[2], w[3] (S / N: the usual 64 x 4 workgroups).  k runs over b.k0 .. b.k1 of
 // w[0] (the level chunks).  One launch per window; FV3_FRAME_MERGED: all four in one launch (slower, kept for A/B).
 // ---------------------------------------------------------------------------------------------
 struct Frame {
   Box w[4];
 };
 #ifndef FV3_HOST_EMU
+// narrow windows (a few columns wide): a workgroup is 8 columns x 32 rows, so a wave reads 8 rows of 64 contiguous bytes (lanes
+// along j -- the transposed form -- made every lane of a load its own 128-byte line: 6 x the time of an S / N window of equal size)
+template <class F>
+__global__ void __launch_bounds__(256) fv3_k3n(Box b, int nkc, GridMap m, F f) {
+  int bx, by, kz;
+  if (!fv3_tile(m, bx, by, kz)) return;
+  const int t = kz / nkc;
+  const int k = b.k0 + (kz - t * nkc);
+  const int i = b.i0 + (int)(bx * 8 + (threadIdx.x & 7)), j = b.j0 + (int)(by * 32 + (threadIdx.x >> 3));
+  if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+}
 template <class F>
 __global__ void __launch_bounds__(256) fv3_kfr(Frame fr, int nkc, GridMap m, F f) {
   int bx, by, kz;
@@ -335,10 +346,19 @@ inline void launch_frame(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f)
     Box b = fr.w[w];
     b.k0 = fr.w[0].k0;
     b.k1 = fr.w[0].k1;
-    if (w < 2)
+    if (w < 2) {
+#ifdef FV3_FRAME_TRANSPOSED  // A/B form: lanes along j
       launch3(c, s, Box{b.j0, b.j1, b.i0, b.i1, b.k0, b.k1}, [=] FV3_HD(int t, int k, int a, int bb) { f(t, k, bb, a); });
-    else
+#else
+      const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nkc = b.k1 - b.k0 + 1;
+      if (ni <= 0 || nj <= 0 || nkc <= 0) continue;
+      dim3 grid;
+      const GridMap m = fv3_grid((ni + 7) / 8, (nj + 31) / 32, c->g.nsub * nkc, &grid);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3n<F>), grid, dim3(256, 1, 1), 0, s, b, nkc, m, f);
+#endif
+    } else {
       launch3(c, s, b, f);
+    }
   }
   return;
 #endif
@@ -355,6 +375,31 @@ inline void launch_frame(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f)
   const GridMap m = fv3_grid((nl + 63) / 64, (nw + 3) / 4, 4 * c->g.nsub * nkc, &grid);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kfr<F>), grid, block, 0, s, fr, nkc, m, f);
 #endif
+}
+
+// launch_frame with the window index handed to the body: f(w, t, k, i, j), w = 0 (W), 1 (E), 2 (S), 3 (N) -- for bodies that
+// test the sub-domain's tile-edge flag of their side and leave the corner cells to the column windows.  KCH 1 (k = level).
+template <class F>
+inline void launch_frame_w(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f) {
+  for (int w = 0; w < 4; ++w) {
+    Box b = fr.w[w];
+    b.k0 = fr.w[0].k0;
+    b.k1 = fr.w[0].k1;
+    auto fw = [=] FV3_HD(int t, int k, int i, int j) { f(w, t, k, i, j); };
+#ifdef FV3_HOST_EMU
+    launch3(c, s, b, fw);
+#else
+    if (w < 2) {
+      const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nkc = b.k1 - b.k0 + 1;
+      if (ni <= 0 || nj <= 0 || nkc <= 0) continue;
+      dim3 grid;
+      const GridMap m = fv3_grid((ni + 7) / 8, (nj + 31) / 32, c->g.nsub * nkc, &grid);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3n<decltype(fw)>), grid, dim3(256, 1, 1), 0, s, b, nkc, m, fw);
+    } else {
+      launch3(c, s, b, fw);
+    }
+#endif
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -995,23 +995,12 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   } else {
     ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, nz1);
     // frame: the 3 outermost corner rows / columns next to a cube-tile edge
-    const int nfr = g.nx + 1 > g.ny + 1 ? g.nx + 1 : g.ny + 1;
-    launch3(c, s, Box{1, nfr, 1, 12, 0, nz1}, [=] FV3_HD(int t, int k, int a, int side) {
+    // (W / E: columns 1..3 / npx-2..npx as narrow windows, S / N: rows 1..3 / npy-2..npy; the corner cells belong to the column windows)
+    launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, 0, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
+                   [=] FV3_HD(int w_, int t, int k, int i, int j) {
       const int fl = g.flags[t];
-      int i, j;
-      // side 1-3: columns 1..3 (W)   4-6: columns npx-2..npx (E)   7-9: rows 1..3 (S)   10-12: rows npy-2..npy (N)
-      if (side <= 6) {
-        if (a > g.ny + 1) return;
-        if (!(fl & (side <= 3 ? FV3_W : FV3_E))) return;
-        i = side <= 3 ? side : g.npx - 6 + side;
-        j = a;
-      } else {
-        if (a > g.nx + 1) return;
-        if (!(fl & (side <= 9 ? FV3_S : FV3_N))) return;
-        j = side <= 9 ? side - 6 : g.npy - 12 + side;
-        i = a;
-        if (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2)) return;  // covered by the column sides
-      }
+      if (!(fl & (w_ == 0 ? FV3_W : w_ == 1 ? FV3_E : w_ == 2 ? FV3_S : FV3_N))) return;
+      if (w_ >= 2 && (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2))) return;  // covered by the column windows
       ke_point(t, k, i, j);
     });
   }

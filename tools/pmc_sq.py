@@ -15,11 +15,11 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"fv3_k(?:wg|[23bw])<(?:\d+, )*(.*?)::\{lambda.*?#(\d+)\}", name)
+    m = re.search(r"fv3_k(?:wg|3n|fr|[23bw])<(?:\d+, )*(.*?)::\{lambda.*?#(\d+)\}", name)
     if m:
         fn = re.sub(r"\(.*\)", "", m.group(1).replace("(anonymous namespace)::", ""))
         return f"{fn}#{m.group(2)}"
-    m = re.search(r"fv3_k(?:wg|[23bw])<(?:\d+, )*Z*L?\d*([A-Za-z_0-9]+)\(", name)
+    m = re.search(r"fv3_k(?:wg|3n|fr|[23bw])<(?:\d+, )*Z*L?\d*([A-Za-z_0-9]+)\(", name)
     if m:
         return m.group(1)
     return re.sub(r"\(.*", "", name)[:50]
