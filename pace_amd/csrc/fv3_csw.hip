@@ -698,7 +698,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
   };
   if (b_split) {
-    // W / E windows transposed (lanes along j), then S / N
+    // the four windows along the sub-domain boundary (launch_frame: W / E as narrow 8 x 32 workgroups, S / N as they lie)
     const int e0 = g.nx - 3;
     launch_frame(c, s, Frame{{Box{-1, 5, -1, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, -1, g.ny + 2, 0, 0}, Box{6, g.nx - 4, -1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_a);
   } else {
@@ -909,7 +909,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const Box nat{0, g.nx + 2, 0, g.ny + 2, 0, nkc - 1};
     if (b_split) {
       // (one right-sized launch per window: launch3w sizes every window's grid for the largest one)
-      // (the 6-column W / E windows run transposed -- lanes along j -- so that a wave has 64 busy lanes instead of 6)
+      // (the 6-column W / E windows run as 8-column x 32-row workgroups: launch_frame)
       const int e0 = g.nx - 3;
       launch_frame(c, s, Frame{{Box{0, 5, 0, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 2, 0, 0}, Box{6, g.nx - 4, 0, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_b);
     } else {
@@ -1014,7 +1014,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
         (divgd + b)[IX(i, j)] = rac * dv;
       }
     };
-    if (march) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
+    if (march) {  // the four windows along the sub-domain boundary
       const int e0 = g.nx - 3;
       launch_frame(c, s, Frame{{Box{1, 5, 1, g.ny + 1, 0, npair - 1}, Box{e0, e0 + 4, 1, g.ny + 1, 0, 0}, Box{6, g.nx - 4, 1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 3, g.ny + 1, 0, 0}}}, stage_c);
     } else {
@@ -1105,7 +1105,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
     }
   };
-  if (fused) {  // the four windows along the sub-domain boundary (W / E transposed: lanes along j)
+  if (fused) {  // the four windows along the sub-domain boundary
     const int e0 = g.nx - 4;
     launch_frame(c, s, Frame{{Box{0, 6, 0, g.ny + 1, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 0, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_d);
   } else {
