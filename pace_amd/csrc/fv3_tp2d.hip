@@ -480,6 +480,9 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 #ifndef TS_WPE
 #define TS_WPE 2  // waves per SIMD the register allocation is sized for
 #endif
+#ifndef TS_LDS_ONLY
+#define TS_LDS_ONLY 0
+#endif
 #ifndef TS_PF
 #define TS_PF 2  // rows fetched ahead of their use (1 or 2)
 #endif
@@ -581,6 +584,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
     const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
+    Real sqx[FV3_LPT], sqi[FV3_LPT], sxv[FV3_LPT], smb[FV3_LPT];  // strips away from the W / E tile edges: what the neighbouring lanes read (wavefront shuffles)
     Real wdu[FV3_LPT], wdv[FV3_LPT];  // vorticity-damping increments of u (face r-2) / v (row r-3)
     const bool wdamp = C_WIND && wind_du != nullptr && wind_don[k] > (Real)1.0e-5;
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
@@ -623,6 +627,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       a1[l] = a2[l] = a3[l] = (Real)1;  // (warm-up steps: outputs masked, keep the divisions finite)
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       wu[l] = wdx[l] = wkf[l] = wke[l] = wv[l] = wdy[l] = wkr[l] = wdu[l] = wdv[l] = (Real)0;
+      sqx[l] = sqi[l] = sxv[l] = smb[l] = (Real)0;
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
@@ -638,6 +643,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
     auto march = [&](auto xe_tag) {
       constexpr bool XE = decltype(xe_tag)::value;
+      constexpr bool LX = XE || TS_LDS_ONLY;  // neighbour reads through the LDS lines (tile-edge strips; TS_LDS_ONLY: everywhere, the A/B form)
       auto step = [&](int r) {
         const int r3 = r - 3 < jsd ? jsd : r - 3;
         const int rn = r + TS_PF < r_end ? r + TS_PF : r_end;
@@ -725,10 +731,15 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           p_prev[l] = pn;
           ypp[l] = y_prev[l];
           y_prev[l] = yv;
-          lq[3 + lane] = qx;
-          lqi[3 + lane] = qi;
+          if constexpr (LX) {
+            lq[3 + lane] = qx;
+            lqi[3 + lane] = qi;
+          } else {
+            sqx[l] = qx;
+            sqi[l] = qi;
+          }
         }
-        blk.wave_sync();
+        if constexpr (LX) blk.wave_sync();
         // ---- phase 2: inner x-flux on row r, outer x-flux on row r-3, fx(row r-3)
         const int jr = r - 3;
         const bool fx_row = jr >= ja && jr <= jb && jr <= ny;
@@ -744,15 +755,27 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             auto Qi = [&](int s_) { return lqi[s_ - i0 + 6]; };
             auto Mx3 = [&](int s_) { return emr[((r - 3) & 3) * 8 + EI(s_)]; };
             fxout = ppm_flux(Qi, Mx3, cx3[l], i, W, E, npx, hord);
-          } else {
+          } else if constexpr (LX) {
             const Real *a = lq + lane, *bq = lqi + lane;
             fxin = ppm_flux_int(a[0], a[1], a[2], a[3], a[4], a[5], cx, hord);
             fxout = ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord);
+          } else {
+            // the six cells around the face from the neighbouring lanes' registers (DPP wave_shr / wave_shl: no LDS line, no ordering point)
+            const Real a0 = FV3_LANE_SHR(3, sqx, l, lane), a1_ = FV3_LANE_SHR(2, sqx, l, lane), a2_ = FV3_LANE_SHR(1, sqx, l, lane), a3_ = sqx[l],
+                       a4 = FV3_LANE_SHL(1, sqx, l, lane), a5 = FV3_LANE_SHL(2, sqx, l, lane);
+            const Real b0 = FV3_LANE_SHR(3, sqi, l, lane), b1 = FV3_LANE_SHR(2, sqi, l, lane), b2 = FV3_LANE_SHR(1, sqi, l, lane), b3 = sqi[l],
+                       b4 = FV3_LANE_SHL(1, sqi, l, lane), b5 = FV3_LANE_SHL(2, sqi, l, lane);
+            fxin = ppm_flux_int(a0, a1_, a2_, a3_, a4, a5, cx, hord);
+            fxout = ppm_flux_int(b0, b1, b2, b3, b4, b5, cx3[l], hord);
           }
           {
             Real v = (Real)0.5 * (fxout + fi3[l]) * (mfx_ ? o_mx[l] : xv3[l]);
-            // (mass of the west cell = the neighbouring lane's mb, through an LDS line instead of a second load of the field)
-            if (on) v = mass_ ? v + (Real)0.5 * damp * ((lane > 0 ? exm[lane - 1] : (Real)0) + mb[l]) * o_dx[l] : v + o_dx[l];
+            Real mwest;  // mass of the west cell = the neighbouring lane's mb (read outside the selections: a shuffle needs every lane)
+            if constexpr (LX)
+              mwest = lane > 0 ? exm[lane - 1] : (Real)0;
+            else
+              mwest = FV3_LANE_SHR(1, smb, l, lane);
+            if (on) v = mass_ ? v + (Real)0.5 * damp * (mwest + mb[l]) * o_dx[l] : v + o_dx[l];
             if (wflux_ && fx_row && own_x[l]) {
               const unsigned p = pcol[l] + (unsigned)(jr * sj32);  // own lanes: ic == i
               (fx + b)[p] = v;
@@ -766,10 +789,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
             if (epi_out_) {
               fxk[l] = v;
-              exf[lane] = v;
+              if constexpr (LX) exf[lane] = v;
               if (area_form_) {
                 xjr[l] = xv3[l];
-                exj[lane] = xv3[l];
+                if constexpr (LX) exj[lane] = xv3[l];
               }
             }
           }
@@ -783,15 +806,34 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           xv2[l] = xv1[l];
           xv1[l] = xv;
           px[l] = xv * fxin;
-          exp_[lane] = px[l];
-          exx[lane] = xv;
+          if constexpr (LX) {
+            exp_[lane] = px[l];
+            exx[lane] = xv;
+          } else {
+            sxv[l] = xv;
+          }
         }
-        blk.wave_sync();
+        if constexpr (LX) blk.wave_sync();
         // ---- phase 3: q_j on row r, outer y-flux at face r-2, fy(face r-2)
         const int jf = r - 2;
         const bool fy_row = jf >= ja && jf <= jb;
         FV3_LANES(blk, lane, l) {
-          const Real p1 = exp_[lane + 1], x1 = exx[lane + 1];
+          Real p1, x1, fxe = (Real)0, xje = (Real)0;  // the east neighbour's values
+          if constexpr (LX) {
+            p1 = exp_[lane + 1];
+            x1 = exx[lane + 1];
+            if (epi_out_) {
+              fxe = exf[lane + 1];
+              if (area_form_) xje = exj[lane + 1];
+            }
+          } else {
+            p1 = FV3_LANE_SHL(1, px, l, lane);
+            x1 = FV3_LANE_SHL(1, sxv, l, lane);
+            if (epi_out_) {
+              fxe = FV3_LANE_SHL(1, fxk, l, lane);
+              if (area_form_) xje = FV3_LANE_SHL(1, xjr, l, lane);
+            }
+          }
           const Real ar = cur[l].ar;
           const Real qj = (cur[l].qy * ar + px[l] - p1) / (ar + cur[l].xv - x1);
           v2[l] = v3[l];
@@ -831,12 +873,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 const Real mu = epi_mult_ ? (epi_mult_ == mass_ ? mb[l] : emu[l]) : (Real)1;
                 if (area_form_) {
                   const Real ar_ = a3[l];
-                  const Real ra_x = ar_ + xjr[l] - exj[lane + 1], ra_y = ar_ + ypp[l] - cur[l].yv;
-                  Real z = (qc * ar_ + fxk[l] - exf[lane + 1] + fyp[l] - v) / (ra_x + ra_y - ar_);
+                  const Real ra_x = ar_ + xjr[l] - xje, ra_y = ar_ + ypp[l] - cur[l].yv;
+                  Real z = (qc * ar_ + fxk[l] - fxe + fyp[l] - v) / (ra_x + ra_y - ar_);
                   if (zdamp) z = z + (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
                   (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = z;
                 } else {
-                  const Real dv_ = (fxk[l] - exf[lane + 1] + fyp[l] - v) * era[l];
+                  const Real dv_ = (fxk[l] - fxe + fyp[l] - v) * era[l];
                   (epi_out_ + b)[pcol[l] + (unsigned)(jr * sj32)] = epi_mult_ ? mu * qc + dv_ : qc + dv_;
                 }
               }
@@ -844,12 +886,16 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
           }
           mb[l] = o_mc[l];
-          if (on && mass_) exm[lane] = mb[l];
+          if constexpr (LX) {
+            if (on && mass_) exm[lane] = mb[l];
+          } else {
+            smb[l] = mb[l];
+          }
           a3[l] = a2[l];
           a2[l] = a1[l];
           a1[l] = cur[l].ar;
         }
-        blk.wave_sync();
+        if constexpr (LX) blk.wave_sync();
       };
       // The prefetched rows rotate through TS_PF + 1 register sets (cur <- nxt <- nx2).  Rolled, the rotation is
       // register copies at the loop head, and a copy of a row still in flight is a full vmcnt(0) drain every
