@@ -64,9 +64,9 @@ def _inputs(n, layout, nz, n_tracers):
     return part, cfg, grids, odyn, ost, tr, wsd
 
 
-@pytest.mark.parametrize("n, layout, n_tracers", [(12, (1, 1), 2), (12, (2, 2), 1)])
-def test_remap_matches_the_oracle(backend, n, layout, n_tracers):
-    nz = 12
+@pytest.mark.parametrize("n, layout, n_tracers, nz", [(12, (1, 1), 2, 12), (12, (2, 2), 1, 12), (24, (1, 1), 1, 79)])
+def test_remap_matches_the_oracle(backend, n, layout, n_tracers, nz):
+    """(the third case: the reference's 79 levels -- sponge layers, the thin top layers, the full depth of the edge-value system)"""
     part, cfg, grids, odyn, ost, tr, wsd = _inputs(n, layout, nz, n_tracers)
     c = get_constants()
     sf = StencilFactory(grids, cfg, c, backend=backend)
