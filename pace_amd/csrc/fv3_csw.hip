@@ -3,9 +3,12 @@
 // CPU twin: oracle/fv3_oracle/c_sw.py.  [SURVEY A.2; reference operator CGridShallowWaterDynamics,
 // checkpoint variables REF tests/savepoint/thresholds/fv_dynamics.yaml:2-75]
 //
-// 5 launches: (A) ua/va  (B) uc,ut / vc,vt with the dt2*dy*sin geometry factor folded in
-// (C) corner divergence  (D) delpc, ptc, wc, ke + absolute vorticity  (E) uc/vc update.
-// utmp / vtmp of d2a2c_vect are pure functions of (u, v) and are evaluated in registers.
+// Five stages: (A) ua/va  (B) uc,ut / vc,vt with the dt2*dy*sin geometry factor folded in  (C) corner divergence
+// (D) delpc, ptc, wc, ke + absolute vorticity  (E) uc/vc update.  utmp / vtmp of d2a2c_vect are pure functions of (u, v)
+// and are evaluated in registers.
+// Default form: ONE marching wave kernel does all five stages on the interior rectangle of every sub-domain (csw_fused_stream);
+// the generic per-point stage kernels at the end of this file finish the windows along the sub-domain boundary, where the
+// tile-edge formulas live.  FV3_CSW_MARCH=abc / =0 and FV3_CSW_B_GENERIC select the earlier forms (bitwise equal, A/B tests).
 #include "fv3_ops.h"
 
 #define CSW_A1 ((Real)0.5625)
