@@ -61,3 +61,14 @@ def test_driver_runs_the_reference_c12_config_shape(tmp_path):
     times = d["times"]["acoustic_mainloop"]["times"]
     assert len(times) == 6 and all(len(t) == 3 for t in times)  # one entry per rank and step, as the reference collector
     assert d["setup"]["finite"] and d["acoustic_simulated_days_per_day"] > 0
+
+
+@pytest.mark.gpu
+def test_driver_runs_the_step_dynamics_body(tmp_path):
+    """--tracers N --remap: k_split x [acoustic call, tracer advection, vertical remap]; the json says so."""
+    p = tmp_path / "c.yaml"
+    p.write_text(YAML)
+    out = tmp_path / "perf.json"
+    assert driver.main([str(p), "--steps", "3", "--tracers", "2", "--remap", "--out", str(out)]) == 0
+    d = json.load(open(out))
+    assert not d["setup"]["acoustic_only"] and d["setup"]["tracers"] == 2 and d["setup"]["remap"] and d["setup"]["finite"]
