@@ -24,9 +24,10 @@ def main():
     ap.add_argument("--n-split", type=int, default=6)
     ap.add_argument("--tracers", type=int, default=2)
     ap.add_argument("--no-remap", action="store_true")
+    ap.add_argument("--precision", type=int, default=64)
     a = ap.parse_args()
     h = DycoreHarness(a.nx, nz=a.nz, layout=(1, 1), dt_atmos=a.dt, k_split=a.k_split, n_split=a.n_split, init="baroclinic", n_tracers=a.tracers,
-                      remap=not a.no_remap, device="cuda:0")
+                      remap=not a.no_remap, device="cuda:0", dtype=torch.float64 if a.precision == 64 else torch.float32)
     n, nz = a.nx, a.nz
     area = [torch.as_tensor(g.area[3 : 3 + n, 3 : 3 + n], device="cuda:0") for g in h.grids]
 
