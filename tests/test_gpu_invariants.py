@@ -95,10 +95,11 @@ def test_fp32_build_tracks_fp64(gpu_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4)])
+@pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4), (48, 1, 6)])
 def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, world):
     """The same cube stepped by one process and by `world` processes (C48: 6 sub-domains split 3 + 3;
-    C24 layout 2x2: 24 sub-domains, 6 per process, tiles straddling processes as on 4 / 8 GPUs;
+    C24 layout 2x2: 24 sub-domains, 6 per process, tiles straddling processes as on 4 / 8 GPUs; C48 on 6 processes: ONE
+    sub-domain per process, the shape of BASELINE's "6 tiles -> 6 GPUs" configuration;
     messages over gloo staged through pinned host memory because the box has one GPU; the 8-GPU
     bench uses RCCL with the identical pack / unpack plans) must give bitwise equal fields."""
     import subprocess
