@@ -9,7 +9,8 @@ times 1 + U(-1e-16, 1e-16)), threshold = 10 x the largest difference to the firs
 [REF tests/savepoint/thresholds/fv_dynamics.yaml:2-170].  Those magnitudes say how strongly one C_SW / D_SW call amplifies
 last-bit noise in each variable -- a property of the ALGORITHM.  Running the same procedure on the oracle (C12 L79,
 baroclinic wave, 6 ranks, one acoustic sub-step) and landing orders of magnitude away from the reference's numbers for a
-variable would point at a restatement error in what feeds that variable.  It does not lift "parity unpinned" (the
+variable would point at a restatement error in what feeds that variable.  Since round 2 the trial also runs the oracle's
+vertical remap after the acoustic call and compares the `Remapping-Out` variables the same way.  It does not lift "parity unpinned" (the
 reference's data stay external); it is the only reference-held NUMBER there is to hold the oracle against.
 
     python tests/threshold_study.py [--write]      # --write: refresh tests/golden/threshold_study_c12.json
@@ -47,6 +48,9 @@ NOT_COMPARABLE = {
     "delpcd": "dead work array after d_sw: the two implementations leave different scratch data in it",
     "wd": "w == 0 in the analytic state and c_sw / d_sw keep it 0; the reference's serialized state has w != 0",
 }
+# (Remapping-Out: every variable listed is compared; the reference run is the moist nwat = 6 configuration with the saturation
+#  adjustment inside its remap, the oracle's is dry -- orders of magnitude are what is being compared)
+
 
 
 def perturb(states, rng):
@@ -81,6 +85,21 @@ def one_trial(seed, perturbed):
     for sp, op, table in (("C_SW-Out", "c_sw", C_SW_OUT), ("D_SW-Out", "d_sw", D_SW_OUT)):
         for var, idx in table.items():
             out[f"{sp}/{var}"] = [np.asarray(c["outs"][idx]).copy() for c in rec.calls[op][:6]]
+    # the vertical remap that closes step_dynamics (k_split = 1: the reference's single remap is its last step, which leaves the
+    # temperature in pt -- compared with our pt * pkz)  [REF tests/savepoint/thresholds/fv_dynamics.yaml:227-326]
+    from fv3_oracle import remap as o_remap
+
+    c = get_constants()
+    for r, D in enumerate(dyn.doms):
+        s = init[r]
+        C = D.sl(1, D.nx, 1, D.ny)
+        o_remap.lagrangian_to_eulerian(D, c, s, dyn.tmp[r]["wsd"].copy(), [])
+        for var in ("delp", "delz", "pe", "peln", "pk", "pkz", "w"):
+            kk = nz + 1 if var in ("pe", "peln", "pk") else nz
+            out.setdefault(f"Remapping-Out/{var}", []).append(s[var][C][:, :, :kk].copy())
+        out.setdefault("Remapping-Out/pt", []).append((s["pt"][C][:, :, :nz] * s["pkz"][C][:, :, :nz]).copy())
+        out.setdefault("Remapping-Out/u", []).append(s["u"][D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz].copy())
+        out.setdefault("Remapping-Out/v", []).append(s["v"][D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz].copy())
     return out
 
 

@@ -9,6 +9,9 @@ fixtures are *data* the reference tree holds, down-selected:
 * c12_restart_tile1.npz - real FV3 C12 L63 state of tile 1 (u, v, W, DZ, T,
   delp, phis, sphum, liq_wat) + ak/bk(64)
   [REF tests/main/data/c12_restart/fv_core.res.tile1.nc, fv_tracer.res.tile1.nc, fv_core.res.nc]
+* reference_thresholds_fv_dynamics.json - the reference's own calibrated savepoint thresholds (absolute / relative per variable)
+  of the C_SW-Out, D_SW-Out, Tracer2D1L-Out and Remapping-In / Out savepoints
+  [REF tests/savepoint/thresholds/fv_dynamics.yaml:2-360]
 """
 import json
 import os
@@ -53,9 +56,26 @@ def c12_restart():
     print("c12_restart_tile1.npz", {k: v.shape for k, v in out.items()})
 
 
+def thresholds():
+    import yaml
+
+    d = yaml.safe_load(open(os.path.join(REF, "tests/savepoint/thresholds/fv_dynamics.yaml")))["savepoints"]
+    out = {}
+    for sec in ("C_SW-Out", "D_SW-Out", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out"):
+        for item in d[sec]:
+            for var, v in item.items():
+                a, r = v.get("absolute"), v.get("relative")
+                if a is None or a != a:  # (nan entries: the reference holds no number)
+                    continue
+                out[f"{sec}/{var}"] = {"absolute": float(a), "relative": None if r is None or r != r else float(r)}
+    json.dump(out, open(os.path.join(OUT, "reference_thresholds_fv_dynamics.json"), "w"), indent=1, sort_keys=True)
+    print("reference_thresholds_fv_dynamics.json", len(out), "entries")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference")
     os.makedirs(OUT, exist_ok=True)
     eta79()
     c12_restart()
+    thresholds()
