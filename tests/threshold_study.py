@@ -93,6 +93,9 @@ def one_trial(seed, perturbed):
     for r, D in enumerate(dyn.doms):
         s = init[r]
         C = D.sl(1, D.nx, 1, D.ny)
+        # what the acoustic call hands to the tracer advection: the accumulated Courant numbers [REF fv_dynamics.yaml:328-343]
+        out.setdefault("Tracer2D1L-In/cxd", []).append(s["cxd"][D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz].copy())
+        out.setdefault("Tracer2D1L-In/cyd", []).append(s["cyd"][D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz].copy())
         o_remap.lagrangian_to_eulerian(D, c, s, dyn.tmp[r]["wsd"].copy(), [])
         for var in ("delp", "delz", "pe", "peln", "pk", "pkz", "w"):
             kk = nz + 1 if var in ("pe", "peln", "pk") else nz

@@ -10,7 +10,7 @@ fixtures are *data* the reference tree holds, down-selected:
   delp, phis, sphum, liq_wat) + ak/bk(64)
   [REF tests/main/data/c12_restart/fv_core.res.tile1.nc, fv_tracer.res.tile1.nc, fv_core.res.nc]
 * reference_thresholds_fv_dynamics.json - the reference's own calibrated savepoint thresholds (absolute / relative per variable)
-  of the C_SW-Out, D_SW-Out, Tracer2D1L-Out and Remapping-In / Out savepoints
+  of the C_SW-Out, D_SW-Out, Tracer2D1L-In / Out and Remapping-In / Out savepoints
   [REF tests/savepoint/thresholds/fv_dynamics.yaml:2-360]
 """
 import json
@@ -61,7 +61,7 @@ def thresholds():
 
     d = yaml.safe_load(open(os.path.join(REF, "tests/savepoint/thresholds/fv_dynamics.yaml")))["savepoints"]
     out = {}
-    for sec in ("C_SW-Out", "D_SW-Out", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out"):
+    for sec in ("C_SW-Out", "D_SW-Out", "Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out"):
         for item in d[sec]:
             for var, v in item.items():
                 a, r = v.get("absolute"), v.get("relative")
