@@ -279,6 +279,13 @@ def main():
                 "algorithmic_bytes_per_call": alg,
                 "ms_per_call": op_ms["d_sw"],
             }
+        # the same fraction for every operator with a pass count in SURVEY §8a (algorithmic bytes per cell = passes x sizeof(Real))
+        passes = {"c_sw": 15, "update_dz_c": 4, "riem_solver_c": 8, "p_grad_c": 7, "d_sw": D_SW_PASSES, "update_dz_d": 6, "riem_solver3": 11, "nh_p_grad": 8}
+        line["roofline_operators"] = {
+            k: {"ms": op_ms[k], "algorithmic_GB": p_ * (8 if a.precision == 64 else 4) * h.cells_local / 1e9,
+                "frac": p_ * (8 if a.precision == 64 else 4) * h.cells_local / (op_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            for k, p_ in passes.items() if k in op_ms and op_ms[k] > 0
+        }
         line["operators_ms_per_substep"] = op_ms
         if not a.no_cpu_baseline:
             per_cell, sample, cores = cpu_baseline()
