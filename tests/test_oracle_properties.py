@@ -122,17 +122,21 @@ def test_oracle_roundoff_growth_matches_the_reference_thresholds():
 
     rows = threshold_study.main(["--trials", "6"])
     comparable = {k: v for k, v in rows.items() if v["comparable"] and v["log10_ratio"] is not None}
-    assert len(comparable) >= 28, sorted(comparable)
+    assert len(comparable) >= 38, sorted(comparable)
     # Remapping-Out/u, v: the reference's numbers are its Remapping-IN thresholds carried through (2.2e-11 / 1.2e-11 on both sides:
     # noise of its own acoustic call incl. moist terms); the oracle's winds enter the remap with 1e-12 and leave with 1e-12 -- the
     # remap adds nothing in either, so only "not larger" is required of those two
-    loose = {"Remapping-Out/u", "Remapping-Out/v"}
+    loose = {"Remapping-Out/u", "Remapping-Out/v", "Remapping-In/u", "Remapping-In/v", "Remapping-In/wsd"}
     bad = {k: v["log10_ratio"] for k, v in comparable.items() if (v["log10_ratio"] > 1.0 or (v["log10_ratio"] < -1.0 and k not in loose) or v["log10_ratio"] < -2.0)}
     assert not bad, bad
     # the remap's own variables land ON the reference's numbers (delp 1.46e-10, pe 4.37e-10, peln 1.78e-14, pk 2.49e-13, T 4.5e-10,
     # delz 1.3e-10, w 1.4e-12): within 0.15 decades
     for k in ("delp", "delz", "pe", "peln", "pk", "pkz", "pt", "w"):
         assert abs(comparable[f"Remapping-Out/{k}"]["log10_ratio"]) < 0.15, (k, comparable[f"Remapping-Out/{k}"])
+    # ... and so does what the whole acoustic call leaves (Remapping-In: the Riemann solvers' w and delz, the pressures): within 0.15
+    # decades (delz 1.27e-10 vs 1.21e-10, w 1.47e-12 vs 1.50e-12, pt 2.1e-13 vs 2.8e-13, pe / peln / pk equal)
+    for k in ("delz", "pe", "peln", "pk", "pt", "w"):
+        assert abs(comparable[f"Remapping-In/{k}"]["log10_ratio"]) < 0.15, (k, comparable[f"Remapping-In/{k}"])
 
 
 @pytest.mark.parametrize("rank", [4, 0])

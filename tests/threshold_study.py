@@ -96,6 +96,13 @@ def one_trial(seed, perturbed):
         # what the acoustic call hands to the tracer advection: the accumulated Courant numbers [REF fv_dynamics.yaml:328-343]
         out.setdefault("Tracer2D1L-In/cxd", []).append(s["cxd"][D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz].copy())
         out.setdefault("Tracer2D1L-In/cyd", []).append(s["cyd"][D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz].copy())
+        # the state the whole acoustic call (incl. the Riemann solvers, the height updates, the pressure gradient) leaves: Remapping-In
+        for var in ("delp", "delz", "pe", "peln", "pk", "pt", "w"):
+            kk = nz + 1 if var in ("pe", "peln", "pk") else nz
+            out.setdefault(f"Remapping-In/{var}", []).append(s[var][C][:, :, :kk].copy())
+        out.setdefault("Remapping-In/u", []).append(s["u"][D.sl(1, D.nx, 1, D.ny + 1)][:, :, :nz].copy())
+        out.setdefault("Remapping-In/v", []).append(s["v"][D.sl(1, D.nx + 1, 1, D.ny)][:, :, :nz].copy())
+        out.setdefault("Remapping-In/wsd", []).append(dyn.tmp[r]["wsd"][C].copy())
         o_remap.lagrangian_to_eulerian(D, c, s, dyn.tmp[r]["wsd"].copy(), [])
         for var in ("delp", "delz", "pe", "peln", "pk", "pkz", "w"):
             kk = nz + 1 if var in ("pe", "peln", "pk") else nz
