@@ -136,6 +136,15 @@ struct fv3_ctx {
   void *xfer_user = nullptr;
   fv3_halo_plan *halo_plans[FV3_HALO_COUNT] = {nullptr};
   Real *ak_dev = nullptr, *bk_dev = nullptr;  // hybrid-coordinate tables on the device (fv3_remap.hip)
+  // Ping-pong of the four scalars d_sw rewrites (delp, pt, w, q_con; fv3_step.hip): d_sw's marches read the old fields through
+  // their halo columns / rows while they produce the new ones, so they write beside them.  Inside fv3_acoustic_step the new
+  // fields simply BECOME the state for the operators that follow (no copy-back); every second sub-step lands in the caller's
+  // arrays again.  pp_buf: the alternate buffers (allocated with the context); pp_from / pp_to: the pointer translation the
+  // registered halo plans apply while the state lives in the alternates.
+  Real *pp_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
+  void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
+  int pp_n = 0;
   // per-operator profiling (fv3_step.hip)
   int profiling = 0;
   struct ProfEvent {

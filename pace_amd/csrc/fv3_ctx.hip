@@ -295,6 +295,19 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     c->scratch.push_back(p);
   }
   {
+    // alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong (FV3_PINGPONG=0: not allocated, the
+    // sequencer then uses d_sw's copy-back form)
+    const char *e = getenv("FV3_PINGPONG");
+    if (!(e && e[0] == '0'))
+      for (auto &pb : c->pp_buf) {
+        pb = (Real *)fv3_dev_alloc(c, (size_t)g.st * g.nsub * sizeof(Real));
+        if (!pb) {
+          fv3_ctx_destroy(c);
+          return fv3_fail(nullptr, FV3_ERR_NOMEM, "device allocation of the ping-pong buffers failed");
+        }
+      }
+  }
+  {
     Geo *gd = (Geo *)fv3_dev_alloc(c, sizeof(Geo));
     if (!gd) {
       fv3_ctx_destroy(c);

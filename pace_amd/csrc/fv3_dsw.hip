@@ -759,11 +759,15 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
   }
 }
 
-extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,
-                        const fv3_field *w_, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_,
-                        const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
-                        const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
-                        const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream) {
+// o_*: where the new delp / pt / w / q_con go.  Null: in place (the operator's own contract: the marches write beside the old
+// fields, which their neighbours still read, and a copy-back follows); fv3_acoustic_step hands in the other half of its
+// ping-pong pair instead and the copy-back disappears.
+int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,
+                 const fv3_field *w_, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_,
+                 const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
+                 const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
+                 const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream,
+                 const fv3_field *o_delp_, const fv3_field *o_pt_, const fv3_field *o_w_, const fv3_field *o_q_con_) {
   if (!c) return FV3_ERR_ARG;
   FV3_FIELD(delpc, delpc_) FV3_FIELD(delp, delp_) FV3_FIELD(pt, pt_) FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(w, w_) FV3_FIELD(uc, uc_)
   FV3_FIELD(vc, vc_) FV3_FIELD(ua, ua_) FV3_FIELD(va, va_) FV3_FIELD(divgd, divgd_) FV3_FIELD(mfx, mfx_) FV3_FIELD(mfy, mfy_) FV3_FIELD(cx, cx_)
@@ -771,6 +775,17 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
   FV3_FIELD(heat_source, heat_source_)
   (void)zh_;
   (void)diss_est_;  // accumulated only with do_skeb (unsupported); kept for signature parity
+  const bool oop = o_delp_ != nullptr;  // out of place
+  Real *o_delp = delp, *o_pt = pt, *o_w = w, *o_q_con = q_con;
+  if (oop) {
+    if (!o_pt_ || !o_w_ || !o_q_con_) return fv3_fail(c, FV3_ERR_ARG, "d_sw: the four output fields come together");
+    o_delp = fv3_chk(c, o_delp_, "o_delp");
+    o_pt = fv3_chk(c, o_pt_, "o_pt");
+    o_w = fv3_chk(c, o_w_, "o_w");
+    o_q_con = fv3_chk(c, o_q_con_, "o_q_con");
+    if (!o_delp || !o_pt || !o_w || !o_q_con) return FV3_ERR_ARG;
+    if (o_delp == delp || o_pt == pt || o_w == w || o_q_con == q_con) return fv3_fail(c, FV3_ERR_ARG, "d_sw: an output field aliases its input");
+  }
   const Geo g = c->g;
   fv3_stream_t s = (fv3_stream_t)stream;
   const Real dt = (Real)dtd;
@@ -807,7 +822,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     //      divisions by the new air mass and w's damping increment / heat (fv3_tp4.hip).  The march reads the old
     //      fields through its halo columns / rows while it produces the new ones, so it writes beside them.
     Real *dQ_x = c->scratch[SC_C], *dQ_y = c->scratch[SC_D], *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
-    Real *n_dp = c->scratch[SC_N], *n_w = c->scratch[SC_O], *n_qc = c->scratch[SC_P], *n_pt = c->scratch[SC_Q];
+    Real *n_dp = oop ? o_delp : c->scratch[SC_N], *n_w = oop ? o_w : c->scratch[SC_O], *n_qc = oop ? o_q_con : c->scratch[SC_P], *n_pt = oop ? o_pt : c->scratch[SC_Q];
     fv3_signal(c, s, 0);
     fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s2, 0);
@@ -820,7 +835,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
     DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
                   cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt};
     dsw_scalars_stream(c, s, q4, scalars_mode);
-    launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+    if (!oop) launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       delp[p] = n_dp[p];
       pt[p] = n_pt[p];
@@ -882,8 +897,8 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
       const unsigned q = IX(i, j);
       const long p = b + q;
       const Real dpnv = dpn[p];
-      delp[p] = dpnv;
-      pt[p] = pt_dp[p] / dpnv;
+      o_delp[p] = dpnv;
+      o_pt[p] = pt_dp[p] / dpnv;
       Real wn = w_dp[p] / dpnv, hs = (Real)0;
       if (g.damp_w[k] > (Real)1.0e-5) {
         const Real dd8 = g.ke_bg[k] * fabs(dt);
@@ -891,9 +906,9 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
         hs = dd8 - dwv * (w[p] + (Real)0.5 * dwv);  // (w[p]: still the pre-transport value)
         wn = wn + dwv;
       }
-      w[p] = wn;
+      o_w[p] = wn;
       heat_s[p] = hs;
-      q_con[p] = qc_dp[p] / dpnv;
+      o_q_con[p] = qc_dp[p] / dpnv;
     });
   }
 
@@ -1120,11 +1135,20 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
         const Real fx0 = (v_pre + b)[p] * rdy0, fx1 = (v_pre + b)[pe_] * rdy1;
         const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
         const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
-        hs = (delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
+        hs = (o_delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
                                      ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2)));
       }
       if (heat_on) (heat_source + b)[p] += hs;
     }
   });
   return fv3_post(c, s, "d_sw");
+}
+
+extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, const fv3_field *pt_, const fv3_field *u_, const fv3_field *v_,
+                        const fv3_field *w_, const fv3_field *uc_, const fv3_field *vc_, const fv3_field *ua_, const fv3_field *va_,
+                        const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
+                        const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
+                        const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream) {
+  return fv3_d_sw_out(c, delpc_, delp_, pt_, u_, v_, w_, uc_, vc_, ua_, va_, divgd_, mfx_, mfy_, cx_, cy_, crx_, cry_, xfx_, yfx_, q_con_, zh_, heat_source_,
+                      diss_est_, dtd, stream, nullptr, nullptr, nullptr, nullptr);
 }

@@ -85,6 +85,10 @@ int run_ops(fv3_ctx *c, fv3_halo_plan *p, int kind, void *stream) {
     void *dst = o.dst;
     const void *src = o.src;
     int64_t dks = o.dst_kstride, sks = o.src_kstride;
+    for (int n = 0; n < c->pp_n; ++n) {  // the state fields that currently live in their alternate buffers (fv3_step.hip)
+      if (dst == c->pp_from[n]) dst = c->pp_to[n];
+      if (src == c->pp_from[n]) src = c->pp_to[n];
+    }
     if (kind == FV3_HALO_PACK) {
       dst = (char *)p->send_buf[o.peer] + (size_t)o.buf_off * sizeof(Real);
       dks = o.buf_kstride;

@@ -114,6 +114,12 @@ void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2
 
 // a2b_ord4: qout levels kout0.. from qin levels kin0.. (nk levels); replace writes back into qin
 void a2b_ord4(fv3_ctx *c, fv3_stream_t s, Real *qin, Real *qout, int kin0, int kout0, int nk, bool replace, Real scale = (Real)1);
+// fv3_d_sw with the new delp / pt / w / q_con written to o_* instead of in place (all four, or all null = fv3_d_sw)
+int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc, const fv3_field *delp, const fv3_field *pt, const fv3_field *u, const fv3_field *v, const fv3_field *w,
+                 const fv3_field *uc, const fv3_field *vc, const fv3_field *ua, const fv3_field *va, const fv3_field *divgd, const fv3_field *mfx,
+                 const fv3_field *mfy, const fv3_field *cx, const fv3_field *cy, const fv3_field *crx, const fv3_field *cry, const fv3_field *xfx,
+                 const fv3_field *yfx, const fv3_field *q_con, const fv3_field *zh, const fv3_field *heat_source, const fv3_field *diss_est, double dt,
+                 void *stream, const fv3_field *o_delp, const fv3_field *o_pt, const fv3_field *o_w, const fv3_field *o_q_con);
 int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u, const fv3_field *v, const fv3_field *pp, const fv3_field *gz, const fv3_field *pk3, const fv3_field *delp,
                          double dt, double ptop, double akap, double gz_scale, void *stream);
 int fv3_update_dz_c_from(fv3_ctx *c, const fv3_field *zs, const fv3_field *ut, const fv3_field *vt, const fv3_field *gz_in, const fv3_field *gz, const fv3_field *ws,

@@ -45,6 +45,29 @@ struct OpTimer {
   }
 };
 
+// part = 0: the whole allocation; 1: the compute cells of a cell-centred field only; 2: the frame around them (levels 0..nz-1)
+int copy_part(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, int part, void *stream) {
+  FV3_FIELD(a, src) FV3_FIELD(b, dst)
+  const Geo g = c->g;
+  auto cp = [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    b[p] = a[p];
+  };
+  fv3_stream_t s = (fv3_stream_t)stream;
+  const int ia = -g.o, ib = g.ni - 1 - g.o, ja = -g.o, jb = g.nj - 1 - g.o;
+  if (part == 0) {
+    launch3<4>(c, s, Box{ia, ib, ja, jb, 0, g.nz}, cp);
+  } else if (part == 1) {
+    launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, g.nz - 1}, cp);
+  } else {
+    launch3<4>(c, s, Box{ia, ib, ja, 0, 0, g.nz - 1}, cp);
+    launch3<4>(c, s, Box{ia, ib, g.ny + 1, jb, 0, g.nz - 1}, cp);
+    launch3<4>(c, s, Box{ia, 0, 1, g.ny, 0, g.nz - 1}, cp);
+    launch3<4>(c, s, Box{g.nx + 1, ib, 1, g.ny, 0, g.nz - 1}, cp);
+  }
+  return fv3_post(c, s, "copy_part");
+}
+
 }  // namespace
 
 extern "C" int fv3_ctx_set_profiling(fv3_ctx *c, int on) {
@@ -113,6 +136,38 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   const double dt = timestep / n_split, dt2 = 0.5 * dt;
   const double ptop = c->ptop, akap = c->cst.rdgas / c->cst.cp_air;
 
+  // Ping-pong of delp / pt / w / q_con (see fv3_ctx::pp_buf): d_sw writes the new fields into the other half of the pair and
+  // the operators that follow -- and the registered halo plans, through the pointer translation -- use that half; after an
+  // even number of sub-steps the state is back in the caller's arrays, after an odd number one copy brings it there.
+  // Only with the registered plans (a host callback moves the caller's own arrays) and when the buffers exist.
+  const bool pingpong = !halo && c->pp_buf[0] != nullptr;
+  fv3_field f_delp[2] = {st->delp, st->delp}, f_pt[2] = {st->pt, st->pt}, f_w[2] = {st->w, st->w}, f_qc[2] = {st->q_con, st->q_con};
+  if (pingpong) {
+    f_delp[1].ptr = c->pp_buf[0];
+    f_pt[1].ptr = c->pp_buf[1];
+    f_w[1].ptr = c->pp_buf[2];
+    f_qc[1].ptr = c->pp_buf[3];
+    c->pp_from[0] = st->delp.ptr;
+    c->pp_from[1] = st->pt.ptr;
+    c->pp_from[2] = st->w.ptr;
+    c->pp_from[3] = st->q_con.ptr;
+    for (int n = 0; n < 4; ++n) c->pp_to[n] = c->pp_buf[n];
+  }
+  c->pp_n = 0;  // 4 while the state lives in the alternate buffers
+  int cur = 0;
+  struct PpGuard {  // (no early return leaves the halo translation switched on)
+    fv3_ctx *c;
+    ~PpGuard() { c->pp_n = 0; }
+  } pp_guard{c};
+
+  if (pingpong) {
+    // cells no operator and no halo update ever writes (the 3 x 3 blocks beyond a cube corner, the allocation padding) keep the
+    // caller's values in both halves of a pair, so that nothing -- not even a discarded corner value -- depends on the half
+    RUN(FV3_OP_GLUE, copy_part(c, &st->delp, &f_delp[1], 2, stream));
+    RUN(FV3_OP_GLUE, copy_part(c, &st->pt, &f_pt[1], 2, stream));
+    RUN(FV3_OP_GLUE, copy_part(c, &st->w, &f_w[1], 2, stream));
+    RUN(FV3_OP_GLUE, copy_part(c, &st->q_con, &f_qc[1], 2, stream));
+  }
   HALO(FV3_HALO_Q_CON__CAPPA, 0);
   HALO(FV3_HALO_DELP__PT, 0);
   HALO(FV3_HALO_U__V, 0);
@@ -138,7 +193,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     }
     HALO(FV3_HALO_U__V, 1);
     HALO(FV3_HALO_W, 1);
-    RUN(FV3_OP_C_SW, fv3_c_sw(c, &st->delp, &st->pt, &st->u, &st->v, &st->w, &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
+    RUN(FV3_OP_C_SW, fv3_c_sw(c, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
                               &ws->delpc, &ws->ptc, dt2, stream));
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 0);
     if (it == 0) {
@@ -150,33 +205,57 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c_from(c, &ws->zs, &ws->ut, &ws->vt, &ws->zh, &ws->gz, &ws->ws3, dt2, stream));
     }
     RUN(FV3_OP_RIEM_SOLVER_C,
-        fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &st->q_con, &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
+        fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &f_qc[cur], &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
     RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
     HALO(FV3_HALO_UC__VC, 0);
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 1);
     HALO(FV3_HALO_UC__VC, 1);
-    RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &st->delp, &st->pt, &st->u, &st->v, &st->w, &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
-                              &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &st->q_con, &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+    if (pingpong) {
+      const int nxt = 1 - cur;
+      RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
+                                    &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
+                                    stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt]));
+      cur = nxt;
+      c->pp_n = cur ? 4 : 0;
+    } else {
+      RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
+                                &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+    }
     HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);
     RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
-    RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &st->q_con, &st->delp, &st->pt, &ws->zh, &st->pe,
-                                              &ws->pkc, &ws->pk3, &st->pk, &st->peln, &st->w, stream));
+    RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
+                                              &ws->pkc, &ws->pk3, &st->pk, &st->peln, &f_w[cur], stream));
     HALO(FV3_HALO_ZH, 0);
     HALO(FV3_HALO_PKC, 0);
-    if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &st->delp, ptop, stream));
-    RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &st->delp, ptop, akap, stream));
+    if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &f_delp[cur], ptop, stream));
+    RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &f_delp[cur], ptop, akap, stream));
     HALO(FV3_HALO_ZH, 1);
     HALO(FV3_HALO_PKC, 1);
     // (the reference stores gz = g * zh first -- compute_geopotential; here the corner interpolation reads zh and scales it)
-    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &st->delp, dt, ptop, akap, c->cst.grav, stream));
-    if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &st->w, dt, ptop, stream));
+    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &f_delp[cur], dt, ptop, akap, c->cst.grav, stream));
+    if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &f_w[cur], dt, ptop, stream));
     if (it != n_split - 1) {
       HALO(FV3_HALO_U__V, 0);
     } else {
       HALO(FV3_HALO_INTERFACE_U__V, 0);
       HALO(FV3_HALO_INTERFACE_U__V, 1);
     }
+  }
+  if (pingpong) {
+    // Bring the state home exactly as the in-place sequence leaves it.  delp / pt / q_con: their halos were exchanged after the
+    // last d_sw, in the buffer that holds them.  w: its halo dates from the top of the last sub-step, i.e. it sits in the
+    // buffer d_sw READ from -- the other one.
+    if (cur == 1) {  // odd number of sub-steps
+      RUN(FV3_OP_GLUE, copy_part(c, &f_delp[1], &st->delp, 0, stream));
+      RUN(FV3_OP_GLUE, copy_part(c, &f_pt[1], &st->pt, 0, stream));
+      RUN(FV3_OP_GLUE, copy_part(c, &f_qc[1], &st->q_con, 0, stream));
+      RUN(FV3_OP_GLUE, copy_part(c, &f_w[1], &st->w, 1, stream));
+    } else if (n_split > 0) {
+      RUN(FV3_OP_GLUE, copy_part(c, &f_w[1], &st->w, 2, stream));
+    }
+    cur = 0;
+    c->pp_n = 0;
   }
   if (cf.d_con > 1.0e-5) {
     HALO(FV3_HALO_HEAT_SOURCE, 0);
