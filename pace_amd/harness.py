@@ -60,6 +60,9 @@ class DycoreHarness:
         n_tracers: int = 0,
         hord_tr: int = 8,
         remap: bool = False,
+        init_data=None,
+        ak=None,
+        bk=None,
     ):
         self.c = get_constants()
         self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
@@ -68,20 +71,26 @@ class DycoreHarness:
         self.layout = Layout(self.part, world_size, proc)
         self.layout.group = group
         t0 = time.time()
-        self.grids = [make_grid(self.part, r, nz=nz) for r in self.layout.local_ranks]
+        self.grids = [make_grid(self.part, r, nz=nz, ak=ak, bk=bk) for r in self.layout.local_ranks]
         if verbose:
             print(f"[harness] grid for ranks {self.layout.local_ranks} in {time.time() - t0:.1f}s", flush=True)
         self.sf = StencilFactory(self.grids, self.cfg, self.c, backend=backend, device=device, dtype=dtype)
         self.state = DycoreState(self.sf.quantity_factory)
         t0 = time.time()
         on_device = not self.sf.hostemu
-        if init not in ("synthetic", "baroclinic"):
-            raise ValueError(f"init {init!r}: 'synthetic' (SURVEY §8d recipe) or 'baroclinic' (JW2006 wave)")
+        if init not in ("synthetic", "baroclinic", "restart"):
+            raise ValueError(f"init {init!r}: 'synthetic' (SURVEY §8d recipe), 'baroclinic' (JW2006 wave) or 'restart' (init_data = the six-tile FV3 restart arrays)")
         for i, (g, r) in enumerate(zip(self.grids, self.layout.local_ranks)):
             if init == "baroclinic":
                 from .init import baroclinic_state
 
                 s = baroclinic_state(g, self.c)
+                for n in STATE_NAMES + ["phis"]:
+                    getattr(self.state, n).set_numpy(s[n], i)
+            elif init == "restart":
+                from .init import restart_state
+
+                s = restart_state(g, init_data, self.part.tile_index(r), self.part.origin(r), self.c)
                 for n in STATE_NAMES + ["phis"]:
                     getattr(self.state, n).set_numpy(s[n], i)
             elif on_device:

@@ -346,3 +346,59 @@ def baroclinic_state(grid: GridData, constants: Optional[ConstantSet] = None, pe
     phis[:, :, 0] = jw_surface_geopotential(lat_a, c)
     st["phis"] = phis
     return st
+
+
+# ---------------------------------------------------------------------------------------------
+# A real FV3 model state: the Fortran restart the reference tree holds (C12, L63, six tiles)
+# [REF tests/main/data/c12_restart/fv_core.res.tile[1-6].nc, fv_tracer.res.tile[1-6].nc; read by the reference through
+# FortranRestartInit, driver/pace/driver/initialization.py:174-229, tests/main/driver/test_restart_fortran.py:21-67].
+# ---------------------------------------------------------------------------------------------
+def restart_state(grid: GridData, data, tile: int, origin=(0, 0), constants: Optional[ConstantSet] = None) -> Dict[str, np.ndarray]:
+    """One rank's state from the six-tile restart arrays ``data`` (``tests/golden/c12_restart_6tiles.npz``: per tile
+    ``u[k, y_if, x]``, ``v[k, y, x_if]``, ``W, DZ, T, delp, sphum, liq_wat [k, y, x]``, ``phis[y, x]``), sub-domain at ``origin``
+    (cells) of tile ``tile``.  As the reference does for a Fortran restart: the prognostic fields are taken as they are
+    (u, v, w, delz, delp), pt = T / pkz with the state's own full pressure (non-hydrostatic), pe / peln / pk from ptop + the
+    running sum of delp [REF driver/pace/driver/initialization.py:375-395].  q_con = the liquid-water mixing ratio and
+    cappa = kappa (1 - 0.2 q_con) stand in for moist_cv, which is outside this build.  Halos are NOT model data: they
+    hold edge-replicated values until the first halo update (every operator of the path exchanges before it reads them)."""
+    c = constants or get_constants()
+    nh, nx, ny, nz = grid.n_halo, grid.nx, grid.ny, grid.nz
+    ox, oy = origin
+    shp2 = (nx + 2 * nh + 1, ny + 2 * nh + 1)
+    shp = shp2 + (nz + 1,)
+    st = {n: np.zeros(shp) for n in STATE_3D}
+
+    def cells(name):
+        return np.transpose(np.asarray(data[name][tile], dtype=np.float64), (2, 1, 0))[ox : ox + nx, oy : oy + ny, :nz]
+
+    def place(name, a, ex=0, ey=0):
+        """compute domain (+ the staggered interface) from a; everything else edge-replicated"""
+        full = np.pad(a, ((nh, nh + 1 - ex), (nh, nh + 1 - ey), (0, 1)), mode="edge")
+        st[name][...] = full
+
+    delp, delz, q = cells("delp"), cells("DZ"), cells("liq_wat")
+    # the dycore's temperature is the density temperature T (1 + zvir q_v) (1 - q_con): the equation of state of the moist model
+    # state p = rho R T_v is what balances its pressure gradients (with the dry T the real state sheds its mountains in a few steps)
+    zvir = c.RVGAS / c.RDGAS - 1.0
+    temp = cells("T") * (1.0 + zvir * cells("sphum")) * (1.0 - q)
+    cappa = c.KAPPA * (1.0 - 0.2 * q)
+    pkz = np.exp(cappa * np.log(c.RDG * delp / delz * temp))  # p^cappa of the full (non-hydrostatic) pressure rho R T_v
+    place("delp", delp)
+    place("delz", delz)
+    place("w", cells("W"))
+    place("q_con", q)
+    place("cappa", cappa)
+    place("pt", temp / pkz)
+    place("pkz", pkz)
+    u = np.transpose(np.asarray(data["u"][tile], dtype=np.float64), (2, 1, 0))[ox : ox + nx, oy : oy + ny + 1, :nz]
+    v = np.transpose(np.asarray(data["v"][tile], dtype=np.float64), (2, 1, 0))[ox : ox + nx + 1, oy : oy + ny, :nz]
+    place("u", u, 0, 1)
+    place("v", v, 1, 0)
+    ptop = float(grid.ak[0])
+    pe = np.concatenate([np.full(delp.shape[:2] + (1,), ptop), ptop + np.cumsum(delp, axis=2)], axis=2)
+    for name, a in (("pe", pe), ("peln", np.log(pe)), ("pk", np.exp(c.KAPPA * np.log(pe)))):
+        st[name][...] = np.pad(a, ((nh, nh + 1), (nh, nh + 1), (0, 0)), mode="edge")
+    phis = np.zeros(shp2 + (1,))
+    phis[:, :, 0] = np.pad(np.asarray(data["phis"][tile], dtype=np.float64).T[ox : ox + nx, oy : oy + ny], ((nh, nh + 1), (nh, nh + 1)), mode="edge")
+    st["phis"] = phis
+    return st

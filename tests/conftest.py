@@ -34,3 +34,13 @@ def gpu_backend():
         build.build(64)
     lib.load(64)  # fails loudly if the HIP library is missing
     return "hip:gfx950"
+
+
+@pytest.fixture(params=["hostemu", pytest.param("hip:gfx950", marks=pytest.mark.gpu)])
+def backend(request):
+    """Both builds of the kernel sources: the host emulation (CPU suite) and the HIP library (-m gpu)."""
+    if request.param == "hostemu":
+        request.getfixturevalue("hostemu")
+    else:
+        request.getfixturevalue("gpu_backend")
+    return request.param

@@ -331,45 +331,7 @@ def test_native_and_python_sequencers_are_identical(backend):
     assert prof["d_sw"][1] == 2 and prof["c_sw"][1] == 2 and prof["halo"][1] > 10, prof
 
 
-def test_realistic_restart_values(backend):
-    """Real FV3 C12 fields (L63 restart of the reference tree) regridded onto tile 1 of the cube:
-    exercises limiter / upwind branches with genuine model data
-    [REF tests/main/data/c12_restart/fv_core.res.tile1.nc]."""
-    import os
-
-    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c12_restart_tile1.npz"))
-    nz = 63
-    part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=1), noise=0.0)
-    ak, bk = f["ak"], f["bk"]
-    from pace_amd.grid import make_grid
-
-    grids = [make_grid(part, r, nz=nz, ak=ak, bk=bk) for r in range(6)]
-    from fv3_oracle.dyn_core import OracleAcousticDynamics
-
-    c = odyn.c
-    for s in ost:  # the same real columns on every tile (halo exchange makes them consistent)
-        T = np.transpose(f["T"], (2, 1, 0))
-        delp = np.transpose(f["delp"], (2, 1, 0))
-        dz = np.transpose(f["DZ"], (2, 1, 0))
-        s["delp"][3:15, 3:15, :nz] = delp
-        s["delz"][3:15, 3:15, :nz] = dz
-        s["w"][3:15, 3:15, :nz] = np.transpose(f["W"], (2, 1, 0))
-        s["u"][3:15, 3:16, :nz] = np.transpose(f["u"], (2, 1, 0))
-        s["v"][3:16, 3:15, :nz] = np.transpose(f["v"], (2, 1, 0))
-        q = np.transpose(f["liq_wat"], (2, 1, 0))
-        s["q_con"][3:15, 3:15, :nz] = q
-        s["cappa"][3:15, 3:15, :nz] = c.KAPPA * (1 - 0.2 * q)
-        pkz = np.exp(s["cappa"][3:15, 3:15, :nz] / (1 - s["cappa"][3:15, 3:15, :nz]) * np.log(c.RDG * delp / dz * T))
-        s["pt"][3:15, 3:15, :nz] = T / pkz
-    odyn = OracleAcousticDynamics(part, grids, cfg, c, phis)
-    for name in ("delp", "delz", "w", "pt", "q_con", "cappa"):
-        odyn.ex.scalar([s[name] for s in ost])
-    odyn.ex.vector([s["u"] for s in ost], [s["v"] for s in ost], "dgrid")
-    odyn.ex.synchronize_vector_interfaces([s["u"] for s in ost], [s["v"] for s in ost])
-    init = [{k: v.copy() for k, v in s.items()} for s in ost]
-    odyn(ost, 30.0, 1)
-    got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 30.0)
-    compare_cubes(got, ost, part, nz, ("delp", "pt", "u", "v", "w", "delz", "q_con"), TOL, atol=W_ATOL)
+# (the real-model-data test lives in tests/test_restart_six_tiles.py: all six tiles of the reference's FV3 restart, not tile 1 replicated)
 
 
 def test_baroclinic_wave_state(backend):

@@ -6,9 +6,10 @@ fixtures are *data* the reference tree holds, down-selected:
 
 * eta79.npz        - L79 ak/bk table
   [REF examples/notebooks/generate_eta_file_netcdf.ipynb:82-135]
-* c12_restart_tile1.npz - real FV3 C12 L63 state of tile 1 (u, v, W, DZ, T,
-  delp, phis, sphum, liq_wat) + ak/bk(64)
-  [REF tests/main/data/c12_restart/fv_core.res.tile1.nc, fv_tracer.res.tile1.nc, fv_core.res.nc]
+* c12_restart_6tiles.npz - the real FV3 C12 L63 model state of the reference tree, ALL SIX tiles (u, v, W, DZ, T, delp, phis, sphum, liq_wat per tile, stacked on a leading tile
+  axis) + ak/bk(64): the one reference-held dataset that pins the cube topology (adjacency, rotations, signs) -- see
+  tests/test_restart_six_tiles.py  [REF tests/main/data/c12_restart/fv_core.res.tile[1-6].nc, fv_tracer.res.tile[1-6].nc;
+  read by the reference in tests/main/driver/test_restart_fortran.py:21-67]
 * reference_thresholds_fv_dynamics.json - the reference's own calibrated savepoint thresholds (absolute / relative per variable)
   of the C_SW-Out, D_SW-Out, Tracer2D1L-In / Out and Remapping-In / Out savepoints
   [REF tests/savepoint/thresholds/fv_dynamics.yaml:2-360]
@@ -38,22 +39,28 @@ def eta79():
     print("eta79.npz", out["ak"][:3], out["bk"][-3:])
 
 
-def c12_restart():
+def c12_restart_six_tiles():
     from scipy.io import netcdf_file
 
     d = os.path.join(REF, "tests/main/data/c12_restart")
     out = {}
-    with netcdf_file(os.path.join(d, "fv_core.res.tile1.nc"), "r", mmap=False) as f:
-        for k in ("u", "v", "W", "DZ", "T", "delp", "phis"):
-            out[k] = np.array(f.variables[k][0], dtype=np.float64)
-    with netcdf_file(os.path.join(d, "fv_tracer.res.tile1.nc"), "r", mmap=False) as f:
-        for k in ("sphum", "liq_wat"):
-            out[k] = np.array(f.variables[k][0], dtype=np.float64)
+    core = ("u", "v", "W", "DZ", "T", "delp", "phis")
+    tracers = ("sphum", "liq_wat")  # specific humidity (virtual temperature) and the condensate the acoustic path carries as q_con
+    for k in core + tracers:
+        out[k] = []
+    for t in range(1, 7):
+        with netcdf_file(os.path.join(d, f"fv_core.res.tile{t}.nc"), "r", mmap=False) as f:
+            for k in core:
+                out[k].append(np.array(f.variables[k][0], dtype=np.float64))
+        with netcdf_file(os.path.join(d, f"fv_tracer.res.tile{t}.nc"), "r", mmap=False) as f:
+            for k in tracers:
+                out[k].append(np.array(f.variables[k][0], dtype=np.float64))
+    out = {k: np.stack(v) for k, v in out.items()}
     with netcdf_file(os.path.join(d, "fv_core.res.nc"), "r", mmap=False) as f:
         out["ak"] = np.array(f.variables["ak"][0], dtype=np.float64)
         out["bk"] = np.array(f.variables["bk"][0], dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "c12_restart_tile1.npz"), **out)
-    print("c12_restart_tile1.npz", {k: v.shape for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "c12_restart_6tiles.npz"), **out)
+    print("c12_restart_6tiles.npz", {k: v.shape for k, v in out.items()})
 
 
 def thresholds():
@@ -77,5 +84,5 @@ if __name__ == "__main__":
         sys.exit("needs /root/reference")
     os.makedirs(OUT, exist_ok=True)
     eta79()
-    c12_restart()
+    c12_restart_six_tiles()
     thresholds()
