@@ -270,6 +270,7 @@ int fv3_halo_plan_buffer(fv3_halo_plan *, int peer_index, int recv, void **ptr, 
  * exchange; librccl.so is bound at run time.  Host-driven transport (tests, gloo): the plan packs, calls
  * fn(user, plan, 0) [post the messages], later fn(user, plan, 1) [complete them], then unpacks. */
 typedef struct { char internal[128]; } fv3_nccl_id;
+int fv3_rccl_available(void); /* 1 when librccl.so could be bound in this process (what every rank checks BEFORE the collective calls) */
 int fv3_comm_unique_id(fv3_nccl_id *id);
 int fv3_ctx_comm_init(fv3_ctx *, const fv3_nccl_id *id, int world, int rank);
 int fv3_ctx_comm_destroy(fv3_ctx *);

@@ -146,6 +146,9 @@ def xppm8(D: Dom, q, c, j0, j1):
     if D.west:
         put(br, 2, AL(3) - Q(2))
         xt = _edge_mean(Q(-1), Q(0), Q(1), Q(2), M(-1), M(0), M(1), M(2))
+        # iord >= 8: the two-sided tile-edge value stays inside the range of the four cells around the edge
+        # (tp_core.F90 xppm, "xt = max(xt, min(q1(-1), q1(0), q1(1), q1(2))); xt = min(xt, max(...))"; pyFV3 xppm.xt_dxa_edge_0 with xt_minmax)
+        xt = np.minimum(np.maximum(xt, np.minimum(np.minimum(Q(-1), Q(0)), np.minimum(Q(1), Q(2)))), np.maximum(np.maximum(Q(-1), Q(0)), np.maximum(Q(1), Q(2))))
         put(bl, 1, xt - Q(1))
         put(br, 0, xt - Q(0))
         put(bl, 0, S14 * DM(-1) + S11 * (Q(-1) - Q(0)))
@@ -157,6 +160,8 @@ def xppm8(D: Dom, q, c, j0, j1):
     if D.east:
         put(bl, npx - 2, AL(npx - 2) - Q(npx - 2))
         xt = _edge_mean(Q(npx - 2), Q(npx - 1), Q(npx), Q(npx + 1), M(npx - 2), M(npx - 1), M(npx), M(npx + 1))
+        xt = np.minimum(np.maximum(xt, np.minimum(np.minimum(Q(npx - 2), Q(npx - 1)), np.minimum(Q(npx), Q(npx + 1)))),
+                        np.maximum(np.maximum(Q(npx - 2), Q(npx - 1)), np.maximum(Q(npx), Q(npx + 1))))
         put(br, npx - 1, xt - Q(npx - 1))
         put(bl, npx, xt - Q(npx))
         put(br, npx, S11 * (Q(npx + 1) - Q(npx)) - S14 * DM(npx + 1))

@@ -823,17 +823,34 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     //      fields through its halo columns / rows while it produces the new ones, so it writes beside them.
     Real *dQ_x = c->scratch[SC_C], *dQ_y = c->scratch[SC_D], *dC_x = c->scratch[SC_G], *dC_y = c->scratch[SC_U];
     Real *n_dp = oop ? o_delp : c->scratch[SC_N], *n_w = oop ? o_w : c->scratch[SC_O], *n_qc = oop ? o_q_con : c->scratch[SC_P], *n_pt = oop ? o_pt : c->scratch[SC_Q];
+    // Levels from fd_k0 on (every chain switched on and of order 2: all but the sponge layers) run the chains INSIDE the marches
+    // (fv3_tp4.hip, FD); only the faces on the cube-corner patches are computed here for them.  FV3_DSW_DELN=arrays: the
+    // chains of every level as del6_stream launches (round-2 form, A/B reference).
+    const char *dn_env = getenv("FV3_DSW_DELN");  // (read per call: the A/B parity test flips it in one process)
+    int fd_k0 = g.nz;
+    if (!(dn_env && !strcmp(dn_env, "arrays")) && scalars_mode == 1) {
+      for (int k = g.nz - 1; k >= 0; --k) {
+        const bool all2 = c->nord_v_h[k] == 2 && c->nord_w_h[k] == 2 && c->nord_t_h[k] == 2 && c->damp_vt_h[k] > 1.0e-4 && c->damp_w_h[k] > 1.0e-5 && c->damp_t_h[k] > 1.0e-4;
+        if (!all2) break;
+        fd_k0 = k;
+      }
+    }
+    if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] fd_k0 = %d of %d\n", fd_k0, g.nz);
     fv3_signal(c, s, 0);
     fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s2, 0);
-    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, nz1);
-    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, nz1);
-    del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, nz1);
-    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, nz1);
+    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, fd_k0 - 1);
+    del6_vt_flux_patches(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, fd_k0, nz1);
+    del6_vt_flux_patches(c, s2, w, d2w, dC_x, dC_y, dn_w, false, fd_k0, nz1);
+    del6_vt_flux_patches(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, fd_k0, nz1);
+    del6_vt_flux_patches(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, fd_k0, nz1);
     fv3_signal(c, s2, 1);
     fv3_wait(c, s, 1);
     DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
-                  cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt};
+                  cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt, dn_w, fd_k0};
     dsw_scalars_stream(c, s, q4, scalars_mode);
     if (!oop) launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);

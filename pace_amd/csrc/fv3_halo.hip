@@ -218,6 +218,8 @@ int fv3_halo_plan_wait(fv3_ctx *c, fv3_halo_plan *p, void *stream) {
   return FV3_OK;
 }
 
+int fv3_rccl_available(void) { return rccl().ok ? 1 : 0; }
+
 int fv3_comm_unique_id(fv3_nccl_id *id) {
   if (!id) return FV3_ERR_ARG;
   Rccl &r = rccl();
@@ -227,6 +229,7 @@ int fv3_comm_unique_id(fv3_nccl_id *id) {
 
 int fv3_ctx_comm_init(fv3_ctx *c, const fv3_nccl_id *id, int world, int rank) {
   if (!c || !id || world < 1 || rank < 0 || rank >= world) return FV3_ERR_ARG;
+  if (c->nccl_comm) return fv3_fail(c, FV3_ERR_ARG, "fv3_ctx_comm_init: this context already has a communicator (fv3_ctx_comm_destroy first)");
   Rccl &r = rccl();
   if (!r.ok) return fv3_fail(c, FV3_ERR_UNSUPPORTED, "RCCL is not available: " + r.err);
   void *comm = nullptr;

@@ -101,6 +101,8 @@ struct DswScalars {
   int hord_dp, hord_vt, hord_tm;
   Deln dn_vt, dn_t;
   Real dt;
+  Deln dn_w;  // w's chain (fused form: the march runs it; the other forms only test its switch through g.damp_w)
+  int fd_k0;  // levels >= fd_k0 run the del-n chains inside the marches (every chain of order 2 there); nz = never
 };
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
@@ -110,6 +112,10 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
 void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
 
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
+// del6_vt_flux_patches: only the faces on the FV3_D6_PATCH^2 patches at the cube corners (staged chain; orders > 0) -- for callers that
+// run the chain themselves everywhere else (the fused scalar marches of d_sw)
+#define FV3_D6_PATCH 8
+void del6_vt_flux_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 
 // a2b_ord4: qout levels kout0.. from qin levels kin0.. (nk levels); replace writes back into qin

@@ -167,17 +167,23 @@ FV3_HD inline Real ppm8_dm(Real qm, Real q0, Real qp) {
   return fv3_sign(fv3_min(fv3_min(fabs(xt), hi), lo), xt);
 }
 
+// iord >= 8: the two-sided tile-edge value is kept inside the range of the four cells around the edge
+// (tp_core.F90 xppm: xt = max(xt, min(q1(-1..2))); xt = min(xt, max(q1(-1..2))); pyFV3 xppm.xt_dxa_edge_0 with xt_minmax)
+FV3_HD inline Real ppm8_edge_clamp(Real xt, Real a, Real b, Real c_, Real d) {
+  return fv3_min(fv3_max(xt, fv3_min(fv3_min(a, b), fv3_min(c_, d))), fv3_max(fv3_max(a, b), fv3_max(c_, d)));
+}
+
 // edge value at the low face of cell s from q(s-2), q(s-1), q(s), q(s+1) = a, b, c_, d
 template <class M>
 FV3_HD inline Real ppm8_al_win(Real a, Real b, Real c_, Real d, M m, int s, bool lo, bool hi, int np_) {
   if (lo) {
     if (s == 0) return c_ + (PPM_S14 * ppm8_dm(a, b, c_) + PPM_S11 * (b - c_));
-    if (s == 1) return ppm_edge_mean(a, b, c_, d, m(-1), m(0), m(1), m(2));
+    if (s == 1) return ppm8_edge_clamp(ppm_edge_mean(a, b, c_, d, m(-1), m(0), m(1), m(2)), a, b, c_, d);
     if (s == 2) return PPM_S15 * b + PPM_S11 * c_ - PPM_S14 * ppm8_dm(b, c_, d);
   }
   if (hi) {
     if (s == np_ - 1) return PPM_S15 * c_ + PPM_S11 * b + PPM_S14 * ppm8_dm(a, b, c_);
-    if (s == np_) return ppm_edge_mean(a, b, c_, d, m(np_ - 2), m(np_ - 1), m(np_), m(np_ + 1));
+    if (s == np_) return ppm8_edge_clamp(ppm_edge_mean(a, b, c_, d, m(np_ - 2), m(np_ - 1), m(np_), m(np_ + 1)), a, b, c_, d);
     if (s == np_ + 1) return b + (PPM_S11 * (c_ - b) - PPM_S14 * ppm8_dm(b, c_, d));
   }
   return (Real)0.5 * (b + c_) + PPM_R3 * (ppm8_dm(a, b, c_) - ppm8_dm(b, c_, d));

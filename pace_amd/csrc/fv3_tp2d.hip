@@ -140,7 +140,7 @@ static void del6_vt_flux_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
 #define D6_SEG 64
 #define D6_PF 2
 #define D6_NMAX 2
-#define D6_PATCH 8
+#define D6_PATCH FV3_D6_PATCH
 
 static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
   const Geo g = c->g;
@@ -366,7 +366,12 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
   if (dn.nord_max > 0) del6_corner_patches(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
 }
 
+void del6_vt_flux_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+  if (dn.nord_max > 0 && k0 <= k1) del6_corner_patches(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
+}
+
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+  if (k0 > k1) return;
   // FV3_DEL6_MODE = staged | stream (default): the staged form is the reference / A-B path
   static const char *mode_env = getenv("FV3_DEL6_MODE");
   static const bool staged = mode_env && !strcmp(mode_env, "staged");

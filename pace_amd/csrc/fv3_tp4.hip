@@ -35,6 +35,16 @@
 // The arithmetic of each tracer is expression for expression the one of tp2d_stream_t (same operation order: bitwise
 // equal results, checked by tests/test_parity.py::test_fused_scalar_march_is_bitwise_the_four_transports and the A/B
 // switch FV3_DSW_SCALARS=separate).
+// FD (round 3): the del-n damping chains of the wave's tracers run INSIDE the march (the reference's DelnFlux, restated as the
+// marching pipeline of del6_stream in fv3_tp2d.hip: iteration s of the chain runs s rows behind the row being consumed, its
+// d2 / flux values live in registers, the i-neighbours come from wavefront shuffles -- LDS lines in the transposed tile-edge
+// march).  The damping fluxes of delp / w / q_con / pt then never exist as fields: four del6_stream launches (3.7 GB read,
+// 4.7 GB written each at C768) and eight field reads of the two marches are gone.  What makes room for the pipeline at two
+// waves per SIMD: the wave's pure delay lines (Courant number, area flux, cell area, inner flux of rows r-1 .. r-3) and the
+// three metric rows of the chain are parked in a per-wave LDS ring (own-lane traffic: no ordering point).  Faces whose
+// dependency cone touches a cube corner still come from the staged chain on the 8 x 8 corner patches (del6_vt_flux_patches)
+// and are read from the flux fields there.  Levels whose chains are not all of order 2 (the sponge layers) take the form
+// without FD.  Same expressions in the same order as del6_stream: bitwise equal (FV3_DSW_DELN=arrays is the A/B switch).
 #include "fv3_ops.h"
 #include "fv3_ppm.h"
 
@@ -70,8 +80,9 @@ FV3_HD inline void q4_for(F &&f) {
 // direction.  "lc" / "r" are the Fortran-local coordinates along L / M.
 // M8: the hord-8 (monotone) reconstruction for every slot (tracer_2d_1l with hord_tr = 8), a separate instantiation so
 // that the hord 5 / 6 kernels of d_sw carry none of it
-template <int ROLE, int PART, bool M8 = false>
-static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
+template <int ROLE, int PART, bool M8 = false, bool FD = false>
+static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi) {
+  static_assert(!FD || (ROLE != Q4_QUAD && PART != Q4_ALL && !M8), "the fused del-n chains exist for the two-tracer interior / edge marches");
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
   constexpr bool TR = PART == Q4_EDGE;      // transposed march
@@ -82,6 +93,10 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
 #else
   constexpr bool DPP = PART == Q4_INTERIOR;
 #endif
+  constexpr bool PARK = FD && DPP;  // delay lines in the LDS ring (the two-waves-per-SIMD kernels)
+  constexpr int NRING = FD ? (PARK ? 8 : 3) : 0;
+  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };  // ring variables (RG_FI + slot)
+  constexpr int FDL = FD && !DPP ? Q4_NT * 5 + 1 : 0;  // LDS lines of the chain (transposed march): d2 of iterations 0..2, fluxes of 0..1 per slot, w's final flux
   const Geo g = c->g;
   DswScalars a = a_;
   if (TR) {  // exchange the roles of the two directions
@@ -92,8 +107,10 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     std::swap(a.dpx, a.dpy);
     std::swap(a.dqx, a.dqy);
     std::swap(a.dtx, a.dty);
+    std::swap(a.dwx, a.dwy);
   }
-  const int nk = g.nz;
+  const int nk = k_hi - k_lo + 1;
+  if (nk <= 0) return;
   const int nL = TR ? g.ny : g.nx, nM = TR ? g.nx : g.ny;  // cells along the lanes / along the march
   const int npL = nL + 1, npM = nM + 1;
   const int nstrip = (nL + 1 + Q4_OUT - 1) / Q4_OUT;
@@ -101,17 +118,19 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
   const int nseg = TR ? 2 : (nM + seg - 1) / seg;  // transposed: "segment" 0 = the low (W) edge columns, 1 = the high (E) ones
   // LDS: per tracer the two L-sweep row lines (q on the new row, the M-advected q three rows behind), (area flux) * (inner
   // L flux) and the final L flux; shared: the L area flux, the old air mass of row r-3, the tile-edge metric ring
-  const size_t smem = DPP ? 0 : sizeof(Real) * (Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
+  const size_t smem_lines = DPP ? 0 : (size_t)(Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
+  const size_t smem = sizeof(Real) * (smem_lines + (size_t)FDL * (FV3_WAVE + 2) + (size_t)NRING * 4 * FV3_WAVE);
   const Geo *gp = c->g_dev;
   const int nh = g.nh, sj32 = g.sj32, go = g.o;
   const int LS = TR ? sj32 : 1, MS = TR ? 1 : sj32;  // element strides of one step along L / along M
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr area = g.area, rarea = g.rarea;
   const MPtr metL = TR ? g.dya : g.dxa;  // cell widths of the one-sided formulas along L
+  const MPtr d6L = TR ? g.del6_u : g.del6_v, d6M = TR ? g.del6_v : g.del6_u;  // del-n face coefficients of the L / M faces
   const Real *damp_w_k = g.damp_w, *ke_bg_k = g.ke_bg;
   const int bitLlo = TR ? FV3_S : FV3_W, bitLhi = TR ? FV3_N : FV3_E, bitMlo = TR ? FV3_W : FV3_S, bitMhi = TR ? FV3_E : FV3_N;
   launch_waves<WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = blk.bz - t * nk;
+    const int t = blk.bz / nk, k = k_lo + (blk.bz - t * nk);
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     const int l0 = 1 + blk.bx * Q4_OUT;  // first owned L face / cell of the strip
@@ -144,6 +163,13 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     Real *exx = (Real *)smem_ + Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1));  // L area flux of the lane's face (read by lane - 1)
     Real *exm = exx + FV3_WAVE + 1;                                          // old delp(lc, r-3) of the lane (read by lane + 1)
     Real *emr = exm + FV3_WAVE + 1;                                          // tile-edge strips: metric ring (4 rows x 8 cells)
+    // FD: the chain's lines (index lane + 1: lane - 1 .. lane + 1 readable) and the own-lane ring [variable][row & 3][lane]
+    Real *fdl = (Real *)smem_ + smem_lines + 1;
+    Real *ring = (Real *)smem_ + smem_lines + (size_t)FDL * (FV3_WAVE + 2);
+    auto LD = [&](int n, int it) -> Real * { return fdl + (n * 5 + it) * (FV3_WAVE + 2); };       // d2 of iteration it (0..2), slot n
+    auto LF = [&](int n, int it) -> Real * { return fdl + (n * 5 + 3 + it) * (FV3_WAVE + 2); };   // L flux of iteration it (0..1)
+    Real *lzx = fdl + Q4_NT * 5 * (FV3_WAVE + 2);                                                 // w: final L flux of row r-3
+    auto RG = [&](int var, int r) -> Real * { return ring + (var * 4 + (r & 3)) * FV3_WAVE; };
     const Real *const qall[4] = {a.delp + b, a.w + b, a.q_con + b, a.pt + b};
     const int hall[4] = {a.hord_dp, a.hord_vt, a.hord_dp, a.hord_tm};
     const Real *qin[Q4_NT];
@@ -160,6 +186,23 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     const bool on_vt = deln_on(a.dn_vt, k), on_t = deln_on(a.dn_t, k);
     const Real damp_vt = on_vt ? deln_damp(a.dn_vt, k) : (Real)0, damp_t = on_t ? deln_damp(a.dn_t, k) : (Real)0;
     const bool on_w = damp_w_k[k] > (Real)1.0e-5;
+    // FD: d2 of iteration 0 = coef * q for delp / w (the damped quantity itself), q for q_con / pt (weighted by the air mass later)
+    Real dcoef[Q4_NT];
+    Q4_EACH(n)
+      dcoef[n] = !FD ? (Real)0 : id == 0 ? deln_damp(a.dn_vt, k) : id == 1 ? deln_damp(a.dn_w, k) : (Real)1;
+    Q4_END
+    // cube corners of this sub-domain: the faces on their 8 x 8 patches come from the flux fields (staged chain)
+    const bool c_ll = (fl & (bitLlo | bitMlo)) == (bitLlo | bitMlo), c_hl = (fl & (bitLhi | bitMlo)) == (bitLhi | bitMlo);
+    const bool c_hh = (fl & (bitLhi | bitMhi)) == (bitLhi | bitMhi), c_lh = (fl & (bitLlo | bitMhi)) == (bitLlo | bitMhi);
+    const bool pz_lo = FD && (c_ll || c_lh) && l0 - 3 <= FV3_D6_PATCH, pz_hi = FD && (c_hl || c_hh) && l0 + FV3_WAVE - 4 >= nL + 2 - FV3_D6_PATCH;
+    // is the L face / cell column lc at M coordinate m on a corner patch?  (patch = faces 1..P resp. n+2-P..n+1 of both directions)
+    auto on_patch = [&](int lc, int m) -> bool {
+      const bool llo = lc >= 1 && lc <= FV3_D6_PATCH, lhi = lc >= nL + 2 - FV3_D6_PATCH && lc >= 1 && lc <= nL + 1;
+      const bool mlo = m >= 1 && m <= FV3_D6_PATCH, mhi = m >= nM + 2 - FV3_D6_PATCH && m >= 1 && m <= nM + 1;
+      return (llo && mlo && c_ll) || (lhi && mlo && c_hl) || (lhi && mhi && c_hh) || (llo && mhi && c_lh);
+    };
+    const Real *const dLall[4] = {a.dpx ? a.dpx + b : nullptr, a.dwx ? a.dwx + b : nullptr, a.dqx ? a.dqx + b : nullptr, a.dtx ? a.dtx + b : nullptr};
+    const Real *const dMall[4] = {a.dpy ? a.dpy + b : nullptr, a.dwy ? a.dwy + b : nullptr, a.dqy ? a.dqy + b : nullptr, a.dty ? a.dty + b : nullptr};
     const Real dd8 = ke_bg_k[k] * fabs(a.dt);
     const int r_end = fb + 3 < Med ? fb + 3 : Med;
 
@@ -186,6 +229,14 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
     Real sqx[Q4_NT][FV3_LPT], sqi[Q4_NT][FV3_LPT], smb[FV3_LPT], sxv[FV3_LPT];  // DPP form: the values the neighbouring lanes read (q on the new row, the M-advected q, old delp, L area flux)
     unsigned pcol[FV3_LPT];  // in-plane offset of (lc, M coordinate 0)
     bool own_x[FV3_LPT], own_y[FV3_LPT];
+    // FD: the chain's state.  sd0 / sd1 / sd2: d2 of iterations 0 / 1 / 2 on rows r / r-1 / r-2 (read by lane + 1, and at the next
+    // step as the row below); gx0 / gx1: L fluxes of iterations 0 / 1 on rows r / r-1 (read by lane - 1 at the next step);
+    // gy0 / gy1: their M fluxes at faces r / r-1; dxd: the final L flux of row r-3; dyf: the final M flux of face r-2 (this step);
+    // zyp: w's final M flux of face r-3; zxo: w's final L flux of row r-3 after the patch override (read by lane - 1)
+    Real sd0[Q4_NT][FV3_LPT], sd1[Q4_NT][FV3_LPT], sd2[Q4_NT][FV3_LPT], gx0[Q4_NT][FV3_LPT], gx1[Q4_NT][FV3_LPT], gy0[Q4_NT][FV3_LPT], gy1[Q4_NT][FV3_LPT];
+    Real dxd[Q4_NT][FV3_LPT], dxn[Q4_NT][FV3_LPT], dyf[Q4_NT][FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
+    Real mdu_n[FV3_LPT], mdv_n[FV3_LPT], mra_n[FV3_LPT];  // the chain's metric terms of the next row (fetched one step ahead)
+    const MPtr d6Lb = d6L + m2, d6Mb = d6M + m2, rab = rarea + m2;
 
     const MPtr metLb = metL + m2;
     const unsigned pbase = (unsigned)(go * sj32 + go);
@@ -243,6 +294,25 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
       if constexpr (!DPP) {
         if (lane == 0) exx[FV3_WAVE] = (Real)0;
       }
+      zyp[l] = zxo[l] = mdu_n[l] = mdv_n[l] = mra_n[l] = (Real)0;
+      Q4_EACH(n)
+        sd0[n][l] = sd1[n][l] = sd2[n][l] = gx0[n][l] = gx1[n][l] = gy0[n][l] = gy1[n][l] = dxd[n][l] = dxn[n][l] = dyf[n][l] = (Real)0;
+      Q4_END
+      if constexpr (FD) {
+        for (int v = 0; v < NRING; ++v)
+          for (int q = 0; q < 4; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
+        if constexpr (!DPP) {
+          for (int q = 0; q < FDL; ++q) {
+            Real *ln = fdl + q * (FV3_WAVE + 2);
+            ln[lane] = (Real)0;
+            if (lane == 0) ln[-1] = ln[FV3_WAVE] = (Real)0;
+          }
+        }
+        const unsigned pm = pcol[l] + (unsigned)((ca - 3) * MS);
+        mdu_n[l] = d6Mb[pm];
+        mdv_n[l] = d6Lb[pm];
+        mra_n[l] = rab[pm];
+      }
       nxt[l] = load_row(ca - 3, l, lane);
       nx2[l] = load_row(ca - 2 < r_end ? ca - 2 : r_end, l, lane);
       if constexpr (!DPP) {
@@ -267,15 +337,17 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             if constexpr (HAS_AIR) {
               o_ax[l] = (a.mfx + b)[p3];
               o_ay[l] = (a.mfy + b)[pf];
-              if (on_vt) {
-                o_dx[0][l] = (a.dpx + b)[p3];
-                o_dy[0][l] = (a.dpy + b)[pf];
-              }
-              if (on_w) {
-                zx0[l] = (a.dwx + b)[p3];
-                zx1[l] = (a.dwx + b)[p3 + 1];
-                zy0[l] = (a.dwy + b)[p3];
-                zy1[l] = (a.dwy + b)[p3 + (unsigned)sj32];
+              if constexpr (!FD) {
+                if (on_vt) {
+                  o_dx[0][l] = (a.dpx + b)[p3];
+                  o_dy[0][l] = (a.dpy + b)[pf];
+                }
+                if (on_w) {
+                  zx0[l] = (a.dwx + b)[p3];
+                  zx1[l] = (a.dwx + b)[p3 + (unsigned)LS];
+                  zy0[l] = (a.dwy + b)[p3];
+                  zy1[l] = (a.dwy + b)[p3 + (unsigned)MS];
+                }
               }
             } else {
               o_mx[l] = (a.fx + b)[p3];
@@ -283,7 +355,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
               o_mc[l] = (a.delp + b)[pf];
               o_dn[l] = (a.o_delp + b)[p3];
             }
-            if constexpr (ROLE != Q4_AIR) {
+            if constexpr (ROLE != Q4_AIR && !FD) {
               constexpr int nq = ROLE == Q4_QUAD ? 2 : 0, np_ = nq + 1;  // slots of q_con / pt
               if (on_vt) {
                 o_dx[np_][l] = (a.dtx + b)[p3];
@@ -294,15 +366,37 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
                 o_dy[nq][l] = (a.dqy + b)[pf];
               }
             }
-            era[l] = (rarea + m2)[p3];
+            if constexpr (FD) {
+              // the chain's metric terms: row r (fetched during the previous step) goes into the ring, row r+1 is requested
+              const Real du_c = mdu_n[l], dv_c = mdv_n[l], ra_c = mra_n[l];
+              const int r1 = r + 1 < r_end ? r + 1 : r_end;
+              const unsigned pm = pcol[l] + (unsigned)(r1 * MS);
+              mdu_n[l] = d6Mb[pm];
+              mdv_n[l] = d6Lb[pm];
+              mra_n[l] = rab[pm];
+              RG(RG_DU, r)[lane] = du_c;
+              RG(RG_DV, r)[lane] = dv_c;
+              RG(RG_RA, r)[lane] = ra_c;
+              era[l] = RG(RG_RA, r - 3)[lane];
+            } else {
+              era[l] = (rarea + m2)[p3];
+            }
           }
           cur[l] = nxt[l];
           nxt[l] = nx2[l];
           nx2[l] = load_row(rn, l, lane);
           if (XE && lane < 8) emr[(r & 3) * 8 + lane] = cur[l].em;
           const Real yv = cur[l].yv;
-          const Real ar3 = a3[l];
+          const Real ar3 = PARK ? RG(RG_AR, r - 3)[lane] : a3[l];
           const Real den_y = ar3 + y_prev[l] - yv;
+          Real du0 = (Real)0, du1 = (Real)0, du2 = (Real)0, ra1 = (Real)0, ra2 = (Real)0;
+          if constexpr (FD) {
+            du0 = RG(RG_DU, r)[lane];
+            du1 = RG(RG_DU, r - 1)[lane];
+            du2 = RG(RG_DU, r - 2)[lane];
+            ra1 = RG(RG_RA, r - 1)[lane];
+            ra2 = RG(RG_RA, r - 2)[lane];
+          }
           Q4_EACH(n)
             Real qy = cur[l].qy[n], qx = qy;
             if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
@@ -316,6 +410,35 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
                 qx = cc<1>(qin[n], *gp, fl, lcc, rc);
               }
               cur[l].qy[n] = qy;
+            }
+            if constexpr (FD) {
+              // ---- del-n chain, own-lane part (del6_stream phase A): d2 of iteration s on row r-s, its M flux at face r-s.
+              //      The raw field value enters (the corner-halo remaps belong to the patches).
+              const Real qraw = cur[l].qy[n];
+              const Real d0c = (id == 0 || id == 1) ? dcoef[n] * qraw : qraw;
+              const Real fyc0 = du0 * (sd0[n][l] - d0c);
+              Real gxe0, gxe1;  // the L fluxes of the lane's high faces: the neighbouring lane's values of the previous step
+              if constexpr (DPP) {
+                gxe0 = FV3_LANE_SHL(1, gx0[n], l, lane);
+                gxe1 = FV3_LANE_SHL(1, gx1[n], l, lane);
+              } else {
+                gxe0 = LF(n, 0)[lane + 1];
+                gxe1 = LF(n, 1)[lane + 1];
+              }
+              const Real d2c1 = TR ? (gy0[n][l] - fyc0 + gx0[n][l] - gxe0) * ra1 : (gx0[n][l] - gxe0 + gy0[n][l] - fyc0) * ra1;
+              const Real fyc1 = du1 * (d2c1 - sd1[n][l]);
+              const Real d2c2 = TR ? (gy1[n][l] - fyc1 + gx1[n][l] - gxe1) * ra2 : (gx1[n][l] - gxe1 + gy1[n][l] - fyc1) * ra2;
+              dyf[n][l] = du2 * (d2c2 - sd2[n][l]);
+              gy0[n][l] = fyc0;
+              gy1[n][l] = fyc1;
+              sd0[n][l] = d0c;
+              sd1[n][l] = d2c1;
+              sd2[n][l] = d2c2;
+              if constexpr (!DPP) {
+                LD(n, 0)[lane] = d0c;
+                LD(n, 1)[lane] = d2c1;
+                LD(n, 2)[lane] = d2c2;
+              }
             }
             w2[n][l] = w3[n][l];
             w3[n][l] = w4[n][l];
@@ -365,6 +488,51 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
         FV3_LANES(blk, lane, l) {
           const Real cx = cur[l].cx, xv = cur[l].xv;
           Real fxin[Q4_NT], fxout[Q4_NT];
+          if constexpr (PARK) {  // rows r-3 of the parked delay lines
+            cx3[l] = RG(RG_CX, r - 3)[lane];
+            xv3[l] = RG(RG_XV, r - 3)[lane];
+            Q4_EACH(n)
+              fi3[n][l] = RG(RG_FI + n, r - 3)[lane];
+            Q4_END
+          }
+          if constexpr (FD) {
+            // ---- del-n chain, L fluxes (del6_stream phase B): the low neighbour's d2 of this step
+            const Real dv0 = RG(RG_DV, r)[lane], dv1 = RG(RG_DV, r - 1)[lane], dv2 = RG(RG_DV, r - 2)[lane];
+            Q4_EACH(n)
+              Real w0, w1, w2_;
+              if constexpr (DPP) {
+                w0 = FV3_LANE_SHR(1, sd0[n], l, lane);
+                w1 = FV3_LANE_SHR(1, sd1[n], l, lane);
+                w2_ = FV3_LANE_SHR(1, sd2[n], l, lane);
+              } else {
+                w0 = LD(n, 0)[lane - 1];
+                w1 = LD(n, 1)[lane - 1];
+                w2_ = LD(n, 2)[lane - 1];
+              }
+              gx0[n][l] = dv0 * (w0 - sd0[n][l]);
+              gx1[n][l] = dv1 * (sd1[n][l] - w1);
+              dxn[n][l] = dv2 * (sd2[n][l] - w2_);  // final L flux of row r-2: the one of row r-3 (dxd) is consumed below
+              // the damping fluxes this step consumes: L flux of (lc, r-3), M flux of face (lc, r-2); on a cube-corner patch from the fields
+              o_dx[n][l] = dxd[n][l];
+              o_dy[n][l] = dyf[n][l];
+            Q4_END
+            if (pz_lo || pz_hi) {
+              const int lc = l0 - 3 + lane;
+              const int jr_ = r - 3, jf_ = r - 2;
+              const bool px_ = jr_ >= 1 && jr_ <= nM && on_patch(lc, jr_), py_ = lc <= nL && on_patch(lc, jf_);
+              Q4_EACH(n)
+                if (px_) o_dx[n][l] = dLall[id][pcol[l] + (unsigned)(jr_ * MS)];
+                if (py_) o_dy[n][l] = dMall[id][pcol[l] + (unsigned)(jf_ * MS)];
+              Q4_END
+            }
+            if constexpr (HAS_AIR) {
+              zx0[l] = o_dx[1][l];
+              zy0[l] = zyp[l];
+              zy1[l] = o_dy[1][l];
+              zxo[l] = o_dx[1][l];
+              if constexpr (!DPP) lzx[lane] = o_dx[1][l];
+            }
+          }
           Q4_EACH(n)
             if (XE) {
               const int lc = l0 - 3 + lane;
@@ -422,18 +590,34 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           Q4_EACH(n)
             fxk[n][l] = vx[n];
             if constexpr (!DPP) exf[n][lane] = vx[n];
-            fi3[n][l] = fi2[n][l];
-            fi2[n][l] = fi1[n][l];
-            fi1[n][l] = fxin[n];
+            if constexpr (PARK) {
+              RG(RG_FI + n, r)[lane] = fxin[n];
+            } else {
+              fi3[n][l] = fi2[n][l];
+              fi2[n][l] = fi1[n][l];
+              fi1[n][l] = fxin[n];
+            }
             px[n][l] = xv * fxin[n];
             if constexpr (!DPP) exp_[n][lane] = px[n][l];
+            if constexpr (FD) {
+              dxd[n][l] = dxn[n][l];
+              if constexpr (!DPP) {
+                LF(n, 0)[lane] = gx0[n][l];
+                LF(n, 1)[lane] = gx1[n][l];
+              }
+            }
           Q4_END
-          cx3[l] = cx2[l];
-          cx2[l] = cx1[l];
-          cx1[l] = cx;
-          xv3[l] = xv2[l];
-          xv2[l] = xv1[l];
-          xv1[l] = xv;
+          if constexpr (PARK) {
+            RG(RG_CX, r)[lane] = cx;
+            RG(RG_XV, r)[lane] = xv;
+          } else {
+            cx3[l] = cx2[l];
+            cx2[l] = cx1[l];
+            cx1[l] = cx;
+            xv3[l] = xv2[l];
+            xv2[l] = xv1[l];
+            xv1[l] = xv;
+          }
           if constexpr (DPP)
             sxv[l] = xv;
           else
@@ -515,6 +699,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
             else
               fxe[n] = exf[n][lane + 1];
           Q4_END
+          if constexpr (FD && HAS_AIR) {  // w's damping flux through the high L face of the cell: the neighbouring lane's
+            if constexpr (DPP)
+              zx1[l] = FV3_LANE_SHL(1, zxo, l, lane);
+            else
+              zx1[l] = lzx[lane + 1];
+          }
           if (fx_row && own_y[l]) {
             // flux-form updates of the cell (lc, r-3): low L / M fluxes fxk / fyp, high L flux from lane + 1, high M flux = vy
             // (x terms first, as the reference writes the divergence)
@@ -532,7 +722,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
               } else if constexpr (id == 1) {
                 Real wn = up[n] / dpn, hs = (Real)0;
                 if (on_w) {
-                  const Real dwv = (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
+                  const Real dwv = TR ? (zy0[l] - zy1[l] + zx0[l] - zx1[l]) * era[l] : (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];  // (x terms first)
                   hs = dd8 - dwv * (w2[n][l] + (Real)0.5 * dwv);
                   wn = wn + dwv;
                 }
@@ -549,9 +739,14 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_) {
           Q4_EACH(n)
             fyp[n][l] = vy[n];
           Q4_END
-          a3[l] = a2[l];
-          a2[l] = a1[l];
-          a1[l] = cur[l].ar;
+          if constexpr (FD && HAS_AIR) zyp[l] = zy1[l];
+          if constexpr (PARK) {
+            RG(RG_AR, r)[lane] = cur[l].ar;
+          } else {
+            a3[l] = a2[l];
+            a2[l] = a1[l];
+            a1[l] = cur[l].ar;
+          }
         }
         if constexpr (!DPP) blk.wave_sync();
       };
@@ -583,16 +778,28 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
   int any = 0;
   for (int t = 0; t < c->g.nsub; ++t) any |= c->g.flags[t];
   const bool edges = any & (FV3_W | FV3_E);
+  const int nz1 = c->g.nz - 1;
   if (mode == 0) {
-    dsw_scalars_t<Q4_QUAD, Q4_ALL>(c, s, a);
+    dsw_scalars_t<Q4_QUAD, Q4_ALL>(c, s, a, 0, nz1);
   } else if (mode == 2) {  // two-tracer waves, all strips in one launch (per-lane tile-edge formulas)
-    dsw_scalars_t<Q4_AIR, Q4_ALL>(c, s, a);
-    dsw_scalars_t<Q4_TRC, Q4_ALL>(c, s, a);
+    dsw_scalars_t<Q4_AIR, Q4_ALL>(c, s, a, 0, nz1);
+    dsw_scalars_t<Q4_TRC, Q4_ALL>(c, s, a, 0, nz1);
   } else {
-    dsw_scalars_t<Q4_AIR, Q4_INTERIOR>(c, s, a);
-    if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE>(c, s, a);
-    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
-    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+    // levels below fd_k0 (the sponge layers: chains of lower order) read the damping fluxes del6_stream wrote; from fd_k0 on the
+    // marches run the chains themselves
+    const int kf = a.fd_k0 < 0 ? 0 : a.fd_k0 > nz1 + 1 ? nz1 + 1 : a.fd_k0;
+    dsw_scalars_t<Q4_AIR, Q4_INTERIOR>(c, s, a, 0, kf - 1);
+    dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+    if (edges) {
+      dsw_scalars_t<Q4_AIR, Q4_EDGE>(c, s, a, 0, kf - 1);
+      dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    }
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a, 0, kf - 1);
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+    if (edges) {
+      dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a, 0, kf - 1);
+      dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    }
   }
 }
 
@@ -600,11 +807,12 @@ void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a) {
   int any = 0;
   for (int t = 0; t < c->g.nsub; ++t) any |= c->g.flags[t];
   const bool edges = any & (FV3_W | FV3_E);
+  const int nz1 = c->g.nz - 1;
   if (a.hord_dp == 8) {
-    dsw_scalars_t<Q4_TRC, Q4_INTERIOR, true>(c, s, a);
-    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, true>(c, s, a);
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR, true>(c, s, a, 0, nz1);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, true>(c, s, a, 0, nz1);
   } else {
-    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a);
-    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a);
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a, 0, nz1);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a, 0, nz1);
   }
 }

@@ -146,7 +146,7 @@ class AcousticDynamics:
         self.layout = comm
         if len(comm.local_ranks) != sf.sizer.n_sub:
             raise ValueError("stencil factory holds a different number of sub-domains than the layout assigns to this process")
-        self.halo = HaloExchanger(sf, comm, group=getattr(comm, "group", None))
+        self.halo = HaloExchanger.shared(sf, comm, group=getattr(comm, "group", None))
         self._updaters = None
         if phis is not None and state is not None:
             self._bind(state)

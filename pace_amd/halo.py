@@ -104,7 +104,22 @@ class _Phase:
 
 
 class HaloExchanger:
-    """Builds and runs halo updates for the sub-domains of one process."""
+    """Builds and runs halo updates for the sub-domains of one process.
+
+    ONE exchanger per context: it owns the context's transport (the RCCL communicator or the host-transport callback), so every
+    operator that exchanges halos on a StencilFactory goes through :meth:`shared` -- a second exchanger would initialise the
+    communicator again / replace the callback under the first one's plans."""
+
+    @classmethod
+    def shared(cls, sf, layout: "Layout", group=None):
+        ex = getattr(sf, "_halo_exchanger", None)
+        if ex is not None:
+            if ex.layout.world_size != layout.world_size or ex.layout.proc != layout.proc or ex.part.total_ranks != layout.part.total_ranks:
+                raise ValueError("this StencilFactory already exchanges halos with a different process layout")
+            return ex
+        ex = cls(sf, layout, group=group)
+        sf._halo_exchanger = ex
+        return ex
 
     def __init__(self, sf, layout: Layout, group=None, comm_stream=None):
         self.sf = sf
@@ -142,6 +157,7 @@ class HaloExchanger:
         # its operators.  FV3_HALO_NATIVE=0 keeps the torch.distributed path below (A/B reference).
         self.native = os.environ.get("FV3_HALO_NATIVE", "1") != "0"
         self.transport = None
+        self.fallback_reason = None
         self._by_plan: Dict[int, "HaloUpdater"] = {}
         self._xfer_cb = None
         if self.native:
@@ -149,45 +165,54 @@ class HaloExchanger:
             if not sf.hostemu:
                 lib.fv3_ctx_set_comm_stream(sf.ctx, 1 if want else 0)
             if layout.world_size > 1:
-                try:
-                    self._init_transport(group)
-                    ok = 1
-                except Exception as e:  # e.g. librccl.so not loadable: agree on the torch.distributed path instead
-                    ok, why = 0, e
-                import torch.distributed as dist
-
-                flag = torch.tensor([ok], dtype=torch.int32, device=sf.device if dist.get_backend(group) == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                if int(flag.item()) == 0:
-                    if layout.proc == 0:
-                        print(f"[pace_amd.halo] native transport unavailable ({why if not ok else 'on another rank'}); using the torch.distributed path", flush=True)
-                    if self.transport == "rccl":
-                        sf.lib.fv3_ctx_comm_destroy(sf.ctx)
-                    self.native, self.transport = False, None
+                self._init_transport(group)
 
     def _init_transport(self, group):
         """RCCL through the library when the process group is nccl (device buffers go straight to ncclSend / ncclRecv on the
         context's communication stream); otherwise the host-driven transport: the library packs, calls back with
-        (plan, phase), this process moves the message buffers with torch.distributed (gloo), the library unpacks."""
+        (plan, phase), this process moves the message buffers with torch.distributed (gloo), the library unpacks.
+
+        The ranks AGREE on the transport before anything collective happens: (1) every rank reports whether librccl could be
+        bound (all-reduce MIN); (2) rank 0 always broadcasts a payload -- the id or an error marker; (3) after
+        ncclCommInitRank every rank reports its status (all-reduce MIN).  A rank that cannot use RCCL therefore never leaves
+        the others waiting in a collective; all of them fall back together to the torch.distributed path (loudly: the bench
+        refuses to report a number over a transport nobody asked for, see ``transport`` / ``FV3_HALO_NATIVE=0``)."""
         import torch.distributed as dist
 
         from . import lib as _lib
 
         sf, lay = self.sf, self.layout
         backend = dist.get_backend(group)
+
+        def agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=sf.device if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        def fall_back(why):
+            if lay.proc == 0:
+                print(f"[pace_amd.halo] native RCCL transport unavailable ({why}); every rank uses the torch.distributed path", flush=True)
+            self.native, self.transport = False, None
+            self.fallback_reason = str(why)
+
         if backend == "nccl" and not sf.hostemu and os.environ.get("FV3_HALO_TRANSPORT", "rccl") == "rccl":
+            if not agree(bool(sf.lib.fv3_rccl_available())):
+                return fall_back("librccl.so could not be bound on some rank")
             ident = _lib.fv3_nccl_id()
             payload = [None]
             if lay.proc == 0:
                 st = sf.lib.fv3_comm_unique_id(C.byref(ident))
-                if st != 0:
-                    raise RuntimeError("fv3_comm_unique_id failed: " + sf.lib.fv3_last_error(None).decode())
-                payload = [bytes(ident.internal)]
+                payload = [bytes(ident.internal) if st == 0 else ("error", sf.lib.fv3_last_error(None).decode())]
             dist.broadcast_object_list(payload, src=0, group=group)
+            if isinstance(payload[0], tuple):
+                return fall_back("fv3_comm_unique_id failed on rank 0: " + payload[0][1])
             C.memmove(C.byref(ident), payload[0], 128)
             st = sf.lib.fv3_ctx_comm_init(sf.ctx, C.byref(ident), lay.world_size, lay.proc)
-            if st != 0:
-                raise RuntimeError("fv3_ctx_comm_init failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
+            why = "" if st == 0 else sf.lib.fv3_last_error(sf.ctx).decode()
+            if not agree(st == 0):
+                if st == 0:
+                    sf.lib.fv3_ctx_comm_destroy(sf.ctx)
+                return fall_back("fv3_ctx_comm_init failed" + (": " + why if why else " on another rank"))
             self.transport = "rccl"
             return
 
@@ -203,6 +228,17 @@ class HaloExchanger:
         self._xfer_cb = _lib.fv3_xfer_fn(xfer)
         sf.lib.fv3_ctx_set_xfer(sf.ctx, self._xfer_cb, None)
         self.transport = "host"
+
+    @property
+    def transport_name(self) -> str:
+        """What moves the messages between processes: 'local' (one process), 'rccl-native' (ncclSend / ncclRecv issued by the
+        library), 'gloo-host' (the library's plans, messages moved by torch.distributed on the host) or 'torch' (the Python
+        torch.distributed path: FV3_HALO_NATIVE=0, or the fallback)."""
+        if self.layout.world_size == 1:
+            return "local"
+        if self.native:
+            return {"rccl": "rccl-native", "host": "gloo-host"}.get(self.transport, "torch")
+        return "torch"
 
     # ------------------------------------------------------------------------------------------
     def _maps(self, key, rank) -> GatherMap:

@@ -170,7 +170,8 @@ class TracerAdvection(_Op):
                 cfg = self.sf.config
                 lay = Layout(CubedSpherePartitioner(cfg.npx - 1, tuple(cfg.layout)), 1, 0)
             if self._halo is None:
-                self._halo = HaloExchanger(self.sf, lay, group=getattr(lay, "group", None))
+                # the context's one exchanger (the acoustic dynamics' own when it exists): it owns the transport
+                self._halo = HaloExchanger.shared(self.sf, lay, group=getattr(lay, "group", None))
             self._updater = self._halo.updater("cell", [(q,) for q in tracers.values()])
             self._bound = key
         return self._updater

@@ -166,3 +166,32 @@ def test_oracle_hord8_is_monotone_where_hord6_overshoots(rank):
     for c0 in (0.45, -0.45):
         assert over[(c0, 8)][0] <= 1e-14 and over[(c0, 8)][1] > 0.0, over
         assert over[(c0, 6)][0] > 1e-3, over
+
+
+def test_oracle_hord8_tile_edge_value_is_clamped_to_its_four_cells():
+    """hord 8 at a cube-tile edge: the two-sided edge value (mean of two one-sided linear extrapolations) is kept inside the range
+    of the four cells around the edge, as tp_core.F90 / pyFV3's xt_dxa_edge_0 do for iord >= 8.  With a sharp extremum next to
+    the edge the unclamped value leaves that range (the test has power) and a transport step then overshoots."""
+    from helpers import Case
+
+    from fv3_oracle import ppm
+
+    cs = Case(36, (3, 3), (0,), nz=3, backend="hostemu")  # rank 0: W and S tile edges
+    D = cs.doms[0]
+    o = D.o
+    shp = cs.states[0]["pt"][:, :, :3].shape
+    i = np.arange(shp[0])[:, None, None] - o  # Fortran-local cell index
+    q = 1.0 + np.where((i == 0) | (i == 1), 5.0, 0.0) * np.ones(shp)  # a two-cell plateau straddling the W edge: both one-sided extrapolations overshoot
+    dxa = D.m.dxa
+    j = D.js
+    raw = ppm._edge_mean(q[-1 + o, j + o], q[0 + o, j + o], q[1 + o, j + o], q[2 + o, j + o], dxa[-1 + o, j + o], dxa[0 + o, j + o], dxa[1 + o, j + o], dxa[2 + o, j + o])
+    assert raw.max() > 6.0 + 0.5, raw  # the unclamped edge value overshoots the spike
+    for c0 in (0.45, -0.45):
+        c = np.full(shp, c0)
+        f = ppm.xppm(D, q.copy(), c, D.jsd, D.jed, 8)
+        R, Re, Rw = D.sl(1, D.nx, D.jsd, D.jed), D.sl(2, D.nx + 1, D.jsd, D.jed), D.sl(0, D.nx - 1, D.jsd, D.jed)
+        # the flux-form face values stay inside the global range of the field, and so does the updated field
+        assert f[D.sl(1, D.nx + 1, D.jsd, D.jed)].max() <= 6.0 + 1e-13 and f[D.sl(1, D.nx + 1, D.jsd, D.jed)].min() >= 1.0 - 1e-13
+        qn = q[R] + c[R] * (f[R] - f[Re])
+        nb = np.stack([q[Rw], q[R], q[Re]])
+        assert np.maximum(qn - nb.max(0), nb.min(0) - qn).max() <= 1e-13

@@ -310,6 +310,24 @@ def test_fused_scalar_march_is_bitwise_the_four_transports(backend, monkeypatch,
             assert np.array_equal(res["quad"][r][name], res["separate"][r][name]), f"{name} rank {r} (quad)"
 
 
+@pytest.mark.parametrize("n, layout", [(65, (1, 1)), (24, (2, 2)), (12, (1, 1))])
+def test_del_n_chains_inside_the_marches_are_bitwise_the_del6_launches(backend, monkeypatch, n, layout):
+    """d_sw's scalar marches with the del-n damping chains run inside them (fv3_tp4.hip FD: levels below the sponge layers)
+    against the same marches reading the damping fluxes four del6_stream launches wrote (FV3_DSW_DELN=arrays): same expressions
+    in the same order, cube-corner patches from the staged chain in both, so every field is bitwise equal -- on multi-strip
+    sub-domains, on 2 x 2 ranks (interior sub-domain edges, one cube corner each) and on sub-domains narrower than a strip."""
+    nz = 6  # (levels 0..2 are the sponge layers: the array form inside the fused run; 3..5 run the chains in the march)
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("fused", "arrays"):
+        monkeypatch.setenv("FV3_DSW_DELN", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
+
+
 def test_native_and_python_sequencers_are_identical(backend):
     """fv3_acoustic_step (C, the product path) and its Python twin in dyn_core.py issue the same
     operator / halo sequence: bitwise equal states, and the per-operator profile is populated."""
