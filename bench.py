@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--n-split", type=int, default=None, help="override (profiling runs only; changes the workload)")
     ap.add_argument("--tracers", type=int, default=0, help="also advect N tracers after every acoustic call (tracer_2d_1l, hord_tr 8): a separate, "
                     "clearly named workload -- the headline metric is the acoustic dynamics alone")
+    ap.add_argument("--emulate-share", type=int, default=0, metavar="N", help="ONE process owning the first 1/N of the sub-domains (the per-GPU share of an "
+                    "N-GPU run) with every inter-process message looped back on the device: the per-GPU compute + pack / unpack time of the N-GPU run without "
+                    "the other GPUs.  A separately named workload, never the headline value")
     ap.add_argument("--remap", action="store_true", help="also run the Lagrangian-to-Eulerian vertical remap after every acoustic call (+ tracer advection): "
                     "with --tracers the body of DynamicalCore.step_dynamics; a separate, clearly named workload")
     a = ap.parse_args()
@@ -171,7 +174,24 @@ def main():
     if (6 * kw["layout"][0] * kw["layout"][1]) % world:
         sys.exit(f"{a.config} has {6 * kw['layout'][0] * kw['layout'][1]} sub-domains: not divisible over {world} GPUs")
     dtype = torch.float64 if a.precision == 64 else torch.float32
-    h = DycoreHarness(world_size=world, proc=rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), n_tracers=a.tracers, remap=a.remap, **kw)
+    share = a.emulate_share if (a.emulate_share and world == 1) else 0
+    if share and (6 * kw["layout"][0] * kw["layout"][1]) % share:
+        sys.exit(f"--emulate-share {share}: {6 * kw['layout'][0] * kw['layout'][1]} sub-domains do not divide")
+    h = DycoreHarness(world_size=share or world, proc=0 if share else rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), n_tracers=a.tracers,
+                      remap=a.remap, loopback=bool(share), **kw)
+    transport = h.dyn.halo.transport_name
+    # A fallback nobody asked for must not produce a number: with an nccl group the messages go through the library's RCCL
+    # transport or the run fails (FV3_HALO_NATIVE=0 asks for the torch.distributed path explicitly; gloo groups are test hooks)
+    if world > 1 and os.environ.get("FV3_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("FV3_HALO_NATIVE", "1") != "0" and transport != "rccl-native":
+        sys.exit(f"[bench] the native RCCL halo transport is not active on rank {rank} (transport: {transport}; reason: {h.dyn.halo.fallback_reason}) -- refusing to report; "
+                 "set FV3_HALO_NATIVE=0 to benchmark the torch.distributed path on purpose")
+    rccl_ranks = 0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([1 if transport == "rccl-native" else 0], device=f"cuda:{local_rank}", dtype=torch.int32)
+        dist.all_reduce(tt)
+        rccl_ranks = int(tt.item())
 
     # ---- per-operator HIP-event timing: fv3_acoustic_step brackets every operator with an event
     #      pair on the stream it launches on (fv3_ctx_set_profiling / fv3_profile_read)
@@ -245,7 +265,7 @@ def main():
             "dtype": "f64" if a.precision == 64 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"C{kw['nx_tile']} L{kw['nz']} layout {kw['layout'][0]}x{kw['layout'][1]} ({h.part.total_ranks} sub-domains of {h.part.nx}^2, {len(h.grids)} per GPU), "
+                "workload": ("EMULATED SHARE 1/%d: " % share if share else "") + f"C{kw['nx_tile']} L{kw['nz']} layout {kw['layout'][0]}x{kw['layout'][1]} ({h.part.total_ranks} sub-domains of {h.part.nx}^2, {len(h.grids)} per GPU), "
                 f"dt_atmos {cfg.dt_atmos:g} s, k_split {cfg.k_split}, n_split {cfg.n_split}, "
                 + ("acoustic dynamics"
                    + (f" + tracer advection of {a.tracers} tracers after every acoustic call (tracer_2d_1l, hord_tr 8)" if a.tracers else "")
@@ -256,7 +276,15 @@ def main():
             },
             "finite": ok,
             "state_checksum": checksum,
+            "halo_transport": transport,
+            "rccl_ranks": rccl_ranks,
+            "sub_domains_per_gpu": len(h.grids),
+            "pingpong_scalars": os.environ.get("FV3_PINGPONG", "1") != "0",
         }
+        if share:
+            line["metric"] = f"EMULATED per-GPU share of an {share}-GPU run (one process alone, messages looped back) -- not the headline metric"
+            line["emulated_share"] = {"of_gpus": share, "sub_domains": len(h.grids), "ideal_ms_per_substep_from_1gpu": None,
+                                      "note": "compute + pack / unpack of the sub-domains one GPU owns in the N-GPU run; no inter-GPU transfer time, halo values are not the neighbours'"}
         if "d_sw" in op_ms:
             alg = D_SW_PASSES * (8 if a.precision == 64 else 4) * h.cells_local
             ach = alg / (op_ms["d_sw"] * 1e-3) / 1e9

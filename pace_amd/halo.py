@@ -148,7 +148,7 @@ class HaloExchanger:
         # messages are staged through pinned host buffers (used to exercise the multi-process
         # path on a single-GPU box; RCCL takes the device buffers directly)
         self.host_staged = False
-        if layout.world_size > 1 and torch.device(sf.device).type == "cuda":
+        if layout.world_size > 1 and torch.device(sf.device).type == "cuda" and not getattr(layout, "loopback", False):
             import torch.distributed as dist
 
             self.host_staged = dist.get_backend(group) == "gloo"
@@ -165,7 +165,10 @@ class HaloExchanger:
             if not sf.hostemu:
                 lib.fv3_ctx_set_comm_stream(sf.ctx, 1 if want else 0)
             if layout.world_size > 1:
-                self._init_transport(group)
+                if getattr(layout, "loopback", False):
+                    self._init_loopback()
+                else:
+                    self._init_transport(group)
 
     def _init_transport(self, group):
         """RCCL through the library when the process group is nccl (device buffers go straight to ncclSend / ncclRecv on the
@@ -229,6 +232,30 @@ class HaloExchanger:
         sf.lib.fv3_ctx_set_xfer(sf.ctx, self._xfer_cb, None)
         self.transport = "host"
 
+    def _init_loopback(self):
+        """One process playing rank ``proc`` of ``world_size`` ALONE (bench.py --emulate-share): the plans, pack / unpack kernels,
+        message buffers and start / wait protocol of the multi-process run, with every message looped back -- the bytes a peer
+        would have sent are this process's own send buffer for that peer (a device copy stands in for the xGMI transfer).  The
+        halo VALUES are therefore not the neighbours' (timing runs only; never a parity path)."""
+        from . import lib as _lib
+
+        def xfer(_user, plan, phase):
+            try:
+                up = self._by_plan[int(plan)]
+                if int(phase) == 0:
+                    for p in up._peers:
+                        rb, sb = up._recv_bufs[p], up._send_bufs[p]
+                        if rb is not None and sb is not None and rb.numel() == sb.numel():
+                            rb.copy_(sb, non_blocking=True)
+                return 0
+            except Exception as e:  # never let an exception cross the C frame
+                self._xfer_error = e
+                return 1
+
+        self._xfer_cb = _lib.fv3_xfer_fn(xfer)
+        self.sf.lib.fv3_ctx_set_xfer(self.sf.ctx, self._xfer_cb, None)
+        self.transport = "loopback"
+
     @property
     def transport_name(self) -> str:
         """What moves the messages between processes: 'local' (one process), 'rccl-native' (ncclSend / ncclRecv issued by the
@@ -237,7 +264,7 @@ class HaloExchanger:
         if self.layout.world_size == 1:
             return "local"
         if self.native:
-            return {"rccl": "rccl-native", "host": "gloo-host"}.get(self.transport, "torch")
+            return {"rccl": "rccl-native", "host": "gloo-host", "loopback": "loopback (one process alone, messages looped back)"}.get(self.transport, "torch")
         return "torch"
 
     # ------------------------------------------------------------------------------------------

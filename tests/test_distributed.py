@@ -53,3 +53,73 @@ def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, lay
                 a, b = got[f"{n}_{i}"], ref[p * per + i][n]
                 sl = (slice(3, -4), slice(3, -4), slice(0, nz))
                 assert np.array_equal(a[sl], b[sl]), (p, i, n, np.abs(a[sl] - b[sl]).max())
+
+
+def _tracer_run(h, scale):
+    """one acoustic call, then the tracer advection on Courant numbers scaled up so that it sub-cycles"""
+    dt = h.cfg.dt_atmos / h.cfg.k_split
+    h.dp1.storage.copy_(h.state.delp.storage)
+    h.dyn(h.state, dt, n_map=1)
+    if scale is None:  # the reference run picks the scale: 2.5 / (largest accumulated Courant number)
+        cm = max(float(h.state.cxd.storage.abs().max()), float(h.state.cyd.storage.abs().max()))
+        scale = 2.5 / cm
+    h.state.cxd.storage.mul_(scale)
+    h.state.cyd.storage.mul_(scale)
+    h._tracer_halo.update()
+    h.tracer_advection(h.tracers, h.dp1, h.state.mfxd, h.state.mfyd, h.state.cxd, h.state.cyd)
+    return scale
+
+
+def _tracer_worker(rank, world, init_file, out_dir, nx_tile, layout, nz, scale):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from pace_amd.harness import DycoreHarness
+
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=world, proc=rank, backend="hostemu", group=None, n_tracers=2, hord_tr=8)
+    _tracer_run(h, scale)
+    assert h.tracer_advection.n_split >= 2, h.tracer_advection.n_split
+    # the acoustic dynamics and the tracer advection share the context's one exchanger (a second one would re-initialise the transport)
+    assert h.tracer_advection._halo is h.dyn.halo
+    np.savez(os.path.join(out_dir, f"proc{rank}.npz"), **{f"{n}_{i}": q.numpy(i) for n, q in h.tracers.items() for i in range(len(h.grids))})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_tracer_advection_with_sub_cycles_matches_single_process(hostemu, tmp_path):
+    """Acoustic call + sub-cycled tracer advection (halo updates of the tracers between the sub-cycles, the Courant bound
+    all-reduced) on two gloo processes = the single-process result, bit for bit: the tracers' halo plan runs through the same
+    exchanger -- and the same host transport -- as the acoustic plans."""
+    nx_tile, layout, nz = 12, (2, 2), 4
+    sys.path.insert(0, ROOT)
+    from pace_amd.harness import DycoreHarness
+
+    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=1, proc=0, backend="hostemu", n_tracers=2, hord_tr=8)
+    scale = _tracer_run(h, None)
+    assert h.tracer_advection.n_split >= 2
+    ref = {n: [q.numpy(i) for i in range(len(h.grids))] for n, q in h.tracers.items()}
+    init_file = str(tmp_path / "init")
+    mp.spawn(_tracer_worker, args=(2, init_file, str(tmp_path), nx_tile, layout, nz, scale), nprocs=2, join=True)
+    per = len(h.grids) // 2
+    for p in range(2):
+        got = np.load(tmp_path / f"proc{p}.npz")
+        for i in range(per):
+            for n in ref:
+                a, b = got[f"{n}_{i}"], ref[n][p * per + i]
+                sl = (slice(3, -4), slice(3, -4), slice(0, nz))
+                assert np.array_equal(a[sl], b[sl]), (p, i, n, np.abs(a[sl] - b[sl]).max())
+
+
+def test_loopback_share_runs_alone(hostemu):
+    """bench.py --emulate-share: one process playing 1 of 8 alone (3 of the 24 sub-domains, its messages looped back) runs the
+    multi-process plans and stays finite."""
+    sys.path.insert(0, ROOT)
+    from pace_amd.harness import DycoreHarness
+
+    h = DycoreHarness(12, nz=4, layout=(2, 2), dt_atmos=60.0, k_split=1, n_split=2, world_size=8, proc=0, backend="hostemu", loopback=True)
+    assert len(h.grids) == 3 and h.dyn.halo.transport_name.startswith("loopback")
+    h.step()
+    assert all(ok for _, _, ok in h.sanity().values())
