@@ -278,6 +278,9 @@ typedef int (*fv3_xfer_fn)(void *user, fv3_halo_plan *plan, int phase);
 int fv3_ctx_set_xfer(fv3_ctx *, fv3_xfer_fn fn, void *user);
 /* run the exchanges on the context's second stream (default: on with a communicator, off without) */
 int fv3_ctx_set_comm_stream(fv3_ctx *, int on);
+/* the stream the exchanges run on when that is switched on (hipStream_t as void*), else NULL: a host-driven transport enqueues its
+ * own copies there so that they stay ordered with the plan's pack / unpack kernels */
+void *fv3_ctx_get_comm_stream(fv3_ctx *);
 
 /* ---- whole acoustic call [REF AcousticDynamics.__call__; SURVEY §3.3] ----------------------------
  * Temporaries AcousticDynamics owns (allocated by the host's QuantityFactory, borrowed here). */

@@ -145,6 +145,10 @@ struct fv3_ctx {
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;
+  // Frame-first passes (fv3_step.hip): the operators that feed a halo update (p_grad_c -> uc / vc; nh_p_grad + ray_fast -> u / v / w)
+  // run their last kernel on the frame of every sub-domain first (the cells a neighbour's halo is packed from), the update starts,
+  // and the interior follows while the messages travel.  0: whole box (default); 1: frame only; 2: interior only.
+  int frame_pass = 0;
   // per-operator profiling (fv3_step.hip)
   int profiling = 0;
   struct ProfEvent {
@@ -473,6 +477,48 @@ inline void launch3w(const fv3_ctx *c, fv3_stream_t s, Box nat, const Wins &ws, 
   const GridMap m = fv3_grid((ni + 63) / 64, (nj + 3) / 4, c->g.nsub * nk * ws.n, &grid);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3w<F>), grid, block, 0, s, nat, ws, nk, m, f);
 #endif
+}
+
+// launch3 / launch2 in frame-first passes: pass 0 = the whole box; 1 = its frame, the FV3_FRAME_W cells next to the box boundary
+// (what the halo updates of the neighbours are packed from: 3 cells + 1 for the staggered fields); 2 = the rest
+#define FV3_FRAME_W 4
+inline bool fv3_frame_boxes(const Box &b, Box (&w)[4], Box &inner) {
+  const int F = FV3_FRAME_W;
+  if (b.i1 - b.i0 + 1 <= 2 * F || b.j1 - b.j0 + 1 <= 2 * F) return false;  // (all frame)
+  w[0] = Box{b.i0, b.i0 + F - 1, b.j0 + F, b.j1 - F, b.k0, b.k1};  // W
+  w[1] = Box{b.i1 - F + 1, b.i1, b.j0 + F, b.j1 - F, b.k0, b.k1};  // E
+  w[2] = Box{b.i0, b.i1, b.j0, b.j0 + F - 1, b.k0, b.k1};          // S
+  w[3] = Box{b.i0, b.i1, b.j1 - F + 1, b.j1, b.k0, b.k1};          // N
+  inner = Box{b.i0 + F, b.i1 - F, b.j0 + F, b.j1 - F, b.k0, b.k1};
+  return true;
+}
+template <class F>
+inline void launch3_pass(const fv3_ctx *c, fv3_stream_t s, Box b, int pass, F f) {
+  Box w[4], inner;
+  if (pass == 0 || !fv3_frame_boxes(b, w, inner)) {
+    if (pass != 2) launch3(c, s, b, f);
+    return;
+  }
+  if (pass == 1)
+    launch_frame(c, s, Frame{{w[0], w[1], w[2], w[3]}}, f);
+  else
+    launch3(c, s, inner, f);
+}
+
+template <class F>
+inline void launch2(const fv3_ctx *c, fv3_stream_t s, Box b, F f);
+template <class F>
+inline void launch2_pass(const fv3_ctx *c, fv3_stream_t s, Box b, int pass, F f) {
+  Box w[4], inner;
+  if (pass == 0 || !fv3_frame_boxes(b, w, inner)) {
+    if (pass != 2) launch2(c, s, b, f);
+    return;
+  }
+  if (pass == 1) {
+    for (const Box &x : w) launch2(c, s, x, f);
+  } else {
+    launch2(c, s, inner, f);
+  }
 }
 
 template <class F>

@@ -767,7 +767,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
                  const fv3_field *divgd_, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_,
                  const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
                  const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream,
-                 const fv3_field *o_delp_, const fv3_field *o_pt_, const fv3_field *o_w_, const fv3_field *o_q_con_) {
+                 const fv3_field *o_delp_, const fv3_field *o_pt_, const fv3_field *o_w_, const fv3_field *o_q_con_, int (*after_scalars)(void *), void *after_user) {
   if (!c) return FV3_ERR_ARG;
   FV3_FIELD(delpc, delpc_) FV3_FIELD(delp, delp_) FV3_FIELD(pt, pt_) FV3_FIELD(u, u_) FV3_FIELD(v, v_) FV3_FIELD(w, w_) FV3_FIELD(uc, uc_)
   FV3_FIELD(vc, vc_) FV3_FIELD(ua, ua_) FV3_FIELD(va, va_) FV3_FIELD(divgd, divgd_) FV3_FIELD(mfx, mfx_) FV3_FIELD(mfy, mfy_) FV3_FIELD(cx, cx_)
@@ -927,6 +927,15 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       heat_s[p] = hs;
       o_q_con[p] = qc_dp[p] / dpnv;
     });
+  }
+
+  // The new delp / w / q_con / pt are final here; the winds take the second half of the operator.  The sequencer starts the
+  // halo update of delp / pt / q_con at this point (out-of-place form only: nothing below writes them, and the one later read --
+  // the new delp of the damping-heat kernel -- is on compute cells, which a halo update does not touch), so that the exchange
+  // overlaps the whole wind part instead of following the operator.
+  if (after_scalars) {
+    const int hst = after_scalars(after_user);
+    if (hst != FV3_OK) return hst;
   }
 
   // ---- cell-mean relative vorticity (+ absolute vorticity)
@@ -1167,5 +1176,5 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *de
                         const fv3_field *crx_, const fv3_field *cry_, const fv3_field *xfx_, const fv3_field *yfx_, const fv3_field *q_con_,
                         const fv3_field *zh_, const fv3_field *heat_source_, const fv3_field *diss_est_, double dtd, void *stream) {
   return fv3_d_sw_out(c, delpc_, delp_, pt_, u_, v_, w_, uc_, vc_, ua_, va_, divgd_, mfx_, mfy_, cx_, cy_, crx_, cry_, xfx_, yfx_, q_con_, zh_, heat_source_,
-                      diss_est_, dtd, stream, nullptr, nullptr, nullptr, nullptr);
+                      diss_est_, dtd, stream, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

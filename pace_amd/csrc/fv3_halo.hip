@@ -265,6 +265,8 @@ int fv3_ctx_set_comm_stream(fv3_ctx *c, int on) {
   return FV3_OK;
 }
 
+void *fv3_ctx_get_comm_stream(fv3_ctx *c) { return c && c->comm_stream_on ? c->comm_stream : nullptr; }
+
 int fv3_ctx_set_halo_plans(fv3_ctx *c, fv3_halo_plan *const *plans, int n) {
   if (!c || (n && !plans) || n < 0 || n > FV3_HALO_COUNT) return FV3_ERR_ARG;
   for (int i = 0; i < FV3_HALO_COUNT; ++i) c->halo_plans[i] = i < n ? plans[i] : nullptr;

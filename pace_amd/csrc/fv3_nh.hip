@@ -783,7 +783,7 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, const fv3_field *uc_, const fv3_field *v
   // registers for the next level: every interface plane is read once instead of twice (9 -> 7 field passes).
   // (rolled loop: an unrolled level loop lets the compiler hoist every level's loads at once)
   const int nz = g.nz, nchunk = (nz + PG_KC - 1) / PG_KC;
-  launch3(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, [=] FV3_HD(int t, int kc, int i, int j) {
+  launch3_pass(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, c->frame_pass, [=] FV3_HD(int t, int kc, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), px = IX(i - 1, j), py = IX(i, j - 1);
     const bool do_u = j <= g.ny, do_v = i <= g.nx;
@@ -832,19 +832,21 @@ int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, c
   // place, but nothing reads them afterwards (gz and pk3 are rebuilt every sub-step), so the three
   // copy-back passes are not spent; the inputs come back unchanged.
   Real *ppb = c->scratch[SC_B], *pk3b = c->scratch[SC_C], *gzb = c->scratch[SC_D], *wk1 = c->scratch[SC_A];
-  launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
-    const long p = t * g.st + IX(i, j);
-    ppb[p] = (Real)0;
-    pk3b[p] = top;
-  });
-  a2b_ord4(c, s, pp, ppb, 1, 1, nz, false);
-  a2b_ord4(c, s, pk3, pk3b, 1, 1, nz, false);
-  a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false, (Real)gz_scale);
-  a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
+  if (c->frame_pass != 2) {  // (interior pass of the frame-first form: the corner fields are in scratch already)
+    launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+      const long p = t * g.st + IX(i, j);
+      ppb[p] = (Real)0;
+      pk3b[p] = top;
+    });
+    a2b_ord4(c, s, pp, ppb, 1, 1, nz, false);
+    a2b_ord4(c, s, pk3, pk3b, 1, 1, nz, false);
+    a2b_ord4(c, s, gz, gzb, 0, 0, nz + 1, false, (Real)gz_scale);
+    a2b_ord4(c, s, delp, wk1, 0, 0, nz, false);
+  }
   // A thread walks PG_KC levels keeping the lower-interface corner values (pk3, gz, pp at k+1, three corners each)
   // in registers for the next level: every interface plane is read once instead of twice (11 -> 8 field passes).
   const int nchunk = (nz + PG_KC - 1) / PG_KC;
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, [=] FV3_HD(int t, int kc, int i, int j) {
+  launch3_pass(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nchunk - 1}, c->frame_pass, [=] FV3_HD(int t, int kc, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
     const bool do_u = i <= g.nx, do_v = j <= g.ny;
@@ -1207,11 +1209,28 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   int nord_max = 0;
   for (int k = 0; k <= nz; ++k) nord_max = std::max(nord_max, c->nord_v_h[k]);
   Deln dn{g.nord_v, g.damp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
-  del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, nz);
+  // Interfaces from fd_k0 on (chain of order 2 and switched on: all but the sponge layers) run the chain INSIDE the transport march
+  // on the strips away from the W / E tile edges (tp2d_stream_t, TF_FD); del6_stream then only serves the tile-edge strips and
+  // the cube-corner patches there.  FV3_DZ_DELN=arrays: the chain of every interface as one del6_stream launch (A/B reference).
+  int fd_k0 = nz + 1;
+  {
+    const char *e = getenv("FV3_DZ_DELN"), *m = getenv("FV3_TP2D_MODE"), *m6 = getenv("FV3_DEL6_MODE");
+    const bool off = (e && !strcmp(e, "arrays")) || (m && !strcmp(m, "staged")) || (m6 && !strcmp(m6, "staged"));
+    if (!off)
+      for (int k = nz; k >= 0; --k) {
+        if (!(c->nord_v_h[k] == 2 && c->damp_vt_h[k] > 1.0e-5)) break;
+        fd_k0 = k;
+      }
+  }
+  del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, fd_k0 - 1);
+  del6_vt_flux_edge_strips(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);
   Real *znew = fx;
   {
-    const TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt, nullptr, nullptr};
-    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, nz, &e);
+    TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt, nullptr, nullptr};
+    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, fd_k0 - 1, &e);
+    e.fd = 1;
+    e.fd_coef = g.damp_vt;
+    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, fd_k0, nz, &e);
   }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
@@ -1271,7 +1290,7 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_
   if (nn == 0) return FV3_OK;
   const Real dm = (Real)c->rf_dm;
   const Real *rf = (const Real *)c->tab_rf;
-  launch2(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+  launch2_pass(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, c->frame_pass, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
     const long p = tb + pix;

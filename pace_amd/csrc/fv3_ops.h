@@ -79,6 +79,11 @@ struct TpEpi {
   // while the pre-damping values (what the damping-heat kernel differentiates) go to wind_u_pre / wind_v_pre
   const Real *wind_du, *wind_dv, *wind_don;
   Real *wind_u_pre, *wind_v_pre;
+  // area form with zfx / zfy (update_dz_d): fd != 0 = the del-n chain of q (order 2 on every level of the call, d2 of iteration 0 =
+  // fd_coef[k] * q) runs INSIDE the march on the strips away from the W / E tile edges; zfx / zfy then only hold the tile-edge
+  // strips and the cube-corner patches (del6_vt_flux_edge_strips).  See dsw_scalars_t (fv3_tp4.hip) for the pipeline.
+  int fd = 0;
+  const Real *fd_coef = nullptr;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).
@@ -115,6 +120,8 @@ void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
 // del6_vt_flux_patches: only the faces on the FV3_D6_PATCH^2 patches at the cube corners (staged chain; orders > 0) -- for callers that
 // run the chain themselves everywhere else (the fused scalar marches of d_sw)
 #define FV3_D6_PATCH 8
+// del6_vt_flux_edge_strips: the strips that touch a W / E cube-tile edge (+ the corner patches) -- for tp2d's fused form (TpEpi::fd)
+void del6_vt_flux_edge_strips(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 void del6_vt_flux_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 void del6_vt_flux(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 
@@ -125,7 +132,8 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc, const fv3_field *delp, cons
                  const fv3_field *uc, const fv3_field *vc, const fv3_field *ua, const fv3_field *va, const fv3_field *divgd, const fv3_field *mfx,
                  const fv3_field *mfy, const fv3_field *cx, const fv3_field *cy, const fv3_field *crx, const fv3_field *cry, const fv3_field *xfx,
                  const fv3_field *yfx, const fv3_field *q_con, const fv3_field *zh, const fv3_field *heat_source, const fv3_field *diss_est, double dt,
-                 void *stream, const fv3_field *o_delp, const fv3_field *o_pt, const fv3_field *o_w, const fv3_field *o_q_con);
+                 void *stream, const fv3_field *o_delp, const fv3_field *o_pt, const fv3_field *o_w, const fv3_field *o_q_con, int (*after_scalars)(void *) = nullptr,
+                 void *after_user = nullptr);  // after_scalars: called once the four new scalars are final (the winds still to come)
 int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u, const fv3_field *v, const fv3_field *pp, const fv3_field *gz, const fv3_field *pk3, const fv3_field *delp,
                          double dt, double ptop, double akap, double gz_scale, void *stream);
 int fv3_update_dz_c_from(fv3_ctx *c, const fv3_field *zs, const fv3_field *ut, const fv3_field *vt, const fv3_field *gz_in, const fv3_field *gz, const fv3_field *ws,

@@ -155,9 +155,20 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   }
   c->pp_n = 0;  // 4 while the state lives in the alternate buffers
   int cur = 0;
+  // Frame-first: with messages to other processes, the operators that feed a halo update compute the frame of every sub-domain
+  // first, the update starts, the interior follows while the messages travel (uc / vc behind p_grad_c; u / v / w behind
+  // nh_p_grad + ray_fast).  Same values either way; without a transport the split only costs launches, so it stays off
+  // (FV3_FRAME_FIRST=1 / 0 forces it).
+  bool frame_first = !halo && (c->nccl_comm != nullptr || c->xfer != nullptr);
+  if (const char *e = getenv("FV3_FRAME_FIRST")) frame_first = !halo && e[0] == '1';
+  bool w_started = false;
+  c->frame_pass = 0;
   struct PpGuard {  // (no early return leaves the halo translation switched on)
     fv3_ctx *c;
-    ~PpGuard() { c->pp_n = 0; }
+    ~PpGuard() {
+      c->pp_n = 0;
+      c->frame_pass = 0;
+    }
   } pp_guard{c};
 
   if (pingpong) {
@@ -185,7 +196,8 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
   for (int it = 0; it < n_split; ++it) {
     const int remap_step = it == n_split - 1;
-    HALO(FV3_HALO_W, 0);
+    if (!w_started) HALO(FV3_HALO_W, 0);
+    w_started = false;
     if (it == 0) {
       RUN(FV3_OP_GLUE, fv3_set_gz(c, &ws->zs, &st->delz, &ws->gz, stream));
       HALO(FV3_HALO_GZ, 0);
@@ -206,22 +218,48 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     }
     RUN(FV3_OP_RIEM_SOLVER_C,
         fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &f_qc[cur], &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
-    RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
-    HALO(FV3_HALO_UC__VC, 0);
+    if (frame_first) {
+      c->frame_pass = 1;
+      RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
+      HALO(FV3_HALO_UC__VC, 0);
+      c->frame_pass = 2;
+      RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
+      c->frame_pass = 0;
+    } else {
+      RUN(FV3_OP_P_GRAD_C, fv3_p_grad_c(c, &st->uc, &st->vc, &ws->delpc, &ws->pkc, &ws->gz, dt2, stream));
+      HALO(FV3_HALO_UC__VC, 0);
+    }
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 1);
     HALO(FV3_HALO_UC__VC, 1);
     if (pingpong) {
+      // d_sw writes the new delp / pt / w / q_con into the other half of the pair.  Their halo update STARTS inside the operator, as
+      // soon as the scalar marches are done, and is waited for after it: with a communicator the exchange (communication stream)
+      // overlaps d_sw's whole wind part [REF docs/util/communication.rst:100-109,169-176: start() ... compute ... wait()]
       const int nxt = 1 - cur;
+      struct Mid {
+        fv3_ctx *c;
+        int pp_n_next;
+        void *stream;
+        fv3_stream_t s;
+      } mid{c, nxt ? 4 : 0, stream, s};
+      auto start_halo = [](void *u) -> int {
+        Mid *m = (Mid *)u;
+        fv3_ctx *c = m->c;
+        fv3_stream_t s = m->s;
+        m->c->pp_n = m->pp_n_next;  // delp / pt / q_con now live in the half d_sw has just written
+        OpTimer tm_(c, s, FV3_OP_HALO);
+        return fv3_halo_step(m->c, FV3_HALO_DELP__PT__Q_CON, 0, m->stream);
+      };
       RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
                                     &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
-                                    stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt]));
+                                    stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt], +start_halo, &mid));
       cur = nxt;
       c->pp_n = cur ? 4 : 0;
     } else {
       RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
                                 &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+      HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     }
-    HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);
     RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
     RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
@@ -232,14 +270,33 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &f_delp[cur], ptop, akap, stream));
     HALO(FV3_HALO_ZH, 1);
     HALO(FV3_HALO_PKC, 1);
-    // (the reference stores gz = g * zh first -- compute_geopotential; here the corner interpolation reads zh and scales it)
-    RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &f_delp[cur], dt, ptop, akap, c->cst.grav, stream));
-    if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &f_w[cur], dt, ptop, stream));
-    if (it != n_split - 1) {
-      HALO(FV3_HALO_U__V, 0);
+    if (frame_first) {
+      // the frame of the new u / v / w first (pressure gradient + Rayleigh damping), the updates start, the interior follows
+      c->frame_pass = 1;
+      RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &f_delp[cur], dt, ptop, akap, c->cst.grav, stream));
+      if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &f_w[cur], dt, ptop, stream));
+      if (it != n_split - 1) {
+        HALO(FV3_HALO_U__V, 0);
+        HALO(FV3_HALO_W, 0);  // (w is final too: the next sub-step finds its update in flight)
+        w_started = true;
+      } else {
+        HALO(FV3_HALO_INTERFACE_U__V, 0);
+      }
+      c->frame_pass = 2;
+      RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &f_delp[cur], dt, ptop, akap, c->cst.grav, stream));
+      if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &f_w[cur], dt, ptop, stream));
+      c->frame_pass = 0;
+      if (it == n_split - 1) HALO(FV3_HALO_INTERFACE_U__V, 1);
     } else {
-      HALO(FV3_HALO_INTERFACE_U__V, 0);
-      HALO(FV3_HALO_INTERFACE_U__V, 1);
+      // (the reference stores gz = g * zh first -- compute_geopotential; here the corner interpolation reads zh and scales it)
+      RUN(FV3_OP_NH_P_GRAD, fv3_nh_p_grad_scaled(c, &st->u, &st->v, &ws->pkc, &ws->zh, &ws->pk3, &f_delp[cur], dt, ptop, akap, c->cst.grav, stream));
+      if (cf.rf_fast) RUN(FV3_OP_RAY_FAST, fv3_ray_fast(c, &st->u, &st->v, &f_w[cur], dt, ptop, stream));
+      if (it != n_split - 1) {
+        HALO(FV3_HALO_U__V, 0);
+      } else {
+        HALO(FV3_HALO_INTERFACE_U__V, 0);
+        HALO(FV3_HALO_INTERFACE_U__V, 1);
+      }
     }
   }
   if (pingpong) {

@@ -197,7 +197,7 @@ static void del6_corner_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real 
   }
 }
 
-static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1, bool edge_strips_only = false) {
   const Geo g = c->g;
   const Deln d = dn;
   const int nk = k1 - k0 + 1;
@@ -210,6 +210,7 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr del6_u = g.del6_u, del6_v = g.del6_v, rarea = g.rarea;
+  const unsigned char *gflags = c->g_dev->flags;
   launch_waves<3>(c, s, nstrip, nseg, g.nsub * npair, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
     const int t = blk.bz / npair, ka = k0 + 2 * (blk.bz - t * npair);
     // per-level controls (the two levels of a pair may differ in order / switch: sponge boundary)
@@ -230,6 +231,10 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
     if (!act[0] && !act[1]) return;
     const long m2 = t * st2;
     const int i0 = 1 + blk.bx * D6_OUT;
+    if (edge_strips_only) {  // only the strips on which tp2d_stream_t evaluates the W / E tile-edge formulas (the others run the chain themselves)
+      const int fl = gflags[t];
+      if (!(((fl & FV3_W) && i0 <= 3) || ((fl & FV3_E) && i0 + D6_OUT + 1 >= nx))) return;
+    }
     const int ja = 1 + blk.by * seg;
     const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
@@ -262,7 +267,8 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
     FV3_LANES(blk, lane, l) {
       const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
       pcol[l] = (unsigned)(go * sj32 + ic + go);
-      own_x[l] = i >= i0 && i < i0 + D6_OUT && i <= nx + 1;
+      // (edge strips only: one more x face -- the high face of the strip's last cell belongs to the next strip, which then does not run)
+      own_x[l] = i >= i0 && i < i0 + D6_OUT + (edge_strips_only ? 1 : 0) && i <= nx + 1;
       own_y[l] = i >= i0 && i < i0 + D6_OUT && i <= nx;
 #pragma unroll
       for (int s_ = 0; s_ <= D6_NMAX; ++s_) {
@@ -364,6 +370,15 @@ static void del6_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Rea
     }
   });
   if (dn.nord_max > 0) del6_corner_patches(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1);
+}
+
+void del6_vt_flux_edge_strips(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
+  if (k0 > k1) return;
+  if (dn.nord_max > D6_NMAX) {
+    del6_vt_flux_staged(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1, nullptr);
+    return;
+  }
+  del6_stream(c, s, q, d2, fx2, fy2, dn, q_raw, k0, k1, true);
 }
 
 void del6_vt_flux_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1) {
@@ -494,7 +509,7 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 
 // FEAT: compile-time feature mask (TF_*): every call site gets a kernel that carries only the state,
 // pointers and branches it uses (the all-features kernel sat at 256 VGPRs with scratch and 131 spilled SGPRs).
-enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND = 32, TF_WFLUX = 64, TF_ACC = 128, TF_ALL = 255 };
+enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND = 32, TF_WFLUX = 64, TF_ACC = 128, TF_ALL = 255, TF_FD = 256 };
 
 template <unsigned FEAT>
 static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
@@ -517,8 +532,13 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nstrip = (g.nx + 1 + TS_OUT - 1) / TS_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
   const int nseg = (g.ny + seg - 1) / seg;
-  const size_t smem = sizeof(Real) * (2 * TS_LINE + 5 * (FV3_WAVE + 1) + 32);
+  constexpr int TS_NRING = (FEAT & TF_FD) ? 7 : 0;  // FD: the chain's metric rows + the parked delay lines, own-lane ring [variable][row & 3][lane]
+  const size_t smem_lines = (size_t)(2 * TS_LINE + 5 * (FV3_WAVE + 1) + 32);
+  const size_t smem = sizeof(Real) * (smem_lines + (size_t)TS_NRING * 4 * FV3_WAVE);
   const bool area_form = epi && epi->area_form;
+  const bool fd_on = (FEAT & TF_FD) && epi && epi->fd && !TS_LDS_ONLY;
+  const Real *fd_coef = epi ? epi->fd_coef : nullptr;
+  const MPtr d6u = g.del6_u, d6v = g.del6_v;
   const Real *zfx = epi ? epi->zfx : nullptr, *zfy = epi ? epi->zfy : nullptr, *zon = epi ? epi->zon : nullptr;
   Real *epi_out = epi ? epi->out : nullptr;
   const Real *epi_mult = epi ? epi->mult : nullptr;
@@ -564,6 +584,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real *exj = exf + FV3_WAVE + 1;   // xfx(i, r-3) (area-form epilogue)
     Real *exm = exj + FV3_WAVE + 1;   // mass(i, r-3) of the lane (read by lane + 1: the west cell of its face)
     Real *emr = exm + FV3_WAVE + 1;   // tile-edge strips: dxa of the 4 + 4 cells around the W / E edge, rows r..r-3 (ring of 4 x 8)
+    Real *ring = (Real *)smem_ + smem_lines;
+    enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };
+    auto RG = [&](int var, int r) -> Real * { return ring + (var * 4 + (r & 3)) * FV3_WAVE; };
     const Real *qq = q + b, *crxb = crx + b, *cryb = cry + b, *xfxb = xfx + b, *yfxb = yfx + b;
     const MPtr areab = area + m2;
     const bool W = (fl & FV3_W) && i0 <= 3, E = (fl & FV3_E) && i0 + TS_OUT + 1 >= npx - 1;
@@ -588,6 +611,21 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
     const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
+    // FD: the del-n chain of q inside the march (strips away from the W / E tile edges); see dsw_scalars_t in fv3_tp4.hip
+    constexpr bool C_FD = (FEAT & TF_FD) != 0;
+    const bool fdm = C_FD && fd_on && zdamp && !(W || E);
+    const Real dcoef = fdm ? fd_coef[k] : (Real)0;
+    Real sd0[FV3_LPT], sd1[FV3_LPT], sd2[FV3_LPT], gx0[FV3_LPT], gx1[FV3_LPT], gy0[FV3_LPT], gy1[FV3_LPT], dxd[FV3_LPT], dxn[FV3_LPT], dyf[FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
+    Real mdu_n[FV3_LPT], mdv_n[FV3_LPT], mra_n[FV3_LPT];
+    const MPtr d6ub = d6u + m2, d6vb = d6v + m2, rab = rarea + m2;
+    const bool c_sw_ = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_se = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
+    const bool c_ne = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_nw = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
+    const bool pz = fdm && (((c_sw_ || c_nw) && i0 - 3 <= FV3_D6_PATCH) || ((c_se || c_ne) && i0 + FV3_WAVE - 4 >= nx + 2 - FV3_D6_PATCH));
+    auto on_patch = [&](int i, int j) -> bool {
+      const bool wi = i >= 1 && i <= FV3_D6_PATCH, ei = i >= nx + 2 - FV3_D6_PATCH && i >= 1 && i <= nx + 1;
+      const bool sj = j >= 1 && j <= FV3_D6_PATCH, nj = j >= ny + 2 - FV3_D6_PATCH && j >= 1 && j <= ny + 1;
+      return (wi && sj && c_sw_) || (ei && sj && c_se) || (ei && nj && c_ne) || (wi && nj && c_nw);
+    };
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Real sqx[FV3_LPT], sqi[FV3_LPT], sxv[FV3_LPT], smb[FV3_LPT];  // strips away from the W / E tile edges: what the neighbouring lanes read (wavefront shuffles)
     Real wdu[FV3_LPT], wdv[FV3_LPT];  // vorticity-damping increments of u (face r-2) / v (row r-3)
@@ -636,6 +674,18 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       fxk[l] = fyp[l] = era[l] = emu[l] = o_mx[l] = o_my[l] = o_dx[l] = o_dy[l] = o_mc[l] = o_ax[l] = o_ay[l] = (Real)0;
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
+      sd0[l] = sd1[l] = sd2[l] = gx0[l] = gx1[l] = gy0[l] = gy1[l] = dxd[l] = dxn[l] = dyf[l] = zyp[l] = zxo[l] = mdu_n[l] = mdv_n[l] = mra_n[l] = (Real)0;
+      if constexpr (C_FD) {
+        if (!(W || E))
+          for (int v = 0; v < TS_NRING; ++v)
+            for (int q_ = 0; q_ < 4; ++q_) RG(v, q_)[lane] = v == RG_AR ? (Real)1 : (Real)0;
+        if (fdm) {
+          const unsigned pm = pcol[l] + (unsigned)((ja - 3) * sj32);
+          mdu_n[l] = d6ub[pm];
+          mdv_n[l] = d6vb[pm];
+          mra_n[l] = rab[pm];
+        }
+      }
       mb[l] = p_prev[l] = y_prev[l] = fi1[l] = fi2[l] = fi3[l] = cx1[l] = cx2[l] = cx3[l] = xv1[l] = xv2[l] = xv3[l] = (Real)0;
       if (lane < 3) lq[lane] = lqi[lane] = lq[FV3_WAVE + 3 + lane] = lqi[FV3_WAVE + 3 + lane] = (Real)0;
       if (lane == 0) exp_[FV3_WAVE] = exx[FV3_WAVE] = (Real)0;
@@ -674,13 +724,28 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
             if (need_mc) o_mc[l] = (mass_ + b)[pf];
             if (epi_out_) {
-              era[l] = (rarea + m2)[p3];
+              if (!(C_FD && fdm)) era[l] = (rarea + m2)[p3];
               if (epi_mult_ && epi_mult_ != mass_) emu[l] = (epi_mult_ + b)[p3];
-              if (zdamp) {
+              if (zdamp && !(C_FD && fdm)) {
                 zx0[l] = (zfx + b)[p3];
                 zx1[l] = (zfx + b)[p3 + 1];
                 zy0[l] = (zfy + b)[p3];
                 zy1[l] = (zfy + b)[p3 + (unsigned)sj32];
+              }
+            }
+            if constexpr (C_FD && !XE) {
+              if (fdm) {
+                // the chain's metric terms: row r (fetched during the previous step) goes into the ring, row r+1 is requested
+                const Real du_c = mdu_n[l], dv_c = mdv_n[l], ra_c = mra_n[l];
+                const int r1 = r + 1 < r_end ? r + 1 : r_end;
+                const unsigned pm = pcol[l] + (unsigned)(r1 * sj32);
+                mdu_n[l] = d6ub[pm];
+                mdv_n[l] = d6vb[pm];
+                mra_n[l] = rab[pm];
+                RG(RG_DU, r)[lane] = du_c;
+                RG(RG_DV, r)[lane] = dv_c;
+                RG(RG_RA, r)[lane] = ra_c;
+                era[l] = RG(RG_RA, r - 3)[lane];
               }
             }
             if (wind_u_) {
@@ -713,6 +778,25 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             qx = cc<1>(qq, *gp, fl, ic, rc);
             cur[l].qy = qy;
           }
+          if constexpr (C_FD && !XE) {
+            if (fdm) {
+              // ---- del-n chain, own-lane part: d2 of iteration s on row r-s, its y flux at face r-s (del6_stream phase A)
+              const Real du0 = RG(RG_DU, r)[lane], du1 = RG(RG_DU, r - 1)[lane], du2 = RG(RG_DU, r - 2)[lane];
+              const Real ra1 = RG(RG_RA, r - 1)[lane], ra2 = RG(RG_RA, r - 2)[lane];
+              const Real d0c = dcoef * cur[l].qy;
+              const Real fyc0 = du0 * (sd0[l] - d0c);
+              const Real gxe0 = FV3_LANE_SHL(1, gx0, l, lane), gxe1 = FV3_LANE_SHL(1, gx1, l, lane);
+              const Real d2c1 = (gx0[l] - gxe0 + gy0[l] - fyc0) * ra1;
+              const Real fyc1 = du1 * (d2c1 - sd1[l]);
+              const Real d2c2 = (gx1[l] - gxe1 + gy1[l] - fyc1) * ra2;
+              dyf[l] = du2 * (d2c2 - sd2[l]);
+              gy0[l] = fyc0;
+              gy1[l] = fyc1;
+              sd0[l] = d0c;
+              sd1[l] = d2c1;
+              sd2[l] = d2c2;
+            }
+          }
           w2[l] = w3[l];
           w3[l] = w4[l];
           w4[l] = w5[l];
@@ -731,7 +815,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           cq[l] = co;
           const Real yv = cur[l].yv;
           const Real pn = yv * fyin[l];
-          const Real ar3 = a3[l];  // area(i, r-3): the row loaded three steps ago
+          constexpr bool PARK = C_FD && !XE;  // the pure delay lines of the wave live in the LDS ring (makes room for the chain)
+          const Real ar3 = PARK ? RG(RG_AR, r - 3)[lane] : a3[l];  // area(i, r-3): the row loaded three steps ago
           const Real qi = (w2[l] * ar3 + p_prev[l] - pn) / (ar3 + y_prev[l] - yv);
           p_prev[l] = pn;
           ypp[l] = y_prev[l];
@@ -751,6 +836,33 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
         FV3_LANES(blk, lane, l) {
           const Real cx = cur[l].cx, xv = cur[l].xv;
           Real fxin, fxout;
+          constexpr bool PARK = C_FD && !XE;
+          if constexpr (PARK) {
+            cx3[l] = RG(RG_CX, r - 3)[lane];
+            xv3[l] = RG(RG_XV, r - 3)[lane];
+            fi3[l] = RG(RG_FI, r - 3)[lane];
+          }
+          if constexpr (C_FD && !XE) {
+            if (fdm) {
+              // ---- del-n chain, x fluxes (del6_stream phase B); the damping fluxes around the cell (i, r-3) for the epilogue
+              const Real dv0 = RG(RG_DV, r)[lane], dv1 = RG(RG_DV, r - 1)[lane], dv2 = RG(RG_DV, r - 2)[lane];
+              const Real w0 = FV3_LANE_SHR(1, sd0, l, lane), w1 = FV3_LANE_SHR(1, sd1, l, lane), w2_ = FV3_LANE_SHR(1, sd2, l, lane);
+              gx0[l] = dv0 * (w0 - sd0[l]);
+              gx1[l] = dv1 * (sd1[l] - w1);
+              dxn[l] = dv2 * (sd2[l] - w2_);
+              Real ox = dxd[l], oy = dyf[l];  // x flux of (i, r-3), y flux of face (i, r-2)
+              if (pz) {
+                const int i = i0 - 3 + lane, jr_ = r - 3, jf_ = r - 2;
+                if (jr_ >= 1 && jr_ <= ny && on_patch(i, jr_)) ox = (zfx + b)[pcol[l] + (unsigned)(jr_ * sj32)];
+                if (i <= nx && on_patch(i, jf_)) oy = (zfy + b)[pcol[l] + (unsigned)(jf_ * sj32)];
+              }
+              zx0[l] = ox;
+              zxo[l] = ox;
+              zy0[l] = zyp[l];
+              zy1[l] = oy;
+              dxd[l] = dxn[l];
+            }
+          }
           if (XE) {
             const int i = i0 - 3 + lane;
             auto EI = [&](int s_) { return s_ <= 2 ? s_ + 1 : s_ - (npx - 2) + 4; };  // ring column of an edge cell
@@ -801,15 +913,21 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               }
             }
           }
-          fi3[l] = fi2[l];
-          fi2[l] = fi1[l];
-          fi1[l] = fxin;
-          cx3[l] = cx2[l];
-          cx2[l] = cx1[l];
-          cx1[l] = cx;
-          xv3[l] = xv2[l];
-          xv2[l] = xv1[l];
-          xv1[l] = xv;
+          if constexpr (PARK) {
+            RG(RG_FI, r)[lane] = fxin;
+            RG(RG_CX, r)[lane] = cx;
+            RG(RG_XV, r)[lane] = xv;
+          } else {
+            fi3[l] = fi2[l];
+            fi2[l] = fi1[l];
+            fi1[l] = fxin;
+            cx3[l] = cx2[l];
+            cx2[l] = cx1[l];
+            cx1[l] = cx;
+            xv3[l] = xv2[l];
+            xv2[l] = xv1[l];
+            xv1[l] = xv;
+          }
           px[l] = xv * fxin;
           if constexpr (LX) {
             exp_[lane] = px[l];
@@ -837,6 +955,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (epi_out_) {
               fxe = FV3_LANE_SHL(1, fxk, l, lane);
               if (area_form_) xje = FV3_LANE_SHL(1, xjr, l, lane);
+            }
+          }
+          if constexpr (C_FD && !XE) {
+            if (fdm) {
+              zx1[l] = FV3_LANE_SHL(1, zxo, l, lane);
+              zyp[l] = zy1[l];
             }
           }
           const Real ar = cur[l].ar;
@@ -877,7 +1001,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 const Real qc = w2[l];  // q(i, r-3)
                 const Real mu = epi_mult_ ? (epi_mult_ == mass_ ? mb[l] : emu[l]) : (Real)1;
                 if (area_form_) {
-                  const Real ar_ = a3[l];
+                  const Real ar_ = (C_FD && !XE) ? RG(RG_AR, r - 3)[lane] : a3[l];
                   const Real ra_x = ar_ + xjr[l] - xje, ra_y = ar_ + ypp[l] - cur[l].yv;
                   Real z = (qc * ar_ + fxk[l] - fxe + fyp[l] - v) / (ra_x + ra_y - ar_);
                   if (zdamp) z = z + (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
@@ -896,9 +1020,13 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           } else {
             smb[l] = mb[l];
           }
-          a3[l] = a2[l];
-          a2[l] = a1[l];
-          a1[l] = cur[l].ar;
+          if constexpr (C_FD && !XE) {
+            RG(RG_AR, r)[lane] = cur[l].ar;
+          } else {
+            a3[l] = a2[l];
+            a2[l] = a1[l];
+            a1[l] = cur[l].ar;
+          }
         }
         if constexpr (LX) blk.wave_sync();
       };
@@ -939,6 +1067,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     if (epi->area_form) m |= TF_AREA;
     if (epi->wind_u) m |= TF_WIND;
     if (epi->acc_x) m |= TF_ACC;
+    if (epi->fd && epi->area_form && epi->zfx) m |= TF_FD;
   }
 #define TP_CASE(F)                                                                                          \
   case (F):                                                                                                 \
@@ -953,6 +1082,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     TP_CASE(TF_MFX | TF_MASS | TF_DAMP | TF_EPI)                  // d_sw: q_con, pt
     TP_CASE(TF_WIND)                                              // d_sw: absolute vorticity + wind update
     TP_CASE(TF_EPI | TF_AREA)                                     // update_dz_d: interface heights
+    TP_CASE(TF_EPI | TF_AREA | TF_FD)                             // update_dz_d: interface heights, their del-n chain inside the march
     default:
       tp2d_stream_t<TF_ALL>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
   }
@@ -964,6 +1094,7 @@ void tp2d(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real
   // FV3_TP2D_MODE = staged | stream (default): the staged form is the reference / A-B path
   static const char *mode_env = getenv("FV3_TP2D_MODE");
   static const bool staged = mode_env && !strcmp(mode_env, "staged");
+  if (k0 > k1) return;
   if (!staged) {
     tp2d_stream(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
     return;

@@ -17,6 +17,7 @@ neighbours on the same device never touch RCCL.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from dataclasses import dataclass, field
@@ -65,6 +66,7 @@ class _Plan:
         d = np.ascontiguousarray(dst_off, dtype=np.int64)
         s = np.ascontiguousarray(src_off, dtype=np.int64)
         g = np.ascontiguousarray(sign, dtype=np.int8)
+        self.offsets = (d, s, g)  # (kept for the loop-back transport, which runs an unpack plan backwards once)
         st = sf.lib.fv3_gather_plan_create(
             sf.ctx,
             C.byref(self.h),
@@ -239,14 +241,31 @@ class HaloExchanger:
         halo VALUES are therefore not the neighbours' (timing runs only; never a parity path)."""
         from . import lib as _lib
 
+        # FV3_LOOPBACK_DELAY_US: a device-side stall of that many microseconds per update on the stream the exchange runs on -- the
+        # transfer time of a real interconnect, to measure how much of it the sequencer hides (tools/overlap_experiment.py)
+        delay_us = float(os.environ.get("FV3_LOOPBACK_DELAY_US", "0"))
+        on_gpu = torch.device(self.sf.device).type == "cuda"
+        spin = 0
+        if delay_us > 0 and on_gpu:
+            spin = int(delay_us * 1.0e-6 * torch.cuda.get_device_properties(self.sf.device).clock_rate * 1.0e3)  # (clock_rate in kHz)
+
         def xfer(_user, plan, phase):
             try:
                 up = self._by_plan[int(plan)]
                 if int(phase) == 0:
-                    for p in up._peers:
-                        rb, sb = up._recv_bufs[p], up._send_bufs[p]
-                        if rb is not None and sb is not None and rb.numel() == sb.numel():
-                            rb.copy_(sb, non_blocking=True)
+                    h = self.sf.lib.fv3_ctx_get_comm_stream(self.sf.ctx) if on_gpu else None
+                    ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(h), device=self.sf.device)) if h else contextlib.nullcontext()
+                    with ctx:  # (the library's communication stream: ordered with the plan's pack / unpack kernels)
+                        for p in up._peers:
+                            rb, sb = up._recv_bufs[p], up._send_bufs[p]
+                            if rb is not None and sb is not None and rb.numel() == sb.numel():
+                                rb.copy_(sb, non_blocking=True)
+                        if spin:
+                            torch.cuda._sleep(spin)
+                    for rev, p, fptr, boff, bks in up._prime:
+                        rb = up._recv_bufs[p]
+                        rev.run(rb.data_ptr() + boff * rb.element_size(), bks, fptr, self.sk, up.nk, h if h else up._stream())
+                    up._prime = []
                 return 0
             except Exception as e:  # never let an exception cross the C frame
                 self._xfer_error = e
@@ -378,6 +397,7 @@ class HaloUpdater:
 
         ex, ph, sf = self.ex, self.ph, self.ex.sf
         ng, nk = len(self.groups), self.nk
+        self._prime = []
         peers = sorted(set(ph.send_count) | set(ph.recv_count))
         pidx = {p: i for i, p in enumerate(peers)}
         ops = []
@@ -395,6 +415,12 @@ class HaloUpdater:
             for peer, cnt in ph.recv_count.items():
                 for comp, plan in ph.recv[peer].items():
                     op(_lib.HALO_UNPACK, plan, gp[comp].storage.data_ptr(), None, ex.sk, 0, gi * cnt * nk, cnt, pidx[peer])
+                    if getattr(ex.layout, "loopback", False) and not ph.send_count.get(peer, 0) and plan.n:
+                        # loop-back run, a peer this process only receives from: its message is primed ONCE with what the halo
+                        # cells hold before the first update (the unpack plan run backwards), so the update keeps writing finite,
+                        # consistent values instead of zeros
+                        d, s_, g = plan.offsets
+                        self._prime.append((_Plan(sf, s_, d, g), peer, gp[comp].storage.data_ptr(), gi * cnt * nk, cnt))
         plist = []
         self._send_bufs, self._recv_bufs = {}, {}
         for p in peers:

@@ -153,6 +153,7 @@ _PROTOS = {
     "fv3_halo_plan_destroy": (C.c_int, [C.c_void_p]),
     "fv3_halo_plan_buffer": (C.c_int, [C.c_void_p, _I, _I, P(C.c_void_p), P(C.c_int64)]),
     "fv3_rccl_available": (C.c_int, []),
+    "fv3_ctx_get_comm_stream": (C.c_void_p, [C.c_void_p]),
     "fv3_comm_unique_id": (C.c_int, [P(fv3_nccl_id)]),
     "fv3_ctx_comm_init": (C.c_int, [C.c_void_p, P(fv3_nccl_id), _I, _I]),
     "fv3_ctx_comm_destroy": (C.c_int, [C.c_void_p]),

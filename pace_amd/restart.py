@@ -1,14 +1,26 @@
-"""Restart adaptor of the dycore state: one netCDF file per rank in the layout the reference driver
-writes and reads back,
+"""Restart adaptor of the dycore state: one netCDF file per rank, named and laid out like the files the reference
+driver writes,
 
     <restart_path>/restart_dycore_state_<rank>.nc
 
 [REF driver/pace/driver/state.py:114-123 ``DriverState.save_state``; :154-172 ``_overwrite_state_from_restart``:
 ``state.<field>.data[:] = ds[<field>].data[:]`` for every field that carries units].  Each variable is the Quantity's full
 ``data`` array -- halo included, index order (i, j, k) -- with its ``units`` attribute and dimension names from the
-Quantity's dims; the reference goes through xarray / netCDF4, this build writes classic netCDF-3 with scipy (64-bit
-offsets), which xarray opens unchanged.  The files are keyed by the reference's GLOBAL rank number, so a run on N GPUs
-(several sub-domains per process) and the reference's one-rank-per-process run exchange restarts freely.
+Quantity's dims, keyed by the reference's GLOBAL rank number (a run on N GPUs with several sub-domains per process writes the
+same files as a one-rank-per-process run).
+
+What does and does not interchange with the reference (stated, not assumed):
+
+* WRITING: classic netCDF-3, 64-bit offsets (scipy is the only netCDF writer in this image); xarray opens such files unchanged.
+  The reference's reader indexes EVERY ``DycoreState`` field that has units (the tracers ``qvapor`` ... ``qcld`` included); this
+  build's state holds the acoustic path's fields only, so a reference run can restart from these files only if the caller adds
+  the remaining fields through ``extra`` (name -> Quantity: the harness passes its tracers).
+* READING: the reference writes through ``xr_dataset.to_netcdf()``, i.e. netCDF-4 / HDF5 by default.  Such files need ``netCDF4``,
+  ``h5netcdf`` or ``xarray`` in the environment (tried in that order); with none of them -- this image -- ``load_state`` says so
+  instead of failing inside scipy.  Classic files (this build's own, or a reference file written with ``format="NETCDF3_64BIT"``)
+  are read with scipy.
+* ``load_state`` is strict: a requested variable that is missing from a file is an error (``allow_missing=True`` keeps what the
+  state holds for it), so a restart can never silently continue from synthetic data.
 """
 from __future__ import annotations
 
@@ -29,20 +41,21 @@ def _path(restart_path: str, rank: int) -> str:
     return os.path.join(restart_path, f"{PREFIX}_{rank}.nc")
 
 
-def save_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str = "RESTART", names: Optional[Iterable[str]] = None) -> list:
-    """Write one file per local rank; returns the paths.  ``local_ranks[i]`` is the global rank of sub-domain i."""
+def save_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str = "RESTART", names: Optional[Iterable[str]] = None, extra=None) -> list:
+    """Write one file per local rank; returns the paths.  ``local_ranks[i]`` is the global rank of sub-domain i.
+    ``extra``: {name: Quantity} written beside the state's fields (the tracers)."""
     from scipy.io import netcdf_file
 
     os.makedirs(restart_path, exist_ok=True)
     names = list(names or (STATE_NAMES + ["phis"]))
+    fields = [(n, getattr(state, n)) for n in names] + list((extra or {}).items())
     out = []
     for i, rank in enumerate(local_ranks):
         p = _path(restart_path, rank)
         with netcdf_file(p, "w", version=2) as f:
             f.history = "pace_amd.restart.save_state"
             f.rank = np.int32(rank)
-            for n in names:
-                q = getattr(state, n)
+            for n, q in fields:
                 a = q.numpy(i)  # (i, j[, k]) host copy of the full storage
                 dims = []
                 for d, length in zip(q.dims, a.shape):
@@ -58,24 +71,61 @@ def save_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str
     return out
 
 
-def load_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str = "RESTART", names: Optional[Iterable[str]] = None) -> DycoreState:
-    """Overwrite ``state`` from the per-rank files (every field present in the file and in the state)."""
-    from scipy.io import netcdf_file
+def _open_variables(path: str):
+    """{name: ndarray (native byte order)} of one restart file, with whatever reader fits its format."""
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+    if magic[:3] == b"CDF":  # classic netCDF (this build's files)
+        from scipy.io import netcdf_file
 
-    want = list(names or (STATE_NAMES + ["phis"]))
+        with netcdf_file(path, "r", mmap=False) as f:
+            return {n: np.array(v[:]).astype(v[:].dtype.newbyteorder("=")) for n, v in f.variables.items()}
+    if magic == b"\x89HDF":  # netCDF-4 / HDF5: what the reference's xarray writes by default
+        try:
+            import netCDF4
+
+            with netCDF4.Dataset(path) as ds:
+                return {n: np.asarray(ds.variables[n][:]) for n in ds.variables}
+        except ImportError:
+            pass
+        try:
+            import h5netcdf
+
+            with h5netcdf.File(path, "r") as ds:
+                return {n: np.asarray(ds.variables[n][...]) for n in ds.variables}
+        except ImportError:
+            pass
+        try:
+            import xarray as xr
+
+            with xr.open_dataset(path) as ds:
+                return {n: np.asarray(ds[n].data) for n in ds.variables}
+        except ImportError:
+            pass
+        raise RuntimeError(f"{path} is a netCDF-4 / HDF5 file (the reference's default restart format) and this environment has none of netCDF4, h5netcdf, "
+                           "xarray to read it; convert it to classic netCDF (xarray: to_netcdf(format='NETCDF3_64BIT')) or install one of them")
+    raise RuntimeError(f"{path}: not a netCDF file (magic {magic!r})")
+
+
+def load_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str = "RESTART", names: Optional[Iterable[str]] = None, extra=None,
+               allow_missing: bool = False) -> DycoreState:
+    """Overwrite ``state`` (and the ``extra`` Quantities, e.g. the tracers) from the per-rank files.  Every requested variable must
+    be in every file unless ``allow_missing``."""
+    want = [(n, getattr(state, n)) for n in (names or (STATE_NAMES + ["phis"]))] + list((extra or {}).items())
     for i, rank in enumerate(local_ranks):
         p = _path(restart_path, rank)
         if not os.path.exists(p):
             raise FileNotFoundError(f"{p}: no restart file for rank {rank}")
-        with netcdf_file(p, "r", mmap=False) as f:
-            for n in want:
-                if n not in f.variables:
-                    continue
-                a = np.array(f.variables[n][:])
-                a = a.astype(a.dtype.newbyteorder("="))  # (netCDF classic is big-endian)
-                q = getattr(state, n)
-                exp = q.numpy(i).shape
-                if a.shape != exp:
-                    raise ValueError(f"{p}: variable {n} has shape {a.shape}, the state expects {exp} (different nx / nz / halo)")
-                q.set_numpy(a, i)
+        have = _open_variables(p)
+        missing = [n for n, _ in want if n not in have]
+        if missing and not allow_missing:
+            raise KeyError(f"{p}: variables missing from the restart file: {', '.join(missing)} (allow_missing=True keeps the state's own values for them)")
+        for n, q in want:
+            if n not in have:
+                continue
+            a = have[n]
+            exp = q.numpy(i).shape
+            if a.shape != exp:
+                raise ValueError(f"{p}: variable {n} has shape {a.shape}, the state expects {exp} (different nx / nz / halo)")
+            q.set_numpy(a, i)
     return state

@@ -51,3 +51,25 @@ def test_eta79_fixture():
     assert ak.shape == (80,) and bk.shape == (80,)
     assert ak[0] == 300.0 and bk[-1] == 1.0 and bk[0] == 0.0
     assert np.all(np.diff(ak + bk * 1e5) > 0)
+
+
+@pytest.mark.parametrize("rank", [0, 1, 4])
+def test_grid_init_not_decomposition_dependent_3x3(rank):
+    """The reference's own grid test [REF tests/main/test_grid_init.py:30-84]: C48, ranks 0 / 1 / 4 of a 3 x 3 layout against the
+    matching window of the 1 x 1 tile, the same list of metric terms (corner and cell-centre positions, area, dx, dy, the four
+    cos_sg / sin_sg, rarea, rdx, rdy) -- and, like the reference (``v1 == v2``), bit for bit on the compute domain."""
+    n, lay = 48, (3, 3)
+    g1 = make_grid(CubedSpherePartitioner(n, (1, 1)), 0, nz=4)
+    part = CubedSpherePartitioner(n, lay)
+    g = make_grid(part, rank, nz=4)
+    x0, y0 = part.origin(rank)
+    m = n // 3
+    cells = ("area", "rarea", "lon_agrid", "lat_agrid", "cos_sg1", "cos_sg2", "cos_sg3", "cos_sg4", "sin_sg1", "sin_sg2", "sin_sg3", "sin_sg4")
+    for name in cells + ("dx", "rdx", "dy", "rdy", "lon", "lat"):
+        a_all = g.fields[name] if name in g.fields else getattr(g, name)
+        b_all = g1.fields[name] if name in g1.fields else getattr(g1, name)
+        ex = 1 if name in ("dy", "rdy", "lon", "lat") else 0  # x-interface / corner staggering
+        ey = 1 if name in ("dx", "rdx", "lon", "lat") else 0
+        a = a_all[3 : 3 + m + ex, 3 : 3 + m + ey]
+        b = b_all[3 + x0 : 3 + x0 + m + ex, 3 + y0 : 3 + y0 + m + ey]
+        assert a.shape == b.shape and np.array_equal(a, b), name

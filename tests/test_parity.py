@@ -328,6 +328,41 @@ def test_del_n_chains_inside_the_marches_are_bitwise_the_del6_launches(backend, 
             assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
+def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
+    """update_dz_d: the del-n chain of the interface heights run inside the transport march (tp2d_stream_t TF_FD, strips away from
+    the W / E tile edges; tile-edge strips and corner patches still from del6_stream) against the chain as its own launch
+    (FV3_DZ_DELN=arrays).  C130: an interior strip between two tile-edge strips; C140 2 x 2: sub-domains whose second strip is
+    interior or tile-edge depending on the side; two row segments."""
+    nz = 3
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=1, k_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("fused", "arrays"):
+        monkeypatch.setenv("FV3_DZ_DELN", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
+
+
+@pytest.mark.parametrize("n, layout, n_split", [(24, (2, 2), 3), (12, (1, 1), 2)])
+def test_frame_first_passes_are_bitwise_neutral(backend, monkeypatch, n, layout, n_split):
+    """fv3_acoustic_step with the operators that feed a halo update split into frame + interior passes (p_grad_c -> uc / vc;
+    nh_p_grad + ray_fast -> u / v / w, whose updates then start before the interior is computed: the multi-process overlap) against
+    the unsplit sequence: every array equal including its halos, for even and odd sub-step counts."""
+    nz = 5
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=n_split, k_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV3_FRAME_FIRST", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE + ["uc", "vc"]:
+            assert np.array_equal(res["1"][r][name], res["0"][r][name]), f"{name} rank {r}"
+
+
 def test_native_and_python_sequencers_are_identical(backend):
     """fv3_acoustic_step (C, the product path) and its Python twin in dyn_core.py issue the same
     operator / halo sequence: bitwise equal states, and the per-operator profile is populated."""

@@ -11,18 +11,19 @@ def _harness(backend, **kw):
     return DycoreHarness(12, nz=6, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=1, backend=backend, **kw)
 
 
-def test_restart_round_trip_continues_bitwise(hostemu, tmp_path):
+def test_restart_round_trip_continues_bitwise(backend, tmp_path):
     """Two steps in one go == one step, save, load into a fresh state, one more step (bit for bit), and the files carry the
-    reference's names / units / (i, j, k) full-storage shapes."""
+    reference's names / units / (i, j, k) full-storage shapes.  On the host emulation and -- device state -> files -> fresh device
+    state -> continuation -- on the MI355X (-m gpu)."""
     from scipy.io import netcdf_file
 
     from pace_amd import restart
     from pace_amd.dyn_core import STATE_NAMES
 
-    a = _harness("hostemu")
+    a = _harness(backend)
     a.step()
     a.step()
-    b = _harness("hostemu")
+    b = _harness(backend)
     b.step()
     paths = restart.save_state(b.state, b.layout.local_ranks, str(tmp_path / "RESTART"))
     assert [os.path.basename(p) for p in paths] == [f"restart_dycore_state_{r}.nc" for r in range(6)]
@@ -30,13 +31,62 @@ def test_restart_round_trip_continues_bitwise(hostemu, tmp_path):
         assert f.variables["delp"].shape == (19, 19, 7) and f.variables["phis"].shape == (19, 19)
         assert f.variables["delp"].units == b"Pa" and f.variables["u"].dims == b"x y_interface z"
         assert set(STATE_NAMES) <= set(f.variables)
-    c = _harness("hostemu", seed=1)  # a different state, fully overwritten by the restart
+    c = _harness(backend, seed=1)  # a different state, fully overwritten by the restart
     restart.load_state(c.state, c.layout.local_ranks, str(tmp_path / "RESTART"))
     c.dyn._bind(c.state)  # (zs depends on phis)
     c.step()
     for n in ("delp", "pt", "u", "v", "w", "delz", "q_con"):
         for r in range(6):
             assert np.array_equal(getattr(a.state, n).numpy(r), getattr(c.state, n).numpy(r)), (n, r)
+
+
+def test_restart_with_tracers_and_remap_continues_bitwise(backend, tmp_path):
+    """The body of step_dynamics (acoustic call + tracer advection + remap) across a restart: the tracers travel in the same
+    files (``extra``), and the continued run equals the uninterrupted one bit for bit."""
+    from pace_amd import restart
+
+    kw = dict(n_tracers=2, hord_tr=8, remap=True)
+    a = _harness(backend, **kw)
+    a.step()
+    a.step()
+    b = _harness(backend, **kw)
+    b.step()
+    restart.save_state(b.state, b.layout.local_ranks, str(tmp_path), extra=b.tracers)
+    c = _harness(backend, seed=1, **kw)
+    restart.load_state(c.state, c.layout.local_ranks, str(tmp_path), extra=c.tracers)
+    c.dyn._bind(c.state)
+    c.step()
+    a.synchronize()
+    c.synchronize()
+    for r in range(6):
+        for n in ("delp", "pt", "u", "v", "w", "delz"):
+            assert np.array_equal(getattr(a.state, n).numpy(r), getattr(c.state, n).numpy(r)), (n, r)
+        for n in a.tracers:
+            assert np.array_equal(a.tracers[n].numpy(r), c.tracers[n].numpy(r)), (n, r)
+
+
+def test_restart_is_strict_about_missing_variables_and_foreign_formats(hostemu, tmp_path):
+    from pace_amd import restart
+
+    b = _harness("hostemu", n_tracers=1)
+    restart.save_state(b.state, b.layout.local_ranks, str(tmp_path))  # (without the tracers)
+    with pytest.raises(KeyError, match="tracer0"):
+        restart.load_state(b.state, b.layout.local_ranks, str(tmp_path), extra=b.tracers)
+    restart.load_state(b.state, b.layout.local_ranks, str(tmp_path), extra=b.tracers, allow_missing=True)
+    # a netCDF-4 / HDF5 file (the reference's default) is recognised; without an HDF5 reader the error says what to do
+    p = tmp_path / "h5"
+    p.mkdir()
+    for r in range(6):
+        (p / f"restart_dycore_state_{r}.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    try:
+        import netCDF4  # noqa: F401
+
+        have_reader = True
+    except ImportError:
+        have_reader = False
+    if not have_reader:
+        with pytest.raises(RuntimeError, match="netCDF-4 / HDF5"):
+            restart.load_state(b.state, b.layout.local_ranks, str(p))
 
 
 def test_restart_shape_mismatch_is_refused(hostemu, tmp_path):

@@ -21,7 +21,7 @@ done
 cd "$R"
 python tools/summarize_rocprof.py "$out/stats/s_kernel_stats.csv" 60 > "$out/kernel_stats.md" 2>&1
 cp "$out/stats/s_kernel_stats.csv" "$out/kernel_stats.csv" 2>/dev/null
-python tools/pmc_traffic.py "$out/pmc_FETCH_SIZE/p_counter_collection.csv" "$out/pmc_WRITE_SIZE/p_counter_collection.csv" 70 2348252160 fxadv "fv3_d_sw#" "$out/traffic_d_sw.json" > "$out/traffic.md" 2>&1
+python tools/pmc_traffic.py "$out/pmc_FETCH_SIZE/p_counter_collection.csv" "$out/pmc_WRITE_SIZE/p_counter_collection.csv" 70 2348252160 fxadv "fv3_d_sw_out#" "$out/traffic_d_sw.json" > "$out/traffic.md" 2>&1
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*counter_collection.csv" -delete
 cat "$out/pytest_gpu.log"
