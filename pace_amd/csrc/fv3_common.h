@@ -154,7 +154,9 @@ struct fv3_ctx {
   struct ProfEvent {
     int op;
     void *e0, *e1;
+    int parent;  // >= 0: recorded inside that operator's own event pair (its time is taken out of the parent's)
   };
+  int prof_parent = -1;
   std::vector<ProfEvent> prof_events;
   double prof_ms[16] = {0};
   int64_t prof_n[16] = {0};

@@ -247,7 +247,15 @@ class HaloExchanger:
         on_gpu = torch.device(self.sf.device).type == "cuda"
         spin = 0
         if delay_us > 0 and on_gpu:
-            spin = int(delay_us * 1.0e-6 * torch.cuda.get_device_properties(self.sf.device).clock_rate * 1.0e3)  # (clock_rate in kHz)
+            # cycles of torch.cuda._sleep per microsecond, measured (the device properties of this build carry no clock rate)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(self.sf.device)
+            torch.cuda._sleep(1000)
+            e0.record()
+            torch.cuda._sleep(20_000_000)
+            e1.record()
+            torch.cuda.synchronize(self.sf.device)
+            spin = int(delay_us * 20_000_000 / (e0.elapsed_time(e1) * 1.0e3))
 
         def xfer(_user, plan, phase):
             try:

@@ -82,10 +82,20 @@ def test_spot_check_machinery_on_the_host_emulation(hostemu):
     _conservation_and_tile0_spot_check("hostemu", 12, 8)
 
 
-def _conservation_and_tile0_spot_check(backend, nx, nz):
+@gpu
+def test_c768_l79_fp64_full_size_one_call(gpu_backend):
+    """cfg-3 at FULL size (the headline workload: C768 L79 fp64, 24 sub-domains of 384^2 in one context, 1 920 planes, the
+    <79>-templated column kernels): one acoustic call of 2 sub-steps through fv3_acoustic_step -- finite, inside the
+    SafetyChecker-style bounds, global air mass conserved to 1e-13 -- then c_sw and d_sw of sub-domain 0 (the SW corner of tile
+    0: W and S tile edges and a cube corner) against the oracle at all 79 levels."""
+    _conservation_and_tile0_spot_check(gpu_backend, 768, 79, layout=(2, 2), dt_atmos=225.0 / 6, native_first=True)
+
+
+def _conservation_and_tile0_spot_check(backend, nx_tile, nz, layout=(1, 1), dt_atmos=200.0, native_first=False):
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(nx, nz=nz, layout=(1, 1), dt_atmos=200.0, k_split=1, n_split=2, backend=backend)
+    h = DycoreHarness(nx_tile, nz=nz, layout=layout, dt_atmos=dt_atmos, k_split=1, n_split=2, backend=backend)
+    nx = nx_tile // layout[0]
     area = h.sf.grid_fields["area"].storage  # [n_sub, nj, ni]
     nh = 3
 
@@ -94,6 +104,16 @@ def _conservation_and_tile0_spot_check(backend, nx, nz):
         return float((d * area[:, None, nh : nh + nx, nh : nh + nx].double()).sum().item())
 
     m0 = mass()
+    if native_first:  # the product sequencer (fv3_acoustic_step) on the full-size state first
+        h.step()
+        h.synchronize()
+        m1 = mass()
+        assert abs(m1 - m0) <= 1e-13 * abs(m0), f"air mass drifted by {(m1 - m0) / m0:.2e} (native call)"
+        san = h.sanity()
+        assert all(v[2] for v in san.values()), san
+        assert 0.0 < san["delp"][0] and san["delp"][1] < 1.0e5 and 1.0 < san["pt"][0] and san["pt"][1] < 1000.0, san
+        assert max(abs(san["u"][0]), abs(san["u"][1]), abs(san["v"][0]), abs(san["v"][1])) < 200.0 and max(abs(san["w"][0]), abs(san["w"][1])) < 50.0, san
+        m0 = m1
     cap = _Capture(0)
     h.dyn.checkpointer = cap  # -> the Python twin of the sequencer (bitwise = fv3_acoustic_step, test_parity)
     h.step()
@@ -105,7 +125,7 @@ def _conservation_and_tile0_spot_check(backend, nx, nz):
     # ---- tile 0, first sub-step: c_sw and d_sw against the oracle on the device's own inputs
     D = Dom(h.grids[0], get_constants())
     V = lambda a: a[:, :, :nz].copy()  # noqa: E731
-    dt = 200.0 / 2
+    dt = dt_atmos / 2
     ci, co = cap.data["C_SW-In"], cap.data["C_SW-Out"]
     z = lambda: np.zeros_like(V(ci["ud"]))  # noqa: E731
     o = dict(uc=z(), vc=z(), ua=z(), va=z(), ut=z(), vt=z(), divgd=z(), omga=z())
