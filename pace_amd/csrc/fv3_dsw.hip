@@ -946,6 +946,19 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   bool keep_uv_dx = false;
   for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
   Real *ut2 = c->scratch[SC_E], *vt2 = c->scratch[SC_F];  // = the utd / vtd slots below (damping fluxes overwrite them on damped levels)
+  // Levels from fdw_k0 on (vorticity damping of order 2: all but the sponge layers): the vorticity transport loads wk and adds f0
+  // itself and runs wk's del-n chain inside its march (tp2d TF_WIND | TF_FD) -- no absolute-vorticity field, no del6_stream launch
+  // over those levels but for the tile-edge strips.  FV3_DSW_VORT_DELN=arrays: the round-2 form (A/B reference).
+  int fdw_k0 = g.nz;
+  {
+    const char *e = getenv("FV3_DSW_VORT_DELN"), *m = getenv("FV3_TP2D_MODE"), *m6 = getenv("FV3_DEL6_MODE");
+    const bool off = (e && !strcmp(e, "arrays")) || (m && !strcmp(m, "staged")) || (m6 && !strcmp(m6, "staged")) || keep_uv_dx;
+    if (!off)
+      for (int k = g.nz - 1; k >= 0; --k) {
+        if (!(c->nord_v_h[k] == 2 && c->damp_vt_h[k] > 1.0e-5)) break;
+        fdw_k0 = k;
+      }
+  }
   // (two levels per thread: the six metric terms are read once)
   launch3(c, s, Box{isd, ied, jsd, jed, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
@@ -961,7 +974,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       const Real e = (v + b)[p] * dy0, e1 = (v + b)[pe_] * dy1;
       const Real wkv = ra * (a - a1 - e + e1);
       (wk + b)[p] = wkv;
-      (vabs + b)[p] = wkv + f0v;  // absolute vorticity for the transport below
+      if (k < fdw_k0) (vabs + b)[p] = wkv + f0v;  // absolute vorticity for the transport below (formed on load from fdw_k0 on)
       if (keep_uv_dx) {
         (vt2 + b)[p] = a;
         (ut2 + b)[p] = e;
@@ -1125,7 +1138,8 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   Real *utd = c->scratch[SC_E], *vtd = c->scratch[SC_F];  // (the tracer-flux slots: free since the tracer transports are done)
   {
     Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
-    del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, nz1);
+    del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, fdw_k0 - 1);
+    del6_vt_flux_edge_strips(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, fdw_k0, nz1);
   }
   // ---- vorticity transport; the wind update u = u*dx + ke - ke[i+1] + fy, v = v*dy + ke - ke[j+1] - fx is the
   //      transport kernel's epilogue (the vorticity fluxes are never stored), and so is the vorticity damping
@@ -1133,8 +1147,12 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   //      formed from -- go to scratch beside
   Real *u_pre = c->scratch[SC_N], *v_pre = c->scratch[SC_O];
   {
-    const TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
-    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, nz1, &e);
+    TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
+    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, fdw_k0 - 1, &e);
+    e.fd = 1;
+    e.fd_coef = tab.d6_vt;
+    e.fd_add = (const Real *)g.f0;
+    tp2d(c, s, wk, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, fdw_k0, nz1, &e);
   }
 
   const bool heat_on = cf.d_con > 1.0e-5;

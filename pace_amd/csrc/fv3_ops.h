@@ -82,8 +82,12 @@ struct TpEpi {
   // area form with zfx / zfy (update_dz_d): fd != 0 = the del-n chain of q (order 2 on every level of the call, d2 of iteration 0 =
   // fd_coef[k] * q) runs INSIDE the march on the strips away from the W / E tile edges; zfx / zfy then only hold the tile-edge
   // strips and the cube-corner patches (del6_vt_flux_edge_strips).  See dsw_scalars_t (fv3_tp4.hip) for the pipeline.
+  // Wind form with wind_du / wind_dv: the same for the relative vorticity q, whose chain gives the damping increments (stored
+  // into wind_du / wind_dv for the damping-heat kernel); fd_add (2-D, optional) is added to q where the transport loads it
+  // (absolute vorticity = q + f0 without a field of its own).
   int fd = 0;
   const Real *fd_coef = nullptr;
+  const Real *fd_add = nullptr;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).

@@ -538,6 +538,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const bool area_form = epi && epi->area_form;
   const bool fd_on = (FEAT & TF_FD) && epi && epi->fd && !TS_LDS_ONLY;
   const Real *fd_coef = epi ? epi->fd_coef : nullptr;
+  const MPtr fd_add = (FEAT & TF_FD) && epi ? (MPtr)epi->fd_add : nullptr;  // 2-D term added to q where it is loaded (absolute = relative vorticity + f0)
   const MPtr d6u = g.del6_u, d6v = g.del6_v;
   const Real *zfx = epi ? epi->zfx : nullptr, *zfy = epi ? epi->zfy : nullptr, *zon = epi ? epi->zon : nullptr;
   Real *epi_out = epi ? epi->out : nullptr;
@@ -611,12 +612,16 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
     const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
+    const bool wdamp = C_WIND && wind_du != nullptr && wind_don[k] > (Real)1.0e-5;
     // FD: the del-n chain of q inside the march (strips away from the W / E tile edges); see dsw_scalars_t in fv3_tp4.hip
     constexpr bool C_FD = (FEAT & TF_FD) != 0;
-    const bool fdm = C_FD && fd_on && zdamp && !(W || E);
+    const bool fdm = C_FD && fd_on && (C_AREA ? zdamp : wdamp) && !(W || E);
     const Real dcoef = fdm ? fd_coef[k] : (Real)0;
     Real sd0[FV3_LPT], sd1[FV3_LPT], sd2[FV3_LPT], gx0[FV3_LPT], gx1[FV3_LPT], gy0[FV3_LPT], gy1[FV3_LPT], dxd[FV3_LPT], dxn[FV3_LPT], dyf[FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
     Real mdu_n[FV3_LPT], mdv_n[FV3_LPT], mra_n[FV3_LPT];
+    constexpr bool C_ADD = C_FD && C_WIND;  // q + fd_add formed where q is consumed (fd_add fetched one step ahead, like the chain's metric rows)
+    Real qa_n[FV3_LPT];
+    const MPtr addb = C_ADD && fd_add ? fd_add + m2 : nullptr;
     const MPtr d6ub = d6u + m2, d6vb = d6v + m2, rab = rarea + m2;
     const bool c_sw_ = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_se = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
     const bool c_ne = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_nw = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
@@ -629,7 +634,6 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real wu[FV3_LPT], wdx[FV3_LPT], wkf[FV3_LPT], wke[FV3_LPT], wv[FV3_LPT], wdy[FV3_LPT], wkr[FV3_LPT];  // wind epilogue inputs
     Real sqx[FV3_LPT], sqi[FV3_LPT], sxv[FV3_LPT], smb[FV3_LPT];  // strips away from the W / E tile edges: what the neighbouring lanes read (wavefront shuffles)
     Real wdu[FV3_LPT], wdv[FV3_LPT];  // vorticity-damping increments of u (face r-2) / v (row r-3)
-    const bool wdamp = C_WIND && wind_du != nullptr && wind_don[k] > (Real)1.0e-5;
     Row nxt[FV3_LPT], nx2[FV3_LPT], cur[FV3_LPT];
     Real a1[FV3_LPT], a2[FV3_LPT], a3[FV3_LPT];  // area of rows r-1, r-2, r-3 (a delay line instead of a second load of the metric)
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_q[FV3_LPT];  // q rows r-3..r, al(r-2)
@@ -675,6 +679,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       if (lane == 0) exf[FV3_WAVE] = exj[FV3_WAVE] = (Real)0;
       xjr[l] = ypp[l] = zx0[l] = zx1[l] = zy0[l] = zy1[l] = (Real)0;
       sd0[l] = sd1[l] = sd2[l] = gx0[l] = gx1[l] = gy0[l] = gy1[l] = dxd[l] = dxn[l] = dyf[l] = zyp[l] = zxo[l] = mdu_n[l] = mdv_n[l] = mra_n[l] = (Real)0;
+      qa_n[l] = (Real)0;
+      if constexpr (C_ADD) {
+        if (addb) qa_n[l] = addb[pcol[l] + (unsigned)((ja - 3) * sj32)];
+      }
       if constexpr (C_FD) {
         if (!(W || E))
           for (int v = 0; v < TS_NRING; ++v)
@@ -756,7 +764,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               wv[l] = (wind_v_ + b)[p3];
               wdy[l] = (gdy + m2)[p3];
               wkr[l] = (wind_ke_ + b)[p3];      // ke(i, jr)
-              if (wdamp) {
+              if (wdamp && !(C_FD && fdm)) {
                 wdu[l] = (wind_du_ + b)[pf];
                 wdv[l] = (wind_dv_ + b)[p3];
               }
@@ -770,12 +778,28 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             nxt[l] = load_row(rn, l, lane);
           }
           if (XE && lane < 8) emr[(r & 3) * 8 + lane] = cur[l].em;
-          Real qy = cur[l].qy, qx = qy;
+          const Real qraw = cur[l].qy;  // (the del-n chain runs on the field itself: no added term, no corner remap)
+          Real qy = qraw, qx = qy;
+          if constexpr (C_ADD) {
+            if (addb) {
+              qy = qx = qraw + qa_n[l];  // (row r's term, requested during the previous step)
+              cur[l].qy = qy;
+              const int r1 = r + 1 < r_end ? r + 1 : r_end;
+              qa_n[l] = addb[pcol[l] + (unsigned)(r1 * sj32)];
+            }
+          }
           if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
             const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
             const int rc = r < jed ? r : jed;  // (trailing steps of the unrolled march)
-            qy = cc<2>(qq, *gp, fl, ic, rc);
-            qx = cc<1>(qq, *gp, fl, ic, rc);
+            const unsigned iy = cc_index<2>(*gp, fl, ic, rc), ix = cc_index<1>(*gp, fl, ic, rc);
+            qy = qq[iy];
+            qx = qq[ix];
+            if constexpr (C_ADD) {
+              if (addb) {
+                qy = qy + addb[iy];
+                qx = qx + addb[ix];
+              }
+            }
             cur[l].qy = qy;
           }
           if constexpr (C_FD && !XE) {
@@ -783,7 +807,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               // ---- del-n chain, own-lane part: d2 of iteration s on row r-s, its y flux at face r-s (del6_stream phase A)
               const Real du0 = RG(RG_DU, r)[lane], du1 = RG(RG_DU, r - 1)[lane], du2 = RG(RG_DU, r - 2)[lane];
               const Real ra1 = RG(RG_RA, r - 1)[lane], ra2 = RG(RG_RA, r - 2)[lane];
-              const Real d0c = dcoef * cur[l].qy;
+              const Real d0c = dcoef * qraw;
               const Real fyc0 = du0 * (sd0[l] - d0c);
               const Real gxe0 = FV3_LANE_SHL(1, gx0, l, lane), gxe1 = FV3_LANE_SHL(1, gx1, l, lane);
               const Real d2c1 = (gx0[l] - gxe0 + gy0[l] - fyc0) * ra1;
@@ -853,13 +877,24 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               Real ox = dxd[l], oy = dyf[l];  // x flux of (i, r-3), y flux of face (i, r-2)
               if (pz) {
                 const int i = i0 - 3 + lane, jr_ = r - 3, jf_ = r - 2;
-                if (jr_ >= 1 && jr_ <= ny && on_patch(i, jr_)) ox = (zfx + b)[pcol[l] + (unsigned)(jr_ * sj32)];
-                if (i <= nx && on_patch(i, jf_)) oy = (zfy + b)[pcol[l] + (unsigned)(jf_ * sj32)];
+                const Real *pfx = C_AREA ? zfx : wind_dv_, *pfy = C_AREA ? zfy : wind_du_;  // the staged chain's fluxes on the patches
+                if (jr_ >= 1 && jr_ <= ny && on_patch(i, jr_)) ox = (pfx + b)[pcol[l] + (unsigned)(jr_ * sj32)];
+                if (i <= nx && on_patch(i, jf_)) oy = (pfy + b)[pcol[l] + (unsigned)(jf_ * sj32)];
               }
-              zx0[l] = ox;
-              zxo[l] = ox;
-              zy0[l] = zyp[l];
-              zy1[l] = oy;
+              if constexpr (C_AREA) {
+                zx0[l] = ox;
+                zxo[l] = ox;
+                zy0[l] = zyp[l];
+                zy1[l] = oy;
+              }
+              if constexpr (C_WIND) {
+                // the vorticity-damping increments of v (row r-3) / u (face r-2); the damping-heat kernel reads them again: stored
+                wdv[l] = ox;
+                wdu[l] = oy;
+                const int jr_ = r - 3, jf_ = r - 2;
+                if (jr_ >= ja && jr_ <= jb && jr_ <= ny && own_x[l]) (const_cast<Real *>(wind_dv_) + b)[pcol[l] + (unsigned)(jr_ * sj32)] = ox;
+                if (jf_ >= ja && jf_ <= jb && own_y[l]) (const_cast<Real *>(wind_du_) + b)[pcol[l] + (unsigned)(jf_ * sj32)] = oy;
+              }
               dxd[l] = dxn[l];
             }
           }
@@ -957,7 +992,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               if (area_form_) xje = FV3_LANE_SHL(1, xjr, l, lane);
             }
           }
-          if constexpr (C_FD && !XE) {
+          if constexpr (C_FD && C_AREA && !XE) {
             if (fdm) {
               zx1[l] = FV3_LANE_SHL(1, zxo, l, lane);
               zyp[l] = zy1[l];
@@ -1067,7 +1102,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     if (epi->area_form) m |= TF_AREA;
     if (epi->wind_u) m |= TF_WIND;
     if (epi->acc_x) m |= TF_ACC;
-    if (epi->fd && epi->area_form && epi->zfx) m |= TF_FD;
+    if (epi->fd && ((epi->area_form && epi->zfx) || (epi->wind_u && epi->wind_du))) m |= TF_FD;
   }
 #define TP_CASE(F)                                                                                          \
   case (F):                                                                                                 \
@@ -1083,6 +1118,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     TP_CASE(TF_WIND)                                              // d_sw: absolute vorticity + wind update
     TP_CASE(TF_EPI | TF_AREA)                                     // update_dz_d: interface heights
     TP_CASE(TF_EPI | TF_AREA | TF_FD)                             // update_dz_d: interface heights, their del-n chain inside the march
+    TP_CASE(TF_WIND | TF_FD)                                      // d_sw: vorticity (q + f0 formed on load) + wind update, the vorticity's del-n chain inside the march
     default:
       tp2d_stream_t<TF_ALL>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
   }

@@ -346,6 +346,23 @@ def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launc
             assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
+def test_vorticity_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
+    """d_sw's vorticity transport with the relative vorticity's del-n chain run inside the march and the absolute vorticity formed
+    on load (wk + f0; tp2d_stream_t TF_WIND | TF_FD) against the round-2 form (absolute-vorticity field + del6_stream launch,
+    FV3_DSW_VORT_DELN=arrays): bitwise equal states."""
+    nz = 4
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=1, k_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("fused", "arrays"):
+        monkeypatch.setenv("FV3_DSW_VORT_DELN", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout, n_split", [(24, (2, 2), 3), (12, (1, 1), 2)])
 def test_frame_first_passes_are_bitwise_neutral(backend, monkeypatch, n, layout, n_split):
     """fv3_acoustic_step with the operators that feed a halo update split into frame + interior passes (p_grad_c -> uc / vc;
