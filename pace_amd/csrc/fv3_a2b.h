@@ -127,8 +127,11 @@ FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int jj = j - 2 + n, ii = i - 2 + n;
-      qx[n] = A2B_B2 * (q[IX(i - 2, jj)] + q[IX(i + 1, jj)]) + A2B_B1 * (q[IX(i - 1, jj)] + q[IX(i, jj)]);
-      qy[n] = A2B_B2 * (q[IX(ii, j - 2)] + q[IX(ii, j + 1)]) + A2B_B1 * (q[IX(ii, j - 1)] + q[IX(ii, j)]);
+      // (every input value scaled first, as Q() and the marching kernel do: the interior branch used to ignore `scale`, which no
+      //  caller noticed -- the marching kernel serves the interior corners of the scaled field -- until fv3_pgf.hip evaluated
+      //  interior corners of g * zh per point)
+      qx[n] = A2B_B2 * (scale * q[IX(i - 2, jj)] + scale * q[IX(i + 1, jj)]) + A2B_B1 * (scale * q[IX(i - 1, jj)] + scale * q[IX(i, jj)]);
+      qy[n] = A2B_B2 * (scale * q[IX(ii, j - 2)] + scale * q[IX(ii, j + 1)]) + A2B_B1 * (scale * q[IX(ii, j - 1)] + scale * q[IX(ii, j)]);
     }
     const Real qxx = A2B_A2 * (qx[0] + qx[3]) + A2B_A1 * (qx[1] + qx[2]);
     const Real qyy = A2B_A2 * (qy[0] + qy[3]) + A2B_A1 * (qy[1] + qy[2]);

@@ -831,6 +831,15 @@ int fv3_nh_p_grad_scaled(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_, c
   // corner-interpolated pp / pk3 / gz / delp go to scratch: the reference interpolates pp, pk3 and gz in
   // place, but nothing reads them afterwards (gz and pk3 are rebuilt every sub-step), so the three
   // copy-back passes are not spent; the inputs come back unchanged.
+  // product form: the four corner interpolations and the wind update as one marching kernel (fv3_pgf.hip); FV3_NH_PGF=staged keeps
+  // the four a2b_ord4 launches + the level-walking update below (A/B reference)
+  {
+    const char *e = getenv("FV3_NH_PGF");  // (read per call: the A/B parity test flips it in one process)
+    if (!(e && !strcmp(e, "staged"))) {
+      nh_pgf_fused(c, s, pp, pk3, gz, delp, u, v, dt, top, (Real)gz_scale, c->frame_pass);
+      return fv3_post(c, s, "nh_p_grad");
+    }
+  }
   Real *ppb = c->scratch[SC_B], *pk3b = c->scratch[SC_C], *gzb = c->scratch[SC_D], *wk1 = c->scratch[SC_A];
   if (c->frame_pass != 2) {  // (interior pass of the frame-first form: the corner fields are in scratch already)
     launch2(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {

@@ -1,0 +1,251 @@
+// fv3_pgf.hip -- nh_p_grad as ONE marching kernel: the four corner interpolations (a2b_ord4 of pp, pk3, gz, delp) and the
+// pressure-gradient update of the D-grid winds fused, so that the corner fields never exist.
+// CPU twin: oracle/fv3_oracle/nh.py nh_p_grad.  [SURVEY A.10; reference operator NonHydrostaticPressureGradient,
+// `nh_p_grad.py`; a2b_ord4: fv3_a2b.h]
+//
+// The staged form (fv3_nh.hip: four a2b_ord4 launches into scratch + a level-walking wind update) moves 16 field passes
+// for 8 algorithmic ones: every corner field is written once and read back.  Here a wave owns a strip of 60 corner columns of
+// ONE level and walks j like the a2b march; per row it interpolates the seven (field, interface) pairs the level needs --
+// gz, pk3, pp at the upper and lower interface, delp -- from 4-row register windows (i-neighbours by wavefront shuffles),
+// keeps the corner values of the previous row, and updates u / v of that row in place.  The lower interface of level k is the
+// upper one of level k+1: both waves read it, the second read is served by L2 (level-major launch order).
+// Corners whose stencil (their own, their east or their north neighbour's) reaches a tile-edge formula -- and, in the
+// frame-first passes of the sequencer, the frame of every sub-domain -- are evaluated per point with a2b_point.
+// Same expressions in the same order as the staged form: bitwise equal (FV3_NH_PGF=staged is the A/B switch).
+#include "fv3_a2b.h"
+
+namespace {
+
+#define PG_OUT 60  // corners owned by a wave: 64 columns of the inputs, 2 + 1 of them halo, one more for the east neighbour's corner
+#define PG_PF 2
+#define PG_NF 7    // gz(k), gz(k+1), pk3(k), pk3(k+1), pp(k), pp(k+1), delp(k)
+
+struct PgfArgs {
+  const Real *pp, *pk3, *gz, *delp;
+  Real *u, *v;
+  Real dt, top, gz_scale;
+  int nz;
+};
+
+// the wind update at corner (i, j) of level k from the corner values of the seven pairs at p, pe = (i+1, j), pn = (i, j+1)
+// (x0: upper interface k, x1: lower interface k+1)
+struct PgfCorner {
+  Real g0, g1, k0, k1, q0, q1, w;
+};
+
+FV3_HD inline void pgf_update(const Geo &g, const PgfArgs &a, int t, int k, int i, int j, unsigned p, const PgfCorner &c, const PgfCorner &e, const PgfCorner &n, Real rx,
+                              Real ry) {
+  const long b = t * g.st + k * g.sk;
+  const Real wkp = c.k1 - c.k0;
+  if (i <= g.nx) {
+    const Real du = a.dt / (wkp + (e.k1 - e.k0)) * ((c.g1 - e.g0) * (e.k1 - c.k0) + (c.g0 - e.g1) * (c.k1 - e.k0));
+    (a.u + b)[p] = ((a.u + b)[p] + du + a.dt / (c.w + e.w) * ((c.g1 - e.g0) * (e.q1 - c.q0) + (c.g0 - e.g1) * (c.q1 - e.q0))) * rx;
+  }
+  if (j <= g.ny) {
+    const Real dv = a.dt / (wkp + (n.k1 - n.k0)) * ((c.g1 - n.g0) * (n.k1 - c.k0) + (c.g0 - n.g1) * (c.k1 - n.k0));
+    (a.v + b)[p] = ((a.v + b)[p] + dv + a.dt / (c.w + n.w) * ((c.g1 - n.g0) * (n.q1 - c.q0) + (c.g0 - n.g1) * (c.q1 - n.q0))) * ry;
+  }
+}
+
+// all seven corner values at one corner, any position (tile-edge formulas included)
+FV3_HD inline PgfCorner pgf_corner_point(const Geo &g, const PgfArgs &a, int t, int k, int i, int j) {
+  const long b = t * g.st + k * g.sk;
+  PgfCorner c;
+  c.g0 = a2b_point(g, a.gz + b, t, i, j, a.gz_scale);
+  c.g1 = a2b_point(g, a.gz + b + g.sk, t, i, j, a.gz_scale);
+  c.k0 = k == 0 ? a.top : a2b_point(g, a.pk3 + b, t, i, j);
+  c.k1 = a2b_point(g, a.pk3 + b + g.sk, t, i, j);
+  c.q0 = k == 0 ? (Real)0 : a2b_point(g, a.pp + b, t, i, j);
+  c.q1 = a2b_point(g, a.pp + b + g.sk, t, i, j);
+  c.w = a2b_point(g, a.delp + b, t, i, j);
+  return c;
+}
+
+// corners the march serves in sub-domain flags fl: its own, its east and its north neighbour's stencils are interior
+FV3_HD inline void pgf_march_range(const Geo &g, int fl, int &ia, int &ib, int &ja, int &jb) {
+  ia = (fl & FV3_W) ? 3 : 1;
+  ib = (fl & FV3_E) ? g.npx - 3 : g.nx + 1;
+  ja = (fl & FV3_S) ? 3 : 1;
+  jb = (fl & FV3_N) ? g.npy - 3 : g.ny + 1;
+}
+
+}  // namespace
+
+// pass (the sequencer's frame-first passes): 0 = every corner; 1 = the frame of every sub-domain only (FV3_FRAME_W wide, per point);
+// 2 = the rest
+void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, const Real *gz, const Real *delp, Real *u, Real *v, Real dt, Real top, Real gz_scale,
+                  int pass) {
+  const Geo g = c->g;
+  const PgfArgs a{pp, pk3, gz, delp, u, v, dt, top, gz_scale, g.nz};
+  const int nz = g.nz;
+  const int F = FV3_FRAME_W;
+  const bool has_frame = (g.nx + 1 > 2 * F) && (g.ny + 1 > 2 * F);  // (launch3_pass: smaller boxes are all frame)
+  auto in_frame = [=] FV3_HD(int i, int j) -> bool { return !has_frame || i <= F || i > g.nx + 1 - F || j <= F || j > g.ny + 1 - F; };
+  // ---- per-point part: the corners next to the tile edges (always), the sub-domain frames (pass 1) ----
+  {
+    const MPtr rdx = g.rdx, rdy = g.rdy;
+    auto point = [=] FV3_HD(int t, int k, int i, int j) {
+      const int fl = g.flags[t];
+      int ia, ib, ja, jb;
+      pgf_march_range(g, fl, ia, ib, ja, jb);
+      const bool marchable = i >= ia && i <= ib && j >= ja && j <= jb;
+      const bool fr = in_frame(i, j);
+      // who serves this corner: pass 0: the march where it can, this kernel elsewhere; pass 1: this kernel on the frame; pass 2:
+      // the march off the frame where it can, this kernel off the frame elsewhere
+      const bool mine = pass == 0 ? !marchable : pass == 1 ? fr : (!fr && !marchable);
+      if (!mine) return;
+      const PgfCorner cc = pgf_corner_point(g, a, t, k, i, j);
+      PgfCorner ce = cc, cn = cc;
+      if (i <= g.nx) ce = pgf_corner_point(g, a, t, k, i + 1, j);
+      if (j <= g.ny) cn = pgf_corner_point(g, a, t, k, i, j + 1);
+      const unsigned p = IX(i, j);
+      pgf_update(g, a, t, k, i, j, p, cc, ce, cn, (rdx + t * g.st2)[p], (rdy + t * g.st2)[p]);
+    };
+    if (pass == 1) {
+      launch3_pass(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, 1, point);
+      return;
+    }
+    if (pass == 0) {
+      // The corners the march leaves out lie in four thin bands: columns 1, 2 / npx-2 .. npx (all rows) and rows 1, 2 /
+      // npy-2 .. npy (the columns between).  A sub-domain without the tile edge a band belongs to finds its points marchable and
+      // returns; the column bands also pick up the S / N rows' first and last columns.  (Pass 2: those corners all lie on the
+      // sub-domain frame, which pass 1 has done.)
+      launch3(c, s, Box{1, 2, 1, g.ny + 1, 0, nz - 1}, point);
+      launch3(c, s, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, nz - 1}, point);
+      launch3(c, s, Box{3, g.npx - 3, 1, 2, 0, nz - 1}, point);
+      launch3(c, s, Box{3, g.npx - 3, g.npy - 2, g.npy, 0, nz - 1}, point);
+    }
+  }
+  // ---- marching part ----
+  const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const Geo *gp = c->g_dev;
+  const int nstrip = (nx + 1 + PG_OUT - 1) / PG_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((ny + 64) / 64) * g.nsub * nz, 2);
+  int nseg = (ny + 1 + seg / 2) / seg;
+  if (nseg < 1) nseg = 1;
+  const int seglen = (ny + 1 + nseg - 1) / nseg;
+  const MPtr rdx = g.rdx, rdy = g.rdy;
+  launch_waves<2>(c, s, nstrip, nseg, g.nsub * nz, 0, [=] FV3_HD(const Blk &blk, char *) {
+    const int t = blk.bz / nz, k = blk.bz - t * nz;
+    const int fl = gp->flags[t];
+    const long b = t * st + k * sk, m2 = t * st2;
+    int ia, ib, ja, jb;
+    pgf_march_range(*gp, fl, ia, ib, ja, jb);
+    const int i0 = 1 + blk.bx * PG_OUT;
+    int j0 = 1 + blk.by * seglen, j1 = j0 + seglen - 1;
+    if (j0 < ja) j0 = ja;
+    if (j1 > jb) j1 = jb;
+    if (j0 > j1) return;
+    const int ilo = i0 > ia ? i0 : ia, ihi = i0 + PG_OUT - 1 < ib ? i0 + PG_OUT - 1 : ib;
+    if (ilo > ihi) return;
+    const int ied = nx + nh, jed = ny + nh;
+    // the seven inputs: level bases and scales; pk3 / pp of interface 0 are constants (top, 0)
+    const Real *src[PG_NF] = {a.gz + b, a.gz + b + sk, a.pk3 + b, a.pk3 + b + sk, a.pp + b, a.pp + b + sk, a.delp + b};
+    const bool top_level = k == 0;
+    Real qa[PG_NF][FV3_LPT], qb[PG_NF][FV3_LPT], qc[PG_NF][FV3_LPT], qd[PG_NF][FV3_LPT];  // input rows r-3 .. r
+    Real x0[PG_NF][FV3_LPT], x1[PG_NF][FV3_LPT], x2[PG_NF][FV3_LPT], x3[PG_NF][FV3_LPT];  // x-interpolated rows r-3 .. r
+    Real pf[PG_PF][PG_NF][FV3_LPT];
+    Real sy[PG_NF][FV3_LPT];   // the y-interpolated corner row (read by the neighbouring lanes, like the new input row qd)
+    Real cp[PG_NF][FV3_LPT], cc[PG_NF][FV3_LPT];   // corner values of rows r-2 (previous step) and r-1 (this step)
+    Real o_u[FV3_LPT], o_v[FV3_LPT], o_rx[FV3_LPT], o_ry[FV3_LPT];
+    unsigned pcol[FV3_LPT];
+    bool own[FV3_LPT];
+    const int r_beg = j0 - 2, r_end = j1 + 2 < jed ? j1 + 2 : jed;
+    auto ld = [&](int f, int r, int l) -> Real {
+      if (top_level && (f == 2 || f == 4)) return (Real)0;  // (never used: the constants replace the corner values)
+      return src[f][pcol[l] + (unsigned)(r * sj32)];
+    };
+    FV3_LANES(blk, lane, l) {
+      const int i = i0 - 2 + lane, ic = i < ied ? i : ied;
+      pcol[l] = (unsigned)(go * sj32 + ic + go);
+      own[l] = i >= ilo && i <= ihi;
+      o_u[l] = o_v[l] = o_rx[l] = o_ry[l] = (Real)0;
+#pragma unroll
+      for (int f = 0; f < PG_NF; ++f) {
+        qa[f][l] = qb[f][l] = qc[f][l] = qd[f][l] = x0[f][l] = x1[f][l] = x2[f][l] = x3[f][l] = sy[f][l] = cp[f][l] = cc[f][l] = (Real)0;
+#pragma unroll
+        for (int n = 0; n < PG_PF; ++n) pf[n][f][l] = ld(f, r_beg + n < r_end ? r_beg + n : r_end, l);
+      }
+    }
+    for (int r = r_beg; r <= r_end; ++r) {
+      const int rn = r + PG_PF < r_end ? r + PG_PF : r_end;
+      const int jw = r - 2;  // row whose winds this step updates
+      const bool row_ok = jw >= j0 && jw <= j1;
+      // ---- phase A: new input row into the windows, y-interpolated corner row r-1
+      FV3_LANES(blk, lane, l) {
+        if (row_ok) {  // (the winds of row r-2 and their metric terms: consumed in phase C)
+          const unsigned p = pcol[l] + (unsigned)(jw * sj32);
+          o_u[l] = (a.u + b)[p];
+          o_v[l] = (a.v + b)[p];
+          o_rx[l] = (rdx + m2)[p];
+          o_ry[l] = (rdy + m2)[p];
+        }
+#pragma unroll
+        for (int f = 0; f < PG_NF; ++f) {
+          const Real sc = f < 2 ? a.gz_scale : (Real)1;
+          const Real qn = f < 2 ? sc * pf[0][f][l] : pf[0][f][l];
+#pragma unroll
+          for (int n = 0; n + 1 < PG_PF; ++n) pf[n][f][l] = pf[n + 1][f][l];
+          pf[PG_PF - 1][f][l] = ld(f, rn, l);
+          qa[f][l] = qb[f][l];
+          qb[f][l] = qc[f][l];
+          qc[f][l] = qd[f][l];
+          qd[f][l] = qn;
+          sy[f][l] = A2B_B2 * (qa[f][l] + qd[f][l]) + A2B_B1 * (qb[f][l] + qc[f][l]);  // corner row r-1
+        }
+      }
+      // ---- phase B: x-interpolated row r, corner values of row r-1
+      FV3_LANES(blk, lane, l) {
+#pragma unroll
+        for (int f = 0; f < PG_NF; ++f) {
+          const Real qm2 = FV3_LANE_SHR(2, qd[f], l, lane), qm1 = FV3_LANE_SHR(1, qd[f], l, lane), qp1 = FV3_LANE_SHL(1, qd[f], l, lane);
+          const Real ym2 = FV3_LANE_SHR(2, sy[f], l, lane), ym1 = FV3_LANE_SHR(1, sy[f], l, lane), yp1 = FV3_LANE_SHL(1, sy[f], l, lane);
+          x0[f][l] = x1[f][l];
+          x1[f][l] = x2[f][l];
+          x2[f][l] = x3[f][l];
+          x3[f][l] = A2B_B2 * (qm2 + qp1) + A2B_B1 * (qm1 + qd[f][l]);
+          const Real qxx = A2B_A2 * (x0[f][l] + x3[f][l]) + A2B_A1 * (x1[f][l] + x2[f][l]);
+          const Real qyy = A2B_A2 * (ym2 + yp1) + A2B_A1 * (ym1 + sy[f][l]);
+          cp[f][l] = cc[f][l];
+          cc[f][l] = (Real)0.5 * (qxx + qyy);
+        }
+        if (top_level) {  // interface 0: pk3 = ptop^kappa, pp = 0 on every corner
+          cp[2][l] = cc[2][l] = a.top;
+          cp[4][l] = cc[4][l] = (Real)0;
+        }
+      }
+      // ---- phase C: the winds of row r-2 (corner values of that row: cp; of its north neighbour: cc; of its east neighbour: lane + 1's cp)
+      FV3_LANES(blk, lane, l) {
+        PgfCorner pc, pe_, pn;
+        pc.g0 = cp[0][l]; pc.g1 = cp[1][l]; pc.k0 = cp[2][l]; pc.k1 = cp[3][l]; pc.q0 = cp[4][l]; pc.q1 = cp[5][l]; pc.w = cp[6][l];
+        pn.g0 = cc[0][l]; pn.g1 = cc[1][l]; pn.k0 = cc[2][l]; pn.k1 = cc[3][l]; pn.q0 = cc[4][l]; pn.q1 = cc[5][l]; pn.w = cc[6][l];
+        pe_.g0 = FV3_LANE_SHL(1, cp[0], l, lane);
+        pe_.g1 = FV3_LANE_SHL(1, cp[1], l, lane);
+        pe_.k0 = FV3_LANE_SHL(1, cp[2], l, lane);
+        pe_.k1 = FV3_LANE_SHL(1, cp[3], l, lane);
+        pe_.q0 = FV3_LANE_SHL(1, cp[4], l, lane);
+        pe_.q1 = FV3_LANE_SHL(1, cp[5], l, lane);
+        pe_.w = FV3_LANE_SHL(1, cp[6], l, lane);
+        const int i = i0 - 2 + lane;
+        bool mine = row_ok && own[l];
+        if (pass == 2 && mine) {  // the sub-domain frame was done per point in pass 1
+          const bool fr = !has_frame || i <= F || i > nx + 1 - F || jw <= F || jw > ny + 1 - F;
+          mine = !fr;
+        }
+        if (mine) {
+          const unsigned p = pcol[l] + (unsigned)(jw * sj32);
+          const Real wkp = pc.k1 - pc.k0;
+          if (i <= nx) {
+            const Real du = a.dt / (wkp + (pe_.k1 - pe_.k0)) * ((pc.g1 - pe_.g0) * (pe_.k1 - pc.k0) + (pc.g0 - pe_.g1) * (pc.k1 - pe_.k0));
+            (a.u + b)[p] = (o_u[l] + du + a.dt / (pc.w + pe_.w) * ((pc.g1 - pe_.g0) * (pe_.q1 - pc.q0) + (pc.g0 - pe_.g1) * (pc.q1 - pe_.q0))) * o_rx[l];
+          }
+          if (jw <= ny) {
+            const Real dv = a.dt / (wkp + (pn.k1 - pn.k0)) * ((pc.g1 - pn.g0) * (pn.k1 - pc.k0) + (pc.g0 - pn.g1) * (pc.k1 - pn.k0));
+            (a.v + b)[p] = (o_v[l] + dv + a.dt / (pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
+          }
+        }
+      }
+    }
+  });
+}

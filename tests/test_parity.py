@@ -363,6 +363,25 @@ def test_vorticity_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_la
             assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2)), (12, (1, 1))])
+def test_fused_nh_p_grad_is_bitwise_the_staged_form(backend, monkeypatch, n, layout):
+    """nh_p_grad as one marching kernel (fv3_pgf.hip: the four corner interpolations + the wind update, corner fields never
+    stored; per-point evaluation next to the tile edges) against the staged form (four a2b_ord4 launches + the level-walking
+    update, FV3_NH_PGF=staged) -- also split into the sequencer's frame-first passes: bitwise equal states."""
+    nz = 4
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2, k_split=1))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode, pgf, ff in (("fused", "fused", "0"), ("fused, frame-first", "fused", "1"), ("staged", "staged", "0")):
+        monkeypatch.setenv("FV3_NH_PGF", pgf)
+        monkeypatch.setenv("FV3_FRAME_FIRST", ff)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for mode in ("fused", "fused, frame-first"):
+        for r in range(part.total_ranks):
+            for name in STATE:
+                assert np.array_equal(res[mode][r][name], res["staged"][r][name]), f"{name} rank {r} ({mode})"
+
+
 @pytest.mark.parametrize("n, layout, n_split", [(24, (2, 2), 3), (12, (1, 1), 2)])
 def test_frame_first_passes_are_bitwise_neutral(backend, monkeypatch, n, layout, n_split):
     """fv3_acoustic_step with the operators that feed a halo update split into frame + interior passes (p_grad_c -> uc / vc;
