@@ -20,7 +20,7 @@
 namespace {
 
 struct A2B {
-  Geo g;
+  const Geo &g;     // (a reference: a by-value copy of the geometry block can end up in scratch memory -- 672 bytes per lane in fv3_pgf.hip's frame kernels)
   const Real *q;    // level base of qin for this (t, k)
   MPtr dxa;  // metric planes for this t
   MPtr dya;
@@ -104,18 +104,11 @@ struct A2B {
 FV3_HD inline Real extrap(Real fac, Real q1, Real q2) { return q1 + fac * (q1 - q2); }
 
 // one output corner, any position: tile-edge formulas included
-FV3_HD inline Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j, Real scale = (Real)1) {
+// (always inlined: called out of line, the geometry block of the kernel's closure has to be addressable and is copied to scratch
+//  memory first -- 672 bytes per lane, 3 waves per SIMD, 4 x the time in fv3_pgf.hip's frame kernels)
+FV3_HD inline __attribute__((always_inline)) Real a2b_point(const Geo &g, const Real *qlev, int t, int i, int j, Real scale = (Real)1) {
   const int fl = g.flags[t];
-  A2B a;
-  a.g = g;
-  a.q = qlev;
-  a.sc = scale;
-  a.dxa = g.dxa + t * g.st2;
-  a.dya = g.dya + t * g.st2;
-  a.W = fl & FV3_W;
-  a.E = fl & FV3_E;
-  a.S = fl & FV3_S;
-  a.N = fl & FV3_N;
+  const A2B a{g, qlev, g.dxa + t * g.st2, g.dya + t * g.st2, (fl & FV3_W) != 0, (fl & FV3_E) != 0, (fl & FV3_S) != 0, (fl & FV3_N) != 0, scale};
   const int npx = g.npx, npy = g.npy;
   const bool onW = a.W && i == 1, onE = a.E && i == npx, onS = a.S && j == 1, onN = a.N && j == npy;
   const Real *ce = g.corner_extrap + t * 12;

@@ -19,6 +19,9 @@ namespace {
 #define PG_OUT 60  // corners owned by a wave: 64 columns of the inputs, 2 + 1 of them halo, one more for the east neighbour's corner
 #define PG_PF 2
 #define PG_NF 7    // gz(k), gz(k+1), pk3(k), pk3(k+1), pp(k), pp(k+1), delp(k)
+#ifndef PG_KB
+#define PG_KB 16   // levels of one tile that are consecutive workgroups of an XCD
+#endif
 
 struct PgfArgs {
   const Real *pp, *pk3, *gz, *delp;
@@ -47,20 +50,6 @@ FV3_HD inline void pgf_update(const Geo &g, const PgfArgs &a, int t, int k, int 
   }
 }
 
-// all seven corner values at one corner, any position (tile-edge formulas included)
-FV3_HD inline PgfCorner pgf_corner_point(const Geo &g, const PgfArgs &a, int t, int k, int i, int j) {
-  const long b = t * g.st + k * g.sk;
-  PgfCorner c;
-  c.g0 = a2b_point(g, a.gz + b, t, i, j, a.gz_scale);
-  c.g1 = a2b_point(g, a.gz + b + g.sk, t, i, j, a.gz_scale);
-  c.k0 = k == 0 ? a.top : a2b_point(g, a.pk3 + b, t, i, j);
-  c.k1 = a2b_point(g, a.pk3 + b + g.sk, t, i, j);
-  c.q0 = k == 0 ? (Real)0 : a2b_point(g, a.pp + b, t, i, j);
-  c.q1 = a2b_point(g, a.pp + b + g.sk, t, i, j);
-  c.w = a2b_point(g, a.delp + b, t, i, j);
-  return c;
-}
-
 // corners the march serves in sub-domain flags fl: its own, its east and its north neighbour's stencils are interior
 FV3_HD inline void pgf_march_range(const Geo &g, int fl, int &ia, int &ib, int &ja, int &jb) {
   ia = (fl & FV3_W) ? 3 : 1;
@@ -80,41 +69,80 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
   const int nz = g.nz;
   const int F = FV3_FRAME_W;
   const bool has_frame = (g.nx + 1 > 2 * F) && (g.ny + 1 > 2 * F);  // (launch3_pass: smaller boxes are all frame)
-  auto in_frame = [=] FV3_HD(int i, int j) -> bool { return !has_frame || i <= F || i > g.nx + 1 - F || j <= F || j > g.ny + 1 - F; };
-  // ---- per-point part: the corners next to the tile edges (always), the sub-domain frames (pass 1) ----
-  {
-    const MPtr rdx = g.rdx, rdy = g.rdy;
-    auto point = [=] FV3_HD(int t, int k, int i, int j) {
-      const int fl = g.flags[t];
-      int ia, ib, ja, jb;
-      pgf_march_range(g, fl, ia, ib, ja, jb);
-      const bool marchable = i >= ia && i <= ib && j >= ja && j <= jb;
-      const bool fr = in_frame(i, j);
-      // who serves this corner: pass 0: the march where it can, this kernel elsewhere; pass 1: this kernel on the frame; pass 2:
-      // the march off the frame where it can, this kernel off the frame elsewhere
-      const bool mine = pass == 0 ? !marchable : pass == 1 ? fr : (!fr && !marchable);
-      if (!mine) return;
-      const PgfCorner cc = pgf_corner_point(g, a, t, k, i, j);
-      PgfCorner ce = cc, cn = cc;
-      if (i <= g.nx) ce = pgf_corner_point(g, a, t, k, i + 1, j);
-      if (j <= g.ny) cn = pgf_corner_point(g, a, t, k, i, j + 1);
-      const unsigned p = IX(i, j);
-      pgf_update(g, a, t, k, i, j, p, cc, ce, cn, (rdx + t * g.st2)[p], (rdy + t * g.st2)[p]);
+  // ---- per-point part: the corners next to the tile edges (pass 0), the sub-domain frames (pass 1) ----
+  // Staged on thin bands: the corner values of the four fields on the bands into scratch, one a2b_point per corner and field
+  // level, then the wind update from there.
+  const MPtr rdx = g.rdx, rdy = g.rdy;
+  Real *ppb = c->scratch[SC_B], *pk3b = c->scratch[SC_C], *gzb = c->scratch[SC_D], *wk1 = c->scratch[SC_A];
+  const int nxp = g.nx + 1, nyp = g.ny + 1;
+  auto corner_at = [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk;
+    const unsigned p = IX(i, j);
+    (gzb + b)[p] = a2b_point(g, a.gz + b, t, i, j, a.gz_scale);
+    (pk3b + b)[p] = k == 0 ? a.top : a2b_point(g, a.pk3 + b, t, i, j);
+    (ppb + b)[p] = k == 0 ? (Real)0 : a2b_point(g, a.pp + b, t, i, j);
+    if (k < nz) (wk1 + b)[p] = a2b_point(g, a.delp + b, t, i, j);
+  };
+  auto winds_at = [=] FV3_HD(int t, int k, int i, int j) {
+    const long b = t * g.st + k * g.sk, b1 = b + g.sk;
+    const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
+    const PgfCorner cc{(gzb + b)[p], (gzb + b1)[p], (pk3b + b)[p], (pk3b + b1)[p], (ppb + b)[p], (ppb + b1)[p], (wk1 + b)[p]};
+    PgfCorner ce = cc, cn = cc;
+    if (i <= g.nx) ce = PgfCorner{(gzb + b)[pe_], (gzb + b1)[pe_], (pk3b + b)[pe_], (pk3b + b1)[pe_], (ppb + b)[pe_], (ppb + b1)[pe_], (wk1 + b)[pe_]};
+    if (j <= g.ny) cn = PgfCorner{(gzb + b)[pn], (gzb + b1)[pn], (pk3b + b)[pn], (pk3b + b1)[pn], (ppb + b)[pn], (ppb + b1)[pn], (wk1 + b)[pn]};
+    pgf_update(g, a, t, k, i, j, p, cc, ce, cn, (rdx + t * g.st2)[p], (rdy + t * g.st2)[p]);
+  };
+  if (pass == 1) {
+    // the FV3_FRAME_W-wide frame of every sub-domain, whatever its tile edges: corners on the frame + one column / row, then the winds
+    Frame windsF, cornersF;
+    if (!has_frame) {
+      windsF = Frame{{Box{1, 0, 1, 0, 0, nz - 1}, Box{1, 0, 1, 0, 0, nz - 1}, Box{1, nxp, 1, nyp, 0, nz - 1}, Box{1, 0, 1, 0, 0, nz - 1}}};
+      cornersF = Frame{{Box{1, 0, 1, 0, 0, nz}, Box{1, 0, 1, 0, 0, nz}, Box{1, nxp, 1, nyp, 0, nz}, Box{1, 0, 1, 0, 0, nz}}};
+    } else {
+      windsF = Frame{{Box{1, F, 1, nyp, 0, nz - 1}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz - 1}, Box{F + 1, nxp - F, 1, F, 0, nz - 1}, Box{F + 1, nxp - F, nyp - F + 1, nyp, 0, nz - 1}}};
+      cornersF = Frame{{Box{1, F + 1, 1, nyp, 0, nz}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz}, Box{F + 2, nxp - F, 1, F + 1, 0, nz}, Box{F + 2, nxp - F, nyp - F + 1, nyp, 0, nz}}};
+    }
+    launch_frame(c, s, cornersF, corner_at);
+    launch_frame(c, s, windsF, winds_at);
+    return;
+  }
+  if (pass == 0) {
+    // Tile-edge frame corners (two columns / rows per side that has a tile edge -- the geometry of a2b_ord4_t's frame launch, lanes
+    // along the edge).  The third corner column / row the band winds need has the interior formula: the march exports it.
+    const int nfr = nxp > nyp ? nxp : nyp;
+    // (one launch per field, one a2b_point per thread: four fields in one thread made a 3 ms kernel of what is 4 x 0.23 ms)
+    auto sides = [=](const Real *qin, Real *out, int k0, int k1, Real scale) {
+      launch3(c, s, Box{1, nfr, 1, 8, k0, k1}, [=] FV3_HD(int t, int k, int a_, int side) {
+        const int fl = g.flags[t];
+        int i, j;
+        // side 1,2: columns 1,2 (W)   3,4: columns npx-1, npx (E)   5,6: rows 1,2 (S)   7,8: rows npy-1, npy (N)
+        if (side <= 4) {
+          if (a_ > nyp) return;
+          if (!(fl & (side <= 2 ? FV3_W : FV3_E))) return;
+          i = side <= 2 ? side : g.npx - 4 + side;
+          j = a_;
+        } else {
+          if (a_ > nxp) return;
+          if (!(fl & (side <= 6 ? FV3_S : FV3_N))) return;
+          j = side <= 6 ? side - 4 : g.npy - 8 + side;
+          i = a_;
+          if (((fl & FV3_W) && i <= 2) || ((fl & FV3_E) && i >= g.npx - 1)) return;  // covered by the column sides
+        }
+        const long b = t * g.st + k * g.sk;
+        (out + b)[IX(i, j)] = a2b_point(g, qin + b, t, i, j, scale);
+      });
     };
-    if (pass == 1) {
-      launch3_pass(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz - 1}, 1, point);
-      return;
-    }
-    if (pass == 0) {
-      // The corners the march leaves out lie in four thin bands: columns 1, 2 / npx-2 .. npx (all rows) and rows 1, 2 /
-      // npy-2 .. npy (the columns between).  A sub-domain without the tile edge a band belongs to finds its points marchable and
-      // returns; the column bands also pick up the S / N rows' first and last columns.  (Pass 2: those corners all lie on the
-      // sub-domain frame, which pass 1 has done.)
-      launch3(c, s, Box{1, 2, 1, g.ny + 1, 0, nz - 1}, point);
-      launch3(c, s, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, nz - 1}, point);
-      launch3(c, s, Box{3, g.npx - 3, 1, 2, 0, nz - 1}, point);
-      launch3(c, s, Box{3, g.npx - 3, g.npy - 2, g.npy, 0, nz - 1}, point);
-    }
+    sides(a.gz, gzb, 0, nz, a.gz_scale);
+    sides(a.pk3, pk3b, 1, nz, (Real)1);
+    sides(a.pp, ppb, 1, nz, (Real)1);
+    sides(a.delp, wk1, 0, nz - 1, (Real)1);
+    // interface 0 of pk3 / pp: constants on every corner the band winds read (bands incl. their neighbour column / row)
+    launch_frame(c, s, Frame{{Box{1, 3, 1, nyp, 0, 0}, Box{g.npx - 2, g.npx, 1, nyp, 0, 0}, Box{4, g.npx - 3, 1, 3, 0, 0}, Box{4, g.npx - 3, g.npy - 2, g.npy, 0, 0}}},
+                 [=] FV3_HD(int t, int, int i, int j) {
+      const long p = t * g.st + IX(i, j);
+      pk3b[p] = a.top;
+      ppb[p] = (Real)0;
+    });
   }
   // ---- marching part ----
   const int nx = g.nx, ny = g.ny, nh = g.nh, sj32 = g.sj32, go = g.o;
@@ -125,9 +153,16 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
   int nseg = (ny + 1 + seg / 2) / seg;
   if (nseg < 1) nseg = 1;
   const int seglen = (ny + 1 + nseg - 1) / nseg;
-  const MPtr rdx = g.rdx, rdy = g.rdy;
-  launch_waves<2>(c, s, nstrip, nseg, g.nsub * nz, 0, [=] FV3_HD(const Blk &blk, char *) {
-    const int t = blk.bz / nz, k = blk.bz - t * nz;
+  // Level-major launch geometry: the workgroups an XCD walks are the levels of ONE (strip, segment) tile (PG_KB of them), then the
+  // next tile -- the lower interface of level k is the upper one of level k+1, and adjacent levels resident together on an XCD read
+  // it from its L2 (plane-major, consecutive levels land on different XCDs and every interface comes from HBM twice).
+  const int nblk = (nz + PG_KB - 1) / PG_KB;
+  launch_waves<2>(c, s, PG_KB, nstrip * nseg, g.nsub * nblk, 0, [=] FV3_HD(const Blk &blk_, char *) {
+    const int t = blk_.bz / nblk, k = (blk_.bz - t * nblk) * PG_KB + blk_.bx;
+    if (k >= nz) return;
+    Blk blk = blk_;
+    blk.by = blk_.by / nstrip;
+    blk.bx = blk_.by - blk.by * nstrip;
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     int ia, ib, ja, jb;
@@ -143,12 +178,15 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
     // the seven inputs: level bases and scales; pk3 / pp of interface 0 are constants (top, 0)
     const Real *src[PG_NF] = {a.gz + b, a.gz + b + sk, a.pk3 + b, a.pk3 + b + sk, a.pp + b, a.pp + b + sk, a.delp + b};
     const bool top_level = k == 0;
-    Real qa[PG_NF][FV3_LPT], qb[PG_NF][FV3_LPT], qc[PG_NF][FV3_LPT], qd[PG_NF][FV3_LPT];  // input rows r-3 .. r
-    Real x0[PG_NF][FV3_LPT], x1[PG_NF][FV3_LPT], x2[PG_NF][FV3_LPT], x3[PG_NF][FV3_LPT];  // x-interpolated rows r-3 .. r
-    Real pf[PG_PF][PG_NF][FV3_LPT];
+    Real qb[PG_NF][FV3_LPT], qc[PG_NF][FV3_LPT], qd[PG_NF][FV3_LPT];  // input rows r-2 .. r (r-3 .. r-1 before a step's shift)
+    Real x1[PG_NF][FV3_LPT], x2[PG_NF][FV3_LPT], x3[PG_NF][FV3_LPT];  // x-interpolated rows r-2 .. r (likewise)
+    // Input rows r .. r+2 in three register sets that rotate by the step's STATIC index (the march is unrolled by three): a rolled
+    // rotation is a register copy of a load still in flight, i.e. a full memory latency per step at two waves per SIMD
+    // (measured: 2.2 us per step, 6.1 ms for the launch).  The winds / metric terms of a row are requested one step early likewise.
+    Real pf[3][PG_NF][FV3_LPT];
     Real sy[PG_NF][FV3_LPT];   // the y-interpolated corner row (read by the neighbouring lanes, like the new input row qd)
     Real cp[PG_NF][FV3_LPT], cc[PG_NF][FV3_LPT];   // corner values of rows r-2 (previous step) and r-1 (this step)
-    Real o_u[FV3_LPT], o_v[FV3_LPT], o_rx[FV3_LPT], o_ry[FV3_LPT];
+    Real o_u[FV3_LPT], o_v[FV3_LPT], o_rx[FV3_LPT], o_ry[FV3_LPT];  // winds / metric terms of the row the NEXT step updates (requested at the end of a step)
     unsigned pcol[FV3_LPT];
     bool own[FV3_LPT];
     const int r_beg = j0 - 2, r_end = j1 + 2 < jed ? j1 + 2 : jed;
@@ -163,36 +201,30 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
       o_u[l] = o_v[l] = o_rx[l] = o_ry[l] = (Real)0;
 #pragma unroll
       for (int f = 0; f < PG_NF; ++f) {
-        qa[f][l] = qb[f][l] = qc[f][l] = qd[f][l] = x0[f][l] = x1[f][l] = x2[f][l] = x3[f][l] = sy[f][l] = cp[f][l] = cc[f][l] = (Real)0;
+        qb[f][l] = qc[f][l] = qd[f][l] = x1[f][l] = x2[f][l] = x3[f][l] = sy[f][l] = cp[f][l] = cc[f][l] = (Real)0;
 #pragma unroll
-        for (int n = 0; n < PG_PF; ++n) pf[n][f][l] = ld(f, r_beg + n < r_end ? r_beg + n : r_end, l);
+        for (int n = 0; n < 3; ++n) pf[n][f][l] = ld(f, r_beg + n < r_end ? r_beg + n : r_end, l);
       }
     }
-    for (int r = r_beg; r <= r_end; ++r) {
-      const int rn = r + PG_PF < r_end ? r + PG_PF : r_end;
+    // step r with Q = (r - r_beg) mod 3: consumes register set Q (row r), refills it with row r+3; the winds of row r-2 were
+    // requested at the end of the previous step, those of row r-1 are requested at the end of this one
+    auto step = [&](int r, auto q_tag) {
+      constexpr int Q = decltype(q_tag)::value;
+      const int rn = r + 3 < r_end ? r + 3 : r_end;
       const int jw = r - 2;  // row whose winds this step updates
       const bool row_ok = jw >= j0 && jw <= j1;
+      const bool next_ok = jw + 1 >= j0 && jw + 1 <= j1;
       // ---- phase A: new input row into the windows, y-interpolated corner row r-1
       FV3_LANES(blk, lane, l) {
-        if (row_ok) {  // (the winds of row r-2 and their metric terms: consumed in phase C)
-          const unsigned p = pcol[l] + (unsigned)(jw * sj32);
-          o_u[l] = (a.u + b)[p];
-          o_v[l] = (a.v + b)[p];
-          o_rx[l] = (rdx + m2)[p];
-          o_ry[l] = (rdy + m2)[p];
-        }
 #pragma unroll
         for (int f = 0; f < PG_NF; ++f) {
           const Real sc = f < 2 ? a.gz_scale : (Real)1;
-          const Real qn = f < 2 ? sc * pf[0][f][l] : pf[0][f][l];
-#pragma unroll
-          for (int n = 0; n + 1 < PG_PF; ++n) pf[n][f][l] = pf[n + 1][f][l];
-          pf[PG_PF - 1][f][l] = ld(f, rn, l);
-          qa[f][l] = qb[f][l];
+          const Real qn = f < 2 ? sc * pf[Q][f][l] : pf[Q][f][l];
+          pf[Q][f][l] = ld(f, rn, l);
+          sy[f][l] = A2B_B2 * (qb[f][l] + qn) + A2B_B1 * (qc[f][l] + qd[f][l]);  // corner row r-1 from rows r-3 .. r
           qb[f][l] = qc[f][l];
           qc[f][l] = qd[f][l];
           qd[f][l] = qn;
-          sy[f][l] = A2B_B2 * (qa[f][l] + qd[f][l]) + A2B_B1 * (qb[f][l] + qc[f][l]);  // corner row r-1
         }
       }
       // ---- phase B: x-interpolated row r, corner values of row r-1
@@ -201,11 +233,11 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
         for (int f = 0; f < PG_NF; ++f) {
           const Real qm2 = FV3_LANE_SHR(2, qd[f], l, lane), qm1 = FV3_LANE_SHR(1, qd[f], l, lane), qp1 = FV3_LANE_SHL(1, qd[f], l, lane);
           const Real ym2 = FV3_LANE_SHR(2, sy[f], l, lane), ym1 = FV3_LANE_SHR(1, sy[f], l, lane), yp1 = FV3_LANE_SHL(1, sy[f], l, lane);
-          x0[f][l] = x1[f][l];
+          const Real xn = A2B_B2 * (qm2 + qp1) + A2B_B1 * (qm1 + qd[f][l]);  // x-interpolated row r
+          const Real qxx = A2B_A2 * (x1[f][l] + xn) + A2B_A1 * (x2[f][l] + x3[f][l]);
           x1[f][l] = x2[f][l];
           x2[f][l] = x3[f][l];
-          x3[f][l] = A2B_B2 * (qm2 + qp1) + A2B_B1 * (qm1 + qd[f][l]);
-          const Real qxx = A2B_A2 * (x0[f][l] + x3[f][l]) + A2B_A1 * (x1[f][l] + x2[f][l]);
+          x3[f][l] = xn;
           const Real qyy = A2B_A2 * (ym2 + yp1) + A2B_A1 * (ym1 + sy[f][l]);
           cp[f][l] = cc[f][l];
           cc[f][l] = (Real)0.5 * (qxx + qyy);
@@ -213,6 +245,24 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
         if (top_level) {  // interface 0: pk3 = ptop^kappa, pp = 0 on every corner
           cp[2][l] = cc[2][l] = a.top;
           cp[4][l] = cc[4][l] = (Real)0;
+        }
+        // the corner column / row next to a tile-edge frame goes to scratch for the band winds (interior formula: only the march has it)
+        if (pass == 0 && (fl & 15)) {
+          const int i = i0 - 2 + lane, jc = r - 1;
+          const bool ecol = ((fl & FV3_W) && i == 3) || ((fl & FV3_E) && i == nx - 1);
+          const bool erow = ((fl & FV3_S) && jc == 3) || ((fl & FV3_N) && jc == ny - 1);
+          // (only corners that HAVE the interior formula: the frame kernel owns the others)
+          const bool interior = i >= ((fl & FV3_W) ? 3 : 1) && i <= ((fl & FV3_E) ? nx - 1 : nx + 1) && jc >= ((fl & FV3_S) ? 3 : 1) && jc <= ((fl & FV3_N) ? ny - 1 : ny + 1);
+          if ((ecol || erow) && interior && lane >= 2 && lane <= FV3_WAVE - 2 && jc >= j0 && jc <= j1 + 1) {
+            const unsigned p = pcol[l] + (unsigned)(jc * sj32);
+            (gzb + b)[p] = cc[0][l];
+            (gzb + b + sk)[p] = cc[1][l];
+            (pk3b + b)[p] = cc[2][l];
+            (pk3b + b + sk)[p] = cc[3][l];
+            (ppb + b)[p] = cc[4][l];
+            (ppb + b + sk)[p] = cc[5][l];
+            (wk1 + b)[p] = cc[6][l];
+          }
         }
       }
       // ---- phase C: the winds of row r-2 (corner values of that row: cp; of its north neighbour: cc; of its east neighbour: lane + 1's cp)
@@ -245,7 +295,31 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
             (a.v + b)[p] = (o_v[l] + dv + a.dt / (pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
           }
         }
+        if (next_ok) {  // (the winds of row r-1 and their metric terms: consumed in phase C of the next step)
+          const unsigned p = pcol[l] + (unsigned)((jw + 1) * sj32);
+          o_u[l] = (a.u + b)[p];
+          o_v[l] = (a.v + b)[p];
+          o_rx[l] = (rdx + m2)[p];
+          o_ry[l] = (rdy + m2)[p];
+        }
       }
+    };
+    // (trailing steps past r_end: their loads are clamped to r_end and every store is masked by the owned-row tests)
+    for (int r = r_beg; r <= r_end; r += 3) {
+      step(r, std::integral_constant<int, 0>{});
+      step(r + 1, std::integral_constant<int, 1>{});
+      step(r + 2, std::integral_constant<int, 2>{});
     }
   });
+  if (pass == 0) {
+    // the winds on the bands the march left out (columns 1, 2 / npx-2 .. npx, rows 1, 2 / npy-2 .. npy of the sub-domains with that
+    // tile edge), from the frame corners and the corner column / row the march exported
+    const Frame windsF{{Box{1, 2, 1, nyp, 0, nz - 1}, Box{g.npx - 2, g.npx, 1, nyp, 0, nz - 1}, Box{3, g.npx - 3, 1, 2, 0, nz - 1}, Box{3, g.npx - 3, g.npy - 2, g.npy, 0, nz - 1}}};
+    launch_frame(c, s, windsF, [=] FV3_HD(int t, int k, int i, int j) {
+      int ia, ib, ja, jb;
+      pgf_march_range(g, g.flags[t], ia, ib, ja, jb);
+      if (i >= ia && i <= ib && j >= ja && j <= jb) return;  // the march's
+      winds_at(t, k, i, j);
+    });
+  }
 }

@@ -57,6 +57,9 @@
 enum { Q4_QUAD = 0, Q4_AIR = 1, Q4_TRC = 2 };
 enum { Q4_ALL = 0, Q4_INTERIOR = 1, Q4_EDGE = 2 };
 #define Q4_EW 3  // cells next to a W / E tile edge the EDGE launch owns
+#ifndef Q4_KB
+#define Q4_KB 16  // levels of one tile that are consecutive workgroups of an XCD (interior marches)
+#endif
 
 // tracer identity of slot n: 0 = delp, 1 = w, 2 = q_con, 3 = pt
 template <int ROLE>
@@ -129,8 +132,27 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   const MPtr d6L = TR ? g.del6_u : g.del6_v, d6M = TR ? g.del6_v : g.del6_u;  // del-n face coefficients of the L / M faces
   const Real *damp_w_k = g.damp_w, *ke_bg_k = g.ke_bg;
   const int bitLlo = TR ? FV3_S : FV3_W, bitLhi = TR ? FV3_N : FV3_E, bitMlo = TR ? FV3_W : FV3_S, bitMhi = TR ? FV3_E : FV3_N;
-  launch_waves<WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k_lo + (blk.bz - t * nk);
+  // Launch geometry.  Plane-major (default before round 3): an XCD walks the tiles of one (sub-domain, level) plane, consecutive
+  // levels land on different XCDs.  Level-major (Q4_KB levels of ONE tile are consecutive workgroups of an XCD): the tile's 2-D metric
+  // rows (area, rarea, the del-n coefficients) are fetched into that XCD's L2 once per Q4_KB levels instead of once per level.
+  // FV3_Q4_KB=0 restores the plane-major order (A/B).
+  static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : Q4_KB;
+  const int KB = (PART == Q4_INTERIOR && kb_env > 0) ? kb_env : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  launch_waves<WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    Blk blk = blk_;
+    int t, k;
+    if (KB) {
+      t = blk_.bz / nblk;
+      const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k = k_lo + kk;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
+    } else {
+      t = blk.bz / nk;
+      k = k_lo + (blk.bz - t * nk);
+    }
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     const int l0 = 1 + blk.bx * Q4_OUT;  // first owned L face / cell of the strip
