@@ -672,6 +672,10 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const long st = g.st, st2 = g.st2, sk = g.sk;
     const int sj32 = g.sj32, go = g.o;
     const bool gl = riem_gam_lds(g);
+    // (two instantiations: the last sub-step also stores pe / peln / pk -- three more base pointers in a kernel that spills scalar
+    //  registers as it is)
+    auto go_ = [&](auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     launch_waves<1>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
       const int t = blk.bz;
       const long tb = t * st;
@@ -684,7 +688,6 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           long tb, sk;
           unsigned pix;
           Real pem, peg, pelng_k, z, akap;
-          bool last;
           Real *pk3, *peln, *pk, *pe, *ppe, *zh, *delz;
           FV3_HD Real pm(int k, Real dm, Real qc) {
             pem = pem + dm;
@@ -692,7 +695,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
             const Real peln_n = log(pem), pelng_n = log(peg_n);
             const Real pk3v = exp(akap * peln_n);
             KW_(pk3, k + 1) = pk3v;
-            if (last) {
+            if constexpr (LAST) {
               KW_(peln, k + 1) = peln_n;
               KW_(pk, k + 1) = pk3v;
               KW_(pe, k + 1) = pem;
@@ -711,9 +714,9 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
         };
         const Real z_bot = zs[t * st2 + pix];
         const Real peln0 = log(ptop);
-        Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, last, pk3, peln, pk, pe, ppe, zh, delz};
+        Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, pk3, LAST ? peln : nullptr, LAST ? pk : nullptr, LAST ? pe : nullptr, ppe, zh, delz};
         KW_(pk3, 0) = exp(akap * peln0);
-        if (last) {
+        if constexpr (LAST) {
           KW_(peln, 0) = peln0;
           KW_(pk, 0) = KW_(pk3, 0);
           KW_(pe, 0) = ptop;
@@ -723,6 +726,11 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
         KW_(zh, nz) = z_bot;
       }
     });
+    };
+    if (last)
+      go_(std::true_type{});
+    else
+      go_(std::false_type{});
     return fv3_post(c, s, "riem_solver3");
   }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {

@@ -75,14 +75,6 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
   const MPtr rdx = g.rdx, rdy = g.rdy;
   Real *ppb = c->scratch[SC_B], *pk3b = c->scratch[SC_C], *gzb = c->scratch[SC_D], *wk1 = c->scratch[SC_A];
   const int nxp = g.nx + 1, nyp = g.ny + 1;
-  auto corner_at = [=] FV3_HD(int t, int k, int i, int j) {
-    const long b = t * g.st + k * g.sk;
-    const unsigned p = IX(i, j);
-    (gzb + b)[p] = a2b_point(g, a.gz + b, t, i, j, a.gz_scale);
-    (pk3b + b)[p] = k == 0 ? a.top : a2b_point(g, a.pk3 + b, t, i, j);
-    (ppb + b)[p] = k == 0 ? (Real)0 : a2b_point(g, a.pp + b, t, i, j);
-    if (k < nz) (wk1 + b)[p] = a2b_point(g, a.delp + b, t, i, j);
-  };
   auto winds_at = [=] FV3_HD(int t, int k, int i, int j) {
     const long b = t * g.st + k * g.sk, b1 = b + g.sk;
     const unsigned p = IX(i, j), pe_ = IX(i + 1, j), pn = IX(i, j + 1);
@@ -102,7 +94,31 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
       windsF = Frame{{Box{1, F, 1, nyp, 0, nz - 1}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz - 1}, Box{F + 1, nxp - F, 1, F, 0, nz - 1}, Box{F + 1, nxp - F, nyp - F + 1, nyp, 0, nz - 1}}};
       cornersF = Frame{{Box{1, F + 1, 1, nyp, 0, nz}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz}, Box{F + 2, nxp - F, 1, F + 1, 0, nz}, Box{F + 2, nxp - F, nyp - F + 1, nyp, 0, nz}}};
     }
-    launch_frame(c, s, cornersF, corner_at);
+    // (one launch per field, one a2b_point per thread -- see the tile-edge frames below)
+    auto corners = [&](const Real *qin, Real *out, int k0, int k1, Real scale) {
+      Frame f = cornersF;
+      for (Box &w : f.w) {
+        w.k0 = k0;
+        w.k1 = k1;
+      }
+      launch_frame(c, s, f, [=] FV3_HD(int t, int k, int i, int j) {
+        const long b = t * g.st + k * g.sk;
+        (out + b)[IX(i, j)] = a2b_point(g, qin + b, t, i, j, scale);
+      });
+    };
+    corners(a.gz, gzb, 0, nz, a.gz_scale);
+    corners(a.pk3, pk3b, 1, nz, (Real)1);
+    corners(a.pp, ppb, 1, nz, (Real)1);
+    corners(a.delp, wk1, 0, nz - 1, (Real)1);
+    {
+      Frame f = cornersF;
+      for (Box &w : f.w) w.k0 = w.k1 = 0;
+      launch_frame(c, s, f, [=] FV3_HD(int t, int, int i, int j) {  // interface 0 of pk3 / pp: constants
+        const long p = t * g.st + IX(i, j);
+        pk3b[p] = a.top;
+        ppb[p] = (Real)0;
+      });
+    }
     launch_frame(c, s, windsF, winds_at);
     return;
   }
