@@ -20,6 +20,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -61,6 +62,7 @@ class _Plan:
 
     def __init__(self, sf, dst_off, src_off, sign):
         self.sf = sf
+        self._lib = sf.lib  # (the plan may outlive the factory by a moment when both are dropped together)
         self.n = int(len(dst_off))
         self.h = C.c_void_p()
         d = np.ascontiguousarray(dst_off, dtype=np.int64)
@@ -88,7 +90,7 @@ class _Plan:
     def __del__(self):
         try:
             if self.h:
-                self.sf.lib.fv3_gather_plan_destroy(self.h)
+                self._lib.fv3_gather_plan_destroy(self.h)
         except Exception:
             pass
 
@@ -124,7 +126,9 @@ class HaloExchanger:
         return ex
 
     def __init__(self, sf, layout: Layout, group=None, comm_stream=None):
-        self.sf = sf
+        # (the factory keeps the exchanger -- `shared` -- so the way back is weak: a strong reference would close a cycle and the
+        #  context's device memory would wait for the cycle collector instead of going when the last user drops the factory)
+        self.sf = sf if isinstance(sf, weakref.ProxyTypes) else weakref.proxy(sf)
         self.layout = layout
         self.part = layout.part
         self.group = group

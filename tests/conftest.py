@@ -44,3 +44,18 @@ def backend(request):
     else:
         request.getfixturevalue("gpu_backend")
     return request.param
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory(request):
+    """After every GPU test: collect what the test dropped and hand PyTorch's cached blocks back, so that the full-size cases
+    (C768 L79 fp64, C768 L127 fp32: tens of GB each) start from an empty device whatever ran before them in the same process."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+
+        import torch
+
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

@@ -128,3 +128,24 @@ def test_header_is_plain_c(tmp_path):
     src.write_text(f'#include "fv3_mi355x.h"\n#include <stdio.h>\nint main(void) {{\n  void *p[{len(names)}];\n{body}\n  printf("%d %p\\n", {len(names)}, p[0]);\n  return 0;\n}}\n')
     obj = tmp_path / "use_all.o"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o", str(obj)], check=True)
+
+
+def test_context_memory_goes_with_the_last_reference(hostemu):
+    """The factory owns the context's device memory (scratch, tables, the second halves of the scalar pairs: tens of GB at C768).
+    Dropping the harness must free it at once -- without waiting for the cycle collector (the shared halo exchanger refers back
+    to its factory weakly for this reason; a full-size GPU test ran out of memory behind its predecessors before)."""
+    import gc
+    import weakref
+
+    from pace_amd.harness import DycoreHarness
+
+    gc.collect()
+    gc.disable()
+    try:
+        h = DycoreHarness(12, nz=8, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=2, backend="hostemu")
+        h.dyn(h.state, 225.0, n_map=1)
+        r = weakref.ref(h.sf)
+        del h
+        assert r() is None
+    finally:
+        gc.enable()
