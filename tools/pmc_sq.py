@@ -58,6 +58,9 @@ def main(path, flt="", top=40):
                            ("SQ_ACTIVE_INST_LDS", "act_lds"), ("SQ_ACTIVE_INST_VMEM", "act_vmem"), ("SQ_WAIT_INST_LDS", "wait_lds")):
                 if c in m:
                     out.append(f"{lab} {100 * m[c] / wc:.0f}%")
+        for c in sorted(m):  # instruction-class counters (tools/prof_mix.sh): per wave
+            if c.startswith("SQ_INSTS_VALU_") or c in ("SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_SENDMSG", "SQ_INSTS_VSKIPPED"):
+                out.append(f"{c[9:].lower()}/wave {m[c] / w:.0f}")
         if "SQ_BUSY_CYCLES" in m:
             out.append(f"busy_cycles {m['SQ_BUSY_CYCLES']:.3g}")
         print(", ".join(out))
