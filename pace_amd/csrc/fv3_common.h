@@ -699,12 +699,14 @@ __global__ void __launch_bounds__(FV3_WAVE) __attribute__((amdgpu_waves_per_eu(W
 // Neighbour reads inside a wave: lane_shr<K>(x) = the value lane - K holds in x (0 below lane 0), lane_shl<K>(x) = lane + K's
 // (0 above lane 63).  On the device these are DPP moves (wave_shr:1 / wave_shl:1 of the GFX9 DPP set, two per fp64 value
 // and shift step): register to register, no LDS line, no ordering point, a few cycles of latency instead of the LDS
-// round trip.  The host emulation reads the neighbour's slot of the per-lane array (the phases of a step run lane by
+// round trip.  bound_ctrl: a lane without a source (lane 0 of a shift right) reads 0 -- with the `old` operand instead, the compiler
+// zeroes the destination before every DPP move (one more VALU instruction per 32-bit half: 72 per row of the two-tracer march).
+// The host emulation reads the neighbour's slot of the per-lane array (the phases of a step run lane by
 // lane there, so the value is complete when it is read).
 // ---------------------------------------------------------------------------------------------
 #if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-FV3_DEV inline int fv3_dpp_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }  // wave_shr:1
-FV3_DEV inline int fv3_dpp_shl1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+FV3_DEV inline int fv3_dpp_shr1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }  // wave_shr:1
+FV3_DEV inline int fv3_dpp_shl1_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }  // wave_shl:1
 FV3_DEV inline double fv3_dpp_shr1(double v) {
   return __hiloint2double(fv3_dpp_shr1_i(__double2hiint(v)), fv3_dpp_shr1_i(__double2loint(v)));
 }

@@ -423,7 +423,9 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
           Q4_EACH(n)
             Real qy = cur[l].qy[n], qx = qy;
             if (corner_row) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
-              const int lc = l0 - 3 + lane, lcc = lc < Led ? lc : Led;
+              int lane_o = lane;
+              FV3_LAUNDER(lane_o);  // (the remaps' per-lane predicates are formed here, not kept as lane masks across the march)
+              const int lc = l0 - 3 + lane_o, lcc = lc < Led ? lc : Led;
               const int rc = r < Med ? r : Med;
               if (TR) {
                 qy = cc<1>(qin[n], *gp, fl, rc, lcc);
@@ -540,7 +542,9 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               o_dy[n][l] = dyf[n][l];
             Q4_END
             if (pz_lo || pz_hi) {
-              const int lc = l0 - 3 + lane;
+              int lane_o = lane;
+              FV3_LAUNDER(lane_o);
+              const int lc = l0 - 3 + lane_o;
               const int jr_ = r - 3, jf_ = r - 2;
               const bool px_ = jr_ >= 1 && jr_ <= nM && on_patch(lc, jr_), py_ = lc <= nL && on_patch(lc, jf_);
               Q4_EACH(n)
