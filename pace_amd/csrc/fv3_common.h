@@ -206,15 +206,24 @@ Real *fv3_chk(fv3_ctx *c, const fv3_field *f, const char *name, bool is2d = fals
 // (8, tiles-per-plane, ceil(planes / 8)): blockIdx.x is then exactly the XCD a workgroup lands on,
 // every XCD walks the tiles of its OWN (sub-domain, level) plane in order, and the rows / columns
 // neighbouring tiles share are served by that XCD's L2 instead of being fetched once per XCD.
+// Few planes (the 2-D kernels and the column solvers have one per sub-domain: 3 on the per-GPU share of an 8-GPU run, 6 of a 4-GPU
+// run, 12 of a 2-GPU run): with whole planes per XCD, 3 planes keep 3 of the 8 XCDs busy and 12 planes give four XCDs twice the
+// work of the others.  Such launches cut every plane into 2^sshift contiguous runs of `tps` tiles ("sub-planes"), enough of
+// them for a multiple of 8: an XCD still walks neighbouring tiles of one plane, and all eight get the same share.
 struct GridMap {
   int gx;       // tiles per plane along i
   float rgx;    // 1 / gx  (tile index -> (bx, by) without an integer division)
   int nplanes;  // sub-domains * levels
+  int sshift;   // log2 of the sub-planes per plane (0: whole planes)
+  int tps;      // tiles per sub-plane (= tiles per plane when sshift == 0)
+  int tpp;      // tiles per plane
 };
 __device__ inline bool fv3_tile(const GridMap &m, int &bx, int &by, int &bz) {
-  bz = (int)(blockIdx.z * 8 + blockIdx.x);
+  const int v = (int)(blockIdx.z * 8 + blockIdx.x);
+  bz = v >> m.sshift;
   if (bz >= m.nplanes) return false;
-  const int y = (int)blockIdx.y;
+  const int y = (int)blockIdx.y + (v - (bz << m.sshift)) * m.tps;
+  if (y >= m.tpp) return false;
   by = (int)(((float)y + 0.5f) * m.rgx);
   bx = y - by * m.gx;
   return true;
@@ -263,15 +272,23 @@ __global__ void __launch_bounds__(256) fv3_k2(Box b, GridMap m, F f) {
 }
 // host side: grid + map for gx x gy tiles on nplanes planes (the float decode is checked once per shape)
 inline GridMap fv3_grid(int gx, int gy, int nplanes, dim3 *grid) {
-  GridMap m{gx, 1.0f / (float)gx, nplanes};
+  const int tpp = gx * gy;
+  int sshift = 0;
+  static const bool no_split = getenv("FV3_GRID_SPLIT") && getenv("FV3_GRID_SPLIT")[0] == '0';  // A/B switch
+  if (!no_split && nplanes < 64 && (nplanes & 7) != 0) {
+    while (((nplanes << sshift) & 7) != 0) ++sshift;  // 8 / gcd(nplanes, 8) sub-planes per plane
+    while (sshift > 0 && (1 << sshift) > tpp) --sshift;  // (never more sub-planes than tiles)
+  }
+  const int tps = (tpp + (1 << sshift) - 1) >> sshift;
+  GridMap m{gx, 1.0f / (float)gx, nplanes, sshift, tps, tpp};
   static thread_local int ok_gx = 0, ok_n = 0;
-  if (gx != ok_gx || gx * gy > ok_n) {
-    for (int y = 0; y < gx * gy; ++y)
+  if (gx != ok_gx || tpp > ok_n) {
+    for (int y = 0; y < tpp; ++y)
       if ((int)(((float)y + 0.5f) * m.rgx) != y / gx) abort();
     ok_gx = gx;
-    ok_n = gx * gy;
+    ok_n = tpp;
   }
-  *grid = dim3(8, gx * gy, (nplanes + 7) / 8);
+  *grid = dim3(8, tps, ((nplanes << sshift) + 7) / 8);
   return m;
 }
 #endif

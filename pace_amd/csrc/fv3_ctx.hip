@@ -318,13 +318,15 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   }
 #ifndef FV3_HOST_EMU
   {
-    // FV3_AUX_STREAM=1: run d_sw's del-n chains on a second stream, one transport ahead.  Off by default:
-    // measured on MI355X (C768) the two streams give bitwise identical states and the same time (d_sw
-    // 91.3-92.0 ms on, 91.8 ms off) -- the transport kernel holds 460 of the 512 VGPRs per SIMD lane, so
-    // the helper kernels find no room to run beside it.
+    // Auxiliary stream (FV3_AUX_STREAM=0 switches it off: everything in program order on the caller's stream): the small launches
+    // of d_sw / update_dz_d -- the del-n chains and transports of the few sponge-layer levels, the cube-corner patches -- run there
+    // beside the big marches of the other levels.  Round 1 measured no gain (the chains of every level beside a transport that held
+    // 460 of 512 registers); since the chains moved into the marches (round 3) what is left are launches of a few waves per CU that
+    // last as long as one wave's march: beside the marches they cost nothing (C768: d_sw 55.8 -> 54.9 ms; the 1/8 share of an
+    // 8-GPU run: 8.98 -> 8.8 ms).  Bitwise the same state either way (tests/test_gpu_invariants.py).
     const char *e = getenv("FV3_AUX_STREAM");
     const char *m = getenv("FV3_TP2D_MODE");  // the staged A/B form recomputes the damping fluxes in shared scratch
-    c->aux_on = (e && e[0] == '1') && !(m && !strcmp(m, "staged"));
+    c->aux_on = !(e && e[0] == '0') && !(m && !strcmp(m, "staged"));
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) c->aux_stream = (void *)st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) c->comm_stream = (void *)st;

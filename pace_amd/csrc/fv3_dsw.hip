@@ -1148,11 +1148,19 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   Real *u_pre = c->scratch[SC_N], *v_pre = c->scratch[SC_O];
   {
     TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
-    tp2d(c, s, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, fdw_k0 - 1, &e);
+    // (the levels without the chain: a small launch, on the auxiliary stream beside the others -- events 2 = fork, 3 = join)
+    fv3_stream_t sv = fdw_k0 > 0 && fdw_k0 <= nz1 ? fv3_aux(c, s) : s;
+    if (sv != s) {
+      fv3_signal(c, s, 2);
+      fv3_wait(c, sv, 2);
+    }
+    tp2d(c, sv, vabs, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, 0, fdw_k0 - 1, &e);
+    if (sv != s) fv3_signal(c, sv, 3);
     e.fd = 1;
     e.fd_coef = tab.d6_vt;
     e.fd_add = (const Real *)g.f0;
     tp2d(c, s, wk, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, fdw_k0, nz1, &e);
+    if (sv != s) fv3_wait(c, s, 3);
   }
 
   const bool heat_on = cf.d_con > 1.0e-5;

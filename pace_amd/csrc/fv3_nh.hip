@@ -1239,15 +1239,24 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
         fd_k0 = k;
       }
   }
-  del6_vt_flux(c, s, zh, d2, fx2, fy2, dn, false, 0, fd_k0 - 1);
+  // (the interfaces without the chain inside the march -- the sponge layers: their del-n launch and their small transport launch go
+  //  to the auxiliary stream, beside the march of the others; events 2 = fork, 3 = join)
+  fv3_stream_t sa = fd_k0 > 0 && fd_k0 <= nz ? fv3_aux(c, s) : s;
+  if (sa != s) {
+    fv3_signal(c, s, 2);
+    fv3_wait(c, sa, 2);
+  }
+  del6_vt_flux(c, sa, zh, d2, fx2, fy2, dn, false, 0, fd_k0 - 1);
   del6_vt_flux_edge_strips(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);
   Real *znew = fx;
   {
     TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt, nullptr, nullptr};
-    tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, fd_k0 - 1, &e);
+    tp2d(c, sa, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, fd_k0 - 1, &e);
+    if (sa != s) fv3_signal(c, sa, 3);
     e.fd = 1;
     e.fd_coef = g.damp_vt;
     tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, fd_k0, nz, &e);
+    if (sa != s) fv3_wait(c, s, 3);
   }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;

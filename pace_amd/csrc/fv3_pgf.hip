@@ -84,45 +84,8 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
     if (j <= g.ny) cn = PgfCorner{(gzb + b)[pn], (gzb + b1)[pn], (pk3b + b)[pn], (pk3b + b1)[pn], (ppb + b)[pn], (ppb + b1)[pn], (wk1 + b)[pn]};
     pgf_update(g, a, t, k, i, j, p, cc, ce, cn, (rdx + t * g.st2)[p], (rdy + t * g.st2)[p]);
   };
-  if (pass == 1) {
-    // the FV3_FRAME_W-wide frame of every sub-domain, whatever its tile edges: corners on the frame + one column / row, then the winds
-    Frame windsF, cornersF;
-    if (!has_frame) {
-      windsF = Frame{{Box{1, 0, 1, 0, 0, nz - 1}, Box{1, 0, 1, 0, 0, nz - 1}, Box{1, nxp, 1, nyp, 0, nz - 1}, Box{1, 0, 1, 0, 0, nz - 1}}};
-      cornersF = Frame{{Box{1, 0, 1, 0, 0, nz}, Box{1, 0, 1, 0, 0, nz}, Box{1, nxp, 1, nyp, 0, nz}, Box{1, 0, 1, 0, 0, nz}}};
-    } else {
-      windsF = Frame{{Box{1, F, 1, nyp, 0, nz - 1}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz - 1}, Box{F + 1, nxp - F, 1, F, 0, nz - 1}, Box{F + 1, nxp - F, nyp - F + 1, nyp, 0, nz - 1}}};
-      cornersF = Frame{{Box{1, F + 1, 1, nyp, 0, nz}, Box{nxp - F + 1, nxp, 1, nyp, 0, nz}, Box{F + 2, nxp - F, 1, F + 1, 0, nz}, Box{F + 2, nxp - F, nyp - F + 1, nyp, 0, nz}}};
-    }
-    // (one launch per field, one a2b_point per thread -- see the tile-edge frames below)
-    auto corners = [&](const Real *qin, Real *out, int k0, int k1, Real scale) {
-      Frame f = cornersF;
-      for (Box &w : f.w) {
-        w.k0 = k0;
-        w.k1 = k1;
-      }
-      launch_frame(c, s, f, [=] FV3_HD(int t, int k, int i, int j) {
-        const long b = t * g.st + k * g.sk;
-        (out + b)[IX(i, j)] = a2b_point(g, qin + b, t, i, j, scale);
-      });
-    };
-    corners(a.gz, gzb, 0, nz, a.gz_scale);
-    corners(a.pk3, pk3b, 1, nz, (Real)1);
-    corners(a.pp, ppb, 1, nz, (Real)1);
-    corners(a.delp, wk1, 0, nz - 1, (Real)1);
-    {
-      Frame f = cornersF;
-      for (Box &w : f.w) w.k0 = w.k1 = 0;
-      launch_frame(c, s, f, [=] FV3_HD(int t, int, int i, int j) {  // interface 0 of pk3 / pp: constants
-        const long p = t * g.st + IX(i, j);
-        pk3b[p] = a.top;
-        ppb[p] = (Real)0;
-      });
-    }
-    launch_frame(c, s, windsF, winds_at);
-    return;
-  }
-  if (pass == 0) {
+  const bool edges_now = pass != 2;  // (tile edges are sub-domain edges: their bands belong to the frame pass)
+  if (edges_now) {
     // Tile-edge frame corners (two columns / rows per side that has a tile edge -- the geometry of a2b_ord4_t's frame launch, lanes
     // along the edge).  The third corner column / row the band winds need has the interior formula: the march exports it.
     const int nfr = nxp > nyp ? nxp : nyp;
@@ -166,9 +129,14 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
   const Geo *gp = c->g_dev;
   const int nstrip = (nx + 1 + PG_OUT - 1) / PG_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((ny + 64) / 64) * g.nsub * nz, 2);
-  int nseg = (ny + 1 + seg / 2) / seg;
+  // sel: 0 = every strip, 1 = only the strips that hold columns of the sub-domain frame, 2 = only the others; rows jlo .. jhi
+  auto march = [&](const int sel, const int jlo, const int jhi) {
+  if (jlo > jhi) return;
+  const int nrow = jhi - jlo + 1;
+  int nseg = (nrow + seg / 2) / seg;
   if (nseg < 1) nseg = 1;
-  const int seglen = (ny + 1 + nseg - 1) / nseg;
+  const int seglen = (nrow + nseg - 1) / nseg;
+  const bool exports = edges_now;
   // Level-major launch geometry: the workgroups an XCD walks are the levels of ONE (strip, segment) tile (PG_KB of them), then the
   // next tile -- the lower interface of level k is the upper one of level k+1, and adjacent levels resident together on an XCD read
   // it from its L2 (plane-major, consecutive levels land on different XCDs and every interface comes from HBM twice).
@@ -184,7 +152,12 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
     int ia, ib, ja, jb;
     pgf_march_range(*gp, fl, ia, ib, ja, jb);
     const int i0 = 1 + blk.bx * PG_OUT;
-    int j0 = 1 + blk.by * seglen, j1 = j0 + seglen - 1;
+    if (sel != 0) {
+      const bool fstrip = i0 <= F || i0 + PG_OUT - 1 >= nx + 2 - F;
+      if ((sel == 1) != fstrip) return;
+    }
+    int j0 = jlo + blk.by * seglen, j1 = j0 + seglen - 1;
+    if (j1 > jhi) j1 = jhi;
     if (j0 < ja) j0 = ja;
     if (j1 > jb) j1 = jb;
     if (j0 > j1) return;
@@ -263,7 +236,7 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
           cp[4][l] = cc[4][l] = (Real)0;
         }
         // the corner column / row next to a tile-edge frame goes to scratch for the band winds (interior formula: only the march has it)
-        if (pass == 0 && (fl & 15)) {
+        if (exports && (fl & 15)) {
           const int i = i0 - 2 + lane, jc = r - 1;
           const bool ecol = ((fl & FV3_W) && i == 3) || ((fl & FV3_E) && i == nx - 1);
           const bool erow = ((fl & FV3_S) && jc == 3) || ((fl & FV3_N) && jc == ny - 1);
@@ -294,11 +267,7 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
         pe_.q1 = FV3_LANE_SHL(1, cp[5], l, lane);
         pe_.w = FV3_LANE_SHL(1, cp[6], l, lane);
         const int i = i0 - 2 + lane;
-        bool mine = row_ok && own[l];
-        if (pass == 2 && mine) {  // the sub-domain frame was done per point in pass 1
-          const bool fr = !has_frame || i <= F || i > nx + 1 - F || jw <= F || jw > ny + 1 - F;
-          mine = !fr;
-        }
+        const bool mine = row_ok && own[l];
         if (mine) {
           const unsigned p = pcol[l] + (unsigned)(jw * sj32);
           const Real wkp = pc.k1 - pc.k0;
@@ -327,7 +296,20 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
       step(r + 2, std::integral_constant<int, 2>{});
     }
   });
-  if (pass == 0) {
+  };
+  // Frame-first passes: the frame pass marches the two row bands of the frame over every strip and the strips that hold the
+  // frame's columns over the rows between (whole strips: the march is 60 columns wide whatever it is asked for -- what it
+  // computes beyond the frame is left out of the interior pass); the interior pass marches the remaining strips and rows.
+  if (pass == 0 || !has_frame) {
+    if (pass != 2) march(0, 1, ny + 1);
+  } else if (pass == 1) {
+    march(0, 1, F);
+    march(0, ny + 2 - F, ny + 1);
+    march(1, F + 1, ny + 1 - F);
+  } else {
+    march(2, F + 1, ny + 1 - F);
+  }
+  if (edges_now) {
     // the winds on the bands the march left out (columns 1, 2 / npx-2 .. npx, rows 1, 2 / npy-2 .. npy of the sub-domains with that
     // tile edge), from the frame corners and the corner column / row the march exported
     const Frame windsF{{Box{1, 2, 1, nyp, 0, nz - 1}, Box{g.npx - 2, g.npx, 1, nyp, 0, nz - 1}, Box{3, g.npx - 3, 1, 2, 0, nz - 1}, Box{3, g.npx - 3, g.npy - 2, g.npy, 0, nz - 1}}};

@@ -815,18 +815,24 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
     // levels below fd_k0 (the sponge layers: chains of lower order) read the damping fluxes del6_stream wrote; from fd_k0 on the
     // marches run the chains themselves
     const int kf = a.fd_k0 < 0 ? 0 : a.fd_k0 > nz1 + 1 ? nz1 + 1 : a.fd_k0;
-    dsw_scalars_t<Q4_AIR, Q4_INTERIOR>(c, s, a, 0, kf - 1);
+    // The few levels below fd_k0 are launches of a handful of waves per CU that last as long as one wave's march: they go to the
+    // auxiliary stream and run BESIDE the marches of the other levels (disjoint levels of the same arrays; the q_con + pt march of
+    // a level follows the delp + w march of that level on either stream).  Events: 2 = fork, 3 = join.
+    fv3_stream_t s2 = kf > 0 && kf <= nz1 ? fv3_aux(c, s) : s;
+    if (s2 != s) {
+      fv3_signal(c, s, 2);
+      fv3_wait(c, s2, 2);
+    }
+    dsw_scalars_t<Q4_AIR, Q4_INTERIOR>(c, s2, a, 0, kf - 1);
+    if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE>(c, s2, a, 0, kf - 1);
+    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s2, a, 0, kf - 1);
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s2, a, 0, kf - 1);
+    if (s2 != s) fv3_signal(c, s2, 3);
     dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
-    if (edges) {
-      dsw_scalars_t<Q4_AIR, Q4_EDGE>(c, s, a, 0, kf - 1);
-      dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
-    }
-    dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s, a, 0, kf - 1);
+    if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
     dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
-    if (edges) {
-      dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s, a, 0, kf - 1);
-      dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
-    }
+    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    if (s2 != s) fv3_wait(c, s, 3);
   }
 }
 
