@@ -839,15 +839,19 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     fv3_signal(c, s, 0);
     fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
     fv3_wait(c, s2, 0);
-    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, fd_k0 - 1);
-    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, fd_k0 - 1);
-    del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, fd_k0 - 1);
-    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, fd_k0 - 1);
+    // (the patches first: they are all the marches of the levels from fd_k0 on wait for; the chains of the sponge layers are read by
+    //  the sponge-layer marches, which follow them on the auxiliary stream)
     del6_vt_flux_patches(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, fd_k0, nz1);
     del6_vt_flux_patches(c, s2, w, d2w, dC_x, dC_y, dn_w, false, fd_k0, nz1);
     del6_vt_flux_patches(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, fd_k0, nz1);
     del6_vt_flux_patches(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, fd_k0, nz1);
-    fv3_signal(c, s2, 1);
+    const bool split_levels = s2 != s && scalars_mode == 1 && fd_k0 > 0 && fd_k0 <= nz1;  // (dsw_scalars_stream puts the sponge layers on s2)
+    if (split_levels) fv3_signal(c, s2, 1);
+    del6_vt_flux(c, s2, delp, d2w, dA_x, dA_y, dn_vt, false, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, w, d2w, dC_x, dC_y, dn_w, false, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, q_con, d2w, dQ_x, dQ_y, dn_t, true, 0, fd_k0 - 1);
+    del6_vt_flux(c, s2, pt, d2w, dB_x, dB_y, dn_vt, true, 0, fd_k0 - 1);
+    if (!split_levels) fv3_signal(c, s2, 1);
     fv3_wait(c, s, 1);
     DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
                   cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt, dn_w, fd_k0};
