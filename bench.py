@@ -120,6 +120,18 @@ def cpu_baseline(seconds_budget=20.0):
     return t_sub / cells, sample, nproc
 
 
+def _flush_c_stdio():
+    """Flush the C-level stdio buffers of this process (libraries that printf into a pipe are fully buffered: their text would
+    otherwise appear at exit, after the JSON line the driver reads)."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +192,7 @@ def main():
     h = DycoreHarness(world_size=share or world, proc=0 if share else rank, device=f"cuda:{local_rank}", dtype=dtype, group=group, verbose=(rank == 0), n_tracers=a.tracers,
                       remap=a.remap, loopback=bool(share), **kw)
     transport = h.dyn.halo.transport_name
+    _flush_c_stdio()  # (RCCL's version banner sits in the C stdio buffer of a piped run: out now, not behind the result line at exit)
     # A fallback nobody asked for must not produce a number: with an nccl group the messages go through the library's RCCL
     # transport or the run fails (FV3_HALO_NATIVE=0 asks for the torch.distributed path explicitly; gloo groups are test hooks)
     if world > 1 and os.environ.get("FV3_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("FV3_HALO_NATIVE", "1") != "0" and transport != "rccl-native":
@@ -325,6 +338,7 @@ def main():
                 "kind": "port",
                 "sample": sample + "; scaled per cell to the benchmarked step (own numpy restatement -- stands in for the reference numpy backend, which cannot run offline)",
             }
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

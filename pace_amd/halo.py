@@ -245,6 +245,22 @@ class HaloExchanger:
         halo VALUES are therefore not the neighbours' (timing runs only; never a parity path)."""
         from . import lib as _lib
 
+        if os.environ.get("FV3_LOOPBACK_TRANSPORT", "copy") == "rccl" and torch.device(self.sf.device).type == "cuda" and not self.sf.hostemu:
+            # The looped-back messages through RCCL itself: a communicator of ONE rank, every message an ncclSend to / ncclRecv from
+            # rank 0 posted by the library exactly as in a multi-GPU run (fv3_halo_plan_start: one group per update on the
+            # communication stream).  What a single-GPU box can execute of the RCCL path: the binding (dlopen, ncclUniqueId by value,
+            # datatype codes), communicator set-up and the group / stream protocol; not the inter-GPU transfer.
+            sf = self.sf
+            if not sf.lib.fv3_rccl_available():
+                raise RuntimeError("FV3_LOOPBACK_TRANSPORT=rccl: librccl.so could not be bound")
+            ident = _lib.fv3_nccl_id()
+            if sf.lib.fv3_comm_unique_id(C.byref(ident)) != 0:
+                raise RuntimeError("fv3_comm_unique_id failed: " + sf.lib.fv3_last_error(None).decode())
+            if sf.lib.fv3_ctx_comm_init(sf.ctx, C.byref(ident), 1, 0) != 0:
+                raise RuntimeError("fv3_ctx_comm_init failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
+            self.transport = "loopback-rccl"
+            return
+
         # FV3_LOOPBACK_DELAY_US: a device-side stall of that many microseconds per update on the stream the exchange runs on -- the
         # transfer time of a real interconnect, to measure how much of it the sequencer hides (tools/overlap_experiment.py)
         delay_us = float(os.environ.get("FV3_LOOPBACK_DELAY_US", "0"))
@@ -274,10 +290,6 @@ class HaloExchanger:
                                 rb.copy_(sb, non_blocking=True)
                         if spin:
                             torch.cuda._sleep(spin)
-                    for rev, p, fptr, boff, bks in up._prime:
-                        rb = up._recv_bufs[p]
-                        rev.run(rb.data_ptr() + boff * rb.element_size(), bks, fptr, self.sk, up.nk, h if h else up._stream())
-                    up._prime = []
                 return 0
             except Exception as e:  # never let an exception cross the C frame
                 self._xfer_error = e
@@ -295,7 +307,8 @@ class HaloExchanger:
         if self.layout.world_size == 1:
             return "local"
         if self.native:
-            return {"rccl": "rccl-native", "host": "gloo-host", "loopback": "loopback (one process alone, messages looped back)"}.get(self.transport, "torch")
+            return {"rccl": "rccl-native", "host": "gloo-host", "loopback": "loopback (one process alone, messages looped back)",
+                    "loopback-rccl": "loopback-rccl (one process alone, messages sent to itself through RCCL)"}.get(self.transport, "torch")
         return "torch"
 
     # ------------------------------------------------------------------------------------------
@@ -435,12 +448,19 @@ class HaloUpdater:
                         self._prime.append((_Plan(sf, s_, d, g), peer, gp[comp].storage.data_ptr(), gi * cnt * nk, cnt))
         plist = []
         self._send_bufs, self._recv_bufs = {}, {}
+        self_rccl = ex.transport == "loopback-rccl"
         for p in peers:
             ns, nr = ph.send_count.get(p, 0) * nk * ng, ph.recv_count.get(p, 0) * nk * ng
             sb = ex._buffer(("s", self.uid, p), ns) if ns else None
             rb = ex._buffer(("r", self.uid, p), nr) if nr else None
             self._send_bufs[p], self._recv_bufs[p] = sb, rb
-            plist.append(_lib.fv3_halo_peer(p, 0, ns, nr, sb.data_ptr() if sb is not None else None, rb.data_ptr() if rb is not None else None))
+            if self_rccl:
+                # every peer is this process (rank 0 of a one-rank communicator); a send to oneself needs its receive of the same
+                # size in the same group, so the one-directional messages (primed receive buffers, see above) are not posted
+                n = ns if ns == nr else 0
+                plist.append(_lib.fv3_halo_peer(0, 0, n, n, sb.data_ptr() if sb is not None else None, rb.data_ptr() if rb is not None else None))
+            else:
+                plist.append(_lib.fv3_halo_peer(p, 0, ns, nr, sb.data_ptr() if sb is not None else None, rb.data_ptr() if rb is not None else None))
         self._peers = peers
         h = C.c_void_p()
         ops_a = (_lib.fv3_halo_op * max(len(ops), 1))(*ops)
@@ -450,6 +470,13 @@ class HaloUpdater:
             raise RuntimeError("fv3_halo_plan_create failed: " + sf.lib.fv3_last_error(sf.ctx).decode())
         self._plan = h
         ex._by_plan[int(h.value)] = self
+        if self._prime:  # (loop-back runs: the one-directional receive buffers are primed when the plan is built)
+            for rev, p, fptr, boff, bks in self._prime:
+                rb = self._recv_bufs[p]
+                rev.run(rb.data_ptr() + boff * rb.element_size(), bks, fptr, ex.sk, self.nk, self._stream())
+            self._prime = []
+            if torch.device(sf.device).type == "cuda":
+                torch.cuda.synchronize(sf.device)
         return h
 
     def _host_transfer(self, phase: int):

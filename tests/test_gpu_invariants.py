@@ -169,3 +169,27 @@ def test_bench_two_ranks_reproduce_the_single_process_state(tmp_path):
     assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["finite"] and l2["scaling"] == "strong"
     assert l2["metric"] == l1["metric"] and l2["config"]["workload"].split(",")[0] == l1["config"]["workload"].split(",")[0]
     assert l2["state_checksum"] == l1["state_checksum"], (l1["state_checksum"], l2["state_checksum"])
+
+
+@pytest.mark.gpu
+def test_rccl_calls_execute_on_a_one_rank_communicator(gpu_backend, monkeypatch):
+    """What one GPU can execute of the RCCL transport: a communicator of one rank (ncclGetUniqueId / ncclCommInitRank through the
+    library's run-time binding) and every message of the 1/8 share's halo updates posted as ncclSend to / ncclRecv from rank 0 in
+    the library's group-per-update protocol on its communication stream (FV3_LOOPBACK_TRANSPORT=rccl).  The state after two
+    acoustic calls must be bitwise the one of the same run with device copies standing in for the messages."""
+    from pace_amd.harness import DycoreHarness
+
+    res = {}
+    for mode in ("copy", "rccl"):
+        monkeypatch.setenv("FV3_LOOPBACK_TRANSPORT", mode)
+        h = DycoreHarness(48, nz=16, layout=(2, 2), dt_atmos=225.0, k_split=2, n_split=3, world_size=8, proc=0, backend=gpu_backend, loopback=True)
+        name = h.dyn.halo.transport_name
+        assert name.startswith("loopback-rccl" if mode == "rccl" else "loopback ("), name
+        for _ in range(2):
+            h.dyn(h.state, 112.5, n_map=1)
+        h.synchronize()
+        res[mode] = {n: getattr(h.state, n).storage.clone() for n in ("delp", "pt", "u", "v", "w", "delz", "q_con")}
+        del h
+    for n, a in res["copy"].items():
+        assert torch.isfinite(a).all(), n
+        assert torch.equal(a, res["rccl"][n]), f"{n}: the RCCL self-loop moved different bytes than the device copies"
