@@ -124,6 +124,9 @@ void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
 // del6_vt_flux_patches: only the faces on the FV3_D6_PATCH^2 patches at the cube corners (staged chain; orders > 0) -- for callers that
 // run the chain themselves everywhere else (the fused scalar marches of d_sw)
 #define FV3_D6_PATCH 8
+#ifndef FV3_Q4_KB_DEFAULT
+#define FV3_Q4_KB_DEFAULT 16  // levels of one tile an XCD walks back to back in the transport marches (0: plane-major launches)
+#endif
 // del6_vt_flux_edge_strips: the strips that touch a W / E cube-tile edge (+ the corner patches) -- for tp2d's fused form (TpEpi::fd)
 void del6_vt_flux_edge_strips(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);
 void del6_vt_flux_patches(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *d2, Real *fx2, Real *fy2, const Deln &dn, bool q_raw, int k0, int k1);

@@ -557,7 +557,26 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr area = g.area, gdxa = g.dxa;
-  launch_waves<TS_WPE>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
+  // Launch geometry as in fv3_tp4.hip: level-major (KB levels of one (strip, segment) tile are consecutive workgroups of an XCD, so the
+  // tile's 2-D metric rows are fetched into that XCD's L2 once per KB levels instead of once per level) when KB > 0; FV3_Q4_KB=0
+  // selects the plane-major form (A/B; same values, same time, 15 - 20 % more L2 misses).
+  static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : FV3_Q4_KB_DEFAULT;
+  const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  launch_waves<TS_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    Blk blk = blk_;
+    int t_, k_;
+    if (KB) {
+      t_ = blk_.bz / nblk;
+      const int kk = (blk_.bz - t_ * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k_ = k0 + kk;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
+    } else {
+      t_ = blk.bz / nk;
+      k_ = k0 + (blk.bz - t_ * nk);
+    }
     // fold the features this instantiation does not have
     constexpr bool C_MFX = FEAT & TF_MFX, C_DAMP = FEAT & TF_DAMP, C_MASS = FEAT & TF_MASS, C_EPI = FEAT & TF_EPI, C_AREA = FEAT & TF_AREA;
     constexpr bool C_WIND = FEAT & TF_WIND, C_WFLUX = FEAT & TF_WFLUX, C_ACC = FEAT & TF_ACC;
@@ -570,7 +589,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     const Real *const wind_du_ = C_WIND ? wind_du : nullptr, *const wind_dv_ = C_WIND ? wind_dv : nullptr;
     Real *const wind_u_pre_ = C_WIND ? wind_u_pre : nullptr, *const wind_v_pre_ = C_WIND ? wind_v_pre : nullptr;
     const bool wflux_ = C_WFLUX && wflux, area_form_ = C_AREA && area_form;
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+    const int t = t_, k = k_;
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     const int i0 = 1 + blk.bx * TS_OUT;                            // first owned face / cell

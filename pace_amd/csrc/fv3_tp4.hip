@@ -58,7 +58,7 @@ enum { Q4_QUAD = 0, Q4_AIR = 1, Q4_TRC = 2 };
 enum { Q4_ALL = 0, Q4_INTERIOR = 1, Q4_EDGE = 2 };
 #define Q4_EW 3  // cells next to a W / E tile edge the EDGE launch owns
 #ifndef Q4_KB
-#define Q4_KB 0   // > 0: that many levels of one tile are consecutive workgroups of an XCD (interior marches); 0: plane-major
+#define Q4_KB FV3_Q4_KB_DEFAULT   // > 0: that many levels of one tile are consecutive workgroups of an XCD (interior marches); 0: plane-major
 #endif
 
 // tracer identity of slot n: 0 = delp, 1 = w, 2 = q_con, 3 = pt
@@ -135,10 +135,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   // Launch geometry.  Plane-major (default before round 3): an XCD walks the tiles of one (sub-domain, level) plane, consecutive
   // levels land on different XCDs.  Level-major (Q4_KB levels of ONE tile are consecutive workgroups of an XCD): the tile's 2-D metric
   // rows (area, rarea, the del-n coefficients) are fetched into that XCD's L2 once per Q4_KB levels instead of once per level.
-  // Measured at C768 (same box): d_sw 55.7 - 56.3 ms level-major (16) against 55.5 plane-major -- the marches are VALU-bound, the
-  // metric rows are not what they wait for -- so plane-major stays the default; FV3_Q4_KB=16 selects the other (A/B).
+  // Measured at C768 (same box, alternating runs): the same time (d_sw 54.7 / 55.05 ms level-major (16) against 55.6 / 55.06 plane-major)
+  // and 14 % fewer L2 misses of the march (FETCH_SIZE 31.7 -> 24.9 GB for delp + w, 37.1 -> 30.8 for q_con + pt: the metric rows were
+  // Infinity-Cache hits, not HBM reads, which is why the time does not move).  Level-major is the default; FV3_Q4_KB=0 selects
+  // plane-major (A/B).
   static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : Q4_KB;
-  const int KB = (PART == Q4_INTERIOR && kb_env > 0) ? kb_env : 0;
+  const int KB = (PART == Q4_INTERIOR && kb_env > 0) ? (kb_env < nk ? kb_env : nk) : 0;
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
   launch_waves<WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
