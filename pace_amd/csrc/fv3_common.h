@@ -511,6 +511,37 @@ inline bool fv3_frame_boxes(const Box &b, Box (&w)[4], Box &inner) {
   inner = Box{b.i0 + F, b.i1 - F, b.j0 + F, b.j1 - F, b.k0, b.k1};
   return true;
 }
+// Columns of the compute domain (1..nx, 1..ny) numbered FRAME FIRST for the column solvers' frame-first passes: the F rows along
+// the S and N edges, the F columns along W and E between them, then the interior, each part row-major (F = 0, or a domain that
+// is all frame: plain row-major).  at(n) -> (i, j).
+struct ColumnOrder {
+  int nx, ny, F;
+  FV3_HD bool split() const { return F > 0 && nx > 2 * F && ny > 2 * F; }
+  FV3_HD int n_frame() const { return split() ? 2 * F * nx + 2 * F * (ny - 2 * F) : nx * ny; }
+  FV3_HD void at(int n, int &i, int &j) const {
+    if (!split()) {
+      j = n / nx;
+      i = 1 + n - j * nx;
+      j += 1;
+      return;
+    }
+    const int band = F * nx, side = F * (ny - 2 * F);
+    if (n < 2 * band) {  // S rows 1 .. F, then N rows ny-F+1 .. ny
+      const int north = n >= band ? 1 : 0, m = n - north * band, r = m / nx;
+      i = 1 + m - r * nx;
+      j = (north ? ny - F + 1 : 1) + r;
+    } else if (n < 2 * band + 2 * side) {  // W columns 1 .. F, then E columns nx-F+1 .. nx, rows F+1 .. ny-F
+      const int q = n - 2 * band, east = q >= side ? 1 : 0, m = q - east * side, r = m / F;
+      i = (east ? nx - F + 1 : 1) + m - r * F;
+      j = F + 1 + r;
+    } else {
+      const int m = n - 2 * band - 2 * side, w = nx - 2 * F, r = m / w;
+      i = F + 1 + m - r * w;
+      j = F + 1 + r;
+    }
+  }
+};
+
 template <class F>
 inline void launch3_pass(const fv3_ctx *c, fv3_stream_t s, Box b, int pass, F f) {
   Box w[4], inner;

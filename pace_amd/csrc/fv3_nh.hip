@@ -674,16 +674,24 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const bool gl = riem_gam_lds(g);
     // (two instantiations: the last sub-step also stores pe / peln / pk -- three more base pointers in a kernel that spills scalar
     //  registers as it is)
+    // Frame-first passes of the sequencer (a transport is present): the columns are numbered frame first (ColumnOrder), pass 1 solves
+    // the waves that hold frame columns, the halo updates of zh / pkc start, pass 2 solves the rest beside them.  Columns are
+    // independent: the same values in any order.
+    const ColumnOrder ord{g.nx, g.ny, c->frame_pass != 0 ? FV3_FRAME_W : 0};
+    const int nwave = (ncol + FV3_WAVE - 1) / FV3_WAVE;
+    const int nwave_frame = c->frame_pass != 0 ? (ord.n_frame() + FV3_WAVE - 1) / FV3_WAVE : 0;
+    const int w_lo = c->frame_pass == 2 ? nwave_frame : 0, w_hi = c->frame_pass == 1 ? nwave_frame : nwave;  // waves [w_lo, w_hi)
     auto go_ = [&](auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    launch_waves<1>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
+    launch_waves<1>(c, s, w_hi - w_lo, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
       const int t = blk.bz;
       const long tb = t * st;
       FV3_LANES(blk, lane, l) {
-        const int cidx = blk.bx * FV3_WAVE + lane;
+        const int cidx = (w_lo + blk.bx) * FV3_WAVE + lane;
         if (cidx >= ncol) continue;
-        const int jr = cidx / ni;
-        const unsigned pix = (unsigned)((j0 + jr + go) * sj32 + (i0 + cidx - jr * ni) + go);
+        int ci, cj;
+        ord.at(cidx, ci, cj);
+        const unsigned pix = (unsigned)((cj + go) * sj32 + ci + go);
         struct Cl {
           long tb, sk;
           unsigned pix;
@@ -733,7 +741,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
       go_(std::false_type{});
     return fv3_post(c, s, "riem_solver3");
   }
-  launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
+  launch2_pass(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, c->frame_pass, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
     const long p = tb + pix;

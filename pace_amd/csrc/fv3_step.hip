@@ -271,10 +271,23 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     }
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);
     RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
-    RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
-                                              &ws->pkc, &ws->pk3, &st->pk, &st->peln, &f_w[cur], stream));
-    HALO(FV3_HALO_ZH, 0);
-    HALO(FV3_HALO_PKC, 0);
+    if (frame_first) {
+      // the frame columns of the new zh / pkc first, their updates start, the interior columns follow beside the messages
+      c->frame_pass = 1;
+      RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
+                                                &ws->pkc, &ws->pk3, &st->pk, &st->peln, &f_w[cur], stream));
+      HALO(FV3_HALO_ZH, 0);
+      HALO(FV3_HALO_PKC, 0);
+      c->frame_pass = 2;
+      RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
+                                                &ws->pkc, &ws->pk3, &st->pk, &st->peln, &f_w[cur], stream));
+      c->frame_pass = 0;
+    } else {
+      RUN(FV3_OP_RIEM_SOLVER3, fv3_riem_solver3(c, remap_step, dt, &st->cappa, ptop, &ws->zs, &ws->wsd, &st->delz, &f_qc[cur], &f_delp[cur], &f_pt[cur], &ws->zh, &st->pe,
+                                                &ws->pkc, &ws->pk3, &st->pk, &st->peln, &f_w[cur], stream));
+      HALO(FV3_HALO_ZH, 0);
+      HALO(FV3_HALO_PKC, 0);
+    }
     if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &f_delp[cur], ptop, stream));
     RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &f_delp[cur], ptop, akap, stream));
     HALO(FV3_HALO_ZH, 1);
