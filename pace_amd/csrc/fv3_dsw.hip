@@ -1071,7 +1071,18 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   // the marching iteration writes its result beside divgd, so the un-iterated divergence stays readable there and
   // the nord > 0 levels need no copy of it into delpc
   const bool dd_sep = !(staged_dd || nord_max > DD_NMAX);
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+  // (with the separate result array only the nord == 0 levels -- the sponge layers -- have work here: the launch covers their range)
+  int kd0 = 0, kd1 = nz1;
+  if (dd_sep) {
+    kd0 = nz1 + 1;
+    kd1 = -1;
+    for (int k = 0; k <= nz1; ++k)
+      if (c->nord_h[k] == 0) {
+        kd0 = std::min(kd0, k);
+        kd1 = std::max(kd1, k);
+      }
+  }
+  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kd0, kd1}, [=] FV3_HD(int t, int k, int i, int j) {
     const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
