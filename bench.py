@@ -345,8 +345,17 @@ def main():
         _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if world > 1:
+        import gc
+
         import torch.distributed as dist
 
+        # orderly teardown: every rank is done with its exchanges (barrier), the library's communicator goes with the context while
+        # the process group still exists, then the process group -- nothing RCCL-related is left for interpreter shutdown
+        torch.cuda.synchronize()
+        dist.barrier()
+        h.close()
+        del h
+        gc.collect()
         dist.destroy_process_group()
 
 

@@ -151,6 +151,11 @@ class DycoreHarness:
                 s = self.state
                 self.remap(self.tracers, s.pt, s.delp, s.delz, s.peln, s.pe, s.pk, s.pkz, s.u, s.v, s.w, s.cappa, self.ps, self.dyn._wsd)
 
+    def close(self):
+        """Destroy the library context now (scratch, streams, the RCCL communicator) instead of at garbage collection -- the end of a
+        multi-process run, while the process group still exists."""
+        self.sf.close()
+
     def synchronize(self):
         if not self.sf.hostemu:
             torch.cuda.synchronize(self.sf.device)
