@@ -19,17 +19,24 @@ ROOT = os.path.dirname(HERE)
 HOSTEMU_DIR = os.path.join(ROOT, "tests", "_hostemu")
 
 SOURCES = ["fv3_ctx.hip", "fv3_tp2d.hip", "fv3_tp4.hip", "fv3_a2b.hip", "fv3_csw.hip", "fv3_dsw.hip", "fv3_nh.hip", "fv3_pgf.hip", "fv3_step.hip", "fv3_halo.hip", "fv3_tracer.hip", "fv3_remap.hip"]
-HEADERS = ["fv3_common.h", "fv3_ops.h", "fv3_ppm.h", "fv3_a2b.h", os.path.join("..", "..", "include", "fv3_mi355x.h")]
+HEADERS = ["fv3_common.h", "fv3_ops.h", "fv3_ppm.h", "fv3_a2b.h", "fv3_math.h", os.path.join("..", "..", "include", "fv3_mi355x.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 HOST_FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-DFV3_HOST_EMU"]
 
 
+def _tag() -> str:
+    """FV3_LIB_TAG=<name>: a separately named build variant (A/B experiments: built here with FV3_EXTRA_FLAGS / FV3_FLAGS_<stem>,
+    selected by the same variable at load time on the GPU box).  Empty = the product library."""
+    t = os.environ.get("FV3_LIB_TAG", "")
+    return ("." + t) if t else ""
+
+
 def lib_path(precision: int = 64, hostemu: bool = False) -> str:
     if hostemu:
         return os.path.join(HOSTEMU_DIR, f"libfv3_hostemu_f{precision}.so")
-    return os.path.join(CSRC, f"libfv3_mi355x_f{precision}.so")
+    return os.path.join(CSRC, f"libfv3_mi355x_f{precision}{_tag()}.so")
 
 
 def _digest(paths, extra):
@@ -49,7 +56,7 @@ def _run(cmd):
 
 def build(precision: int = 64, hostemu: bool = False, force: bool = False, verbose: bool = True) -> str:
     out = lib_path(precision, hostemu)
-    objdir = os.path.join(HOSTEMU_DIR if hostemu else CSRC, f"_obj_f{precision}")
+    objdir = os.path.join(HOSTEMU_DIR if hostemu else CSRC, f"_obj_f{precision}{'' if hostemu else _tag()}")
     os.makedirs(objdir, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]

@@ -40,6 +40,52 @@ typedef hipStream_t fv3_stream_t;
 #endif
 typedef FV3_REAL Real;
 
+// ---------------------------------------------------------------------------------------------
+// In-kernel phase stamps (diagnostic builds only: -DFV3_STAMPS, never the product library).  rocprofv3's thread trace needs a
+// decoder library this image does not ship, so the marches are timed from inside: s_memtime (shader clock) at the phase
+// boundaries of a step, pinned with sched_barriers, the per-phase sums of a wave written to a record at its end.
+// Record = {kernel id, steps, sum[0..5]} (32-bit cycle sums); word 0 of the buffer counts the records.
+// ---------------------------------------------------------------------------------------------
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+#define FV3_STAMP_RECS 16384
+unsigned long long *fv3_stamp_buf();  // (fv3_ctx.hip) device buffer, allocated on first use
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FV3_STAMP_STATE unsigned st_t = (unsigned)__builtin_amdgcn_s_memtime(), st_a[6] = {0u, 0u, 0u, 0u, 0u, 0u}, st_n = 0u
+#define FV3_STAMP(i)                                            \
+  do {                                                          \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+    st_a[i] += t_ - st_t;                                       \
+    st_t = t_;                                                  \
+    if ((i) == 0) ++st_n;                                       \
+    __builtin_amdgcn_sched_barrier(0);                          \
+  } while (0)
+#define FV3_STAMP_USE(x) asm volatile("" ::"v"(x))
+#define FV3_STAMP_FLUSH(buf, kid, tid)                                          \
+  do {                                                                          \
+    if ((tid) == 0) {                                                           \
+      const unsigned long long slot_ = atomicAdd((buf), 1ull);                  \
+      if (slot_ < FV3_STAMP_RECS) {                                             \
+        unsigned long long *r_ = (buf) + 8 + slot_ * 8;                         \
+        r_[0] = (kid);                                                          \
+        r_[1] = st_n;                                                           \
+        for (int q_ = 0; q_ < 6; ++q_) r_[2 + q_] = st_a[q_];                   \
+      }                                                                         \
+    }                                                                           \
+  } while (0)
+#else
+#define FV3_STAMP_STATE unsigned st_n = 0u
+#define FV3_STAMP(i) ((void)0)
+#define FV3_STAMP_USE(x) ((void)0)
+#define FV3_STAMP_FLUSH(buf, kid, tid) ((void)st_n)
+#endif
+#else
+#define FV3_STAMP_STATE ((void)0)
+#define FV3_STAMP(i) ((void)0)
+#define FV3_STAMP_USE(x) ((void)0)
+#define FV3_STAMP_FLUSH(buf, kid, tid) ((void)0)
+#endif
+
 #define FV3_W 1
 #define FV3_E 2
 #define FV3_S 4

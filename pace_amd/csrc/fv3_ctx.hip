@@ -128,6 +128,34 @@ static void column_namelist(fv3_ctx *c) {
   damp_vt[nz] = damp_vt[nz - 1];
 }
 
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+// diagnostic builds only (-DFV3_STAMPS): the record buffer of the in-kernel phase stamps (fv3_common.h)
+unsigned long long *fv3_stamp_buf() {
+  static unsigned long long *buf = nullptr;
+  if (!buf) {
+    const size_t n = (size_t)(8 + 8 * FV3_STAMP_RECS) * sizeof(unsigned long long);
+    if (hipMalloc((void **)&buf, n) != hipSuccess) return nullptr;
+    (void)hipMemset(buf, 0, n);
+  }
+  return buf;
+}
+extern "C" int fv3_stamps_reset(void) {
+  unsigned long long *b = fv3_stamp_buf();
+  return b && hipMemset(b, 0, 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+// out[0] = number of records written (may exceed the capacity), then up to max_recs records of 8 words
+extern "C" long fv3_stamps_read(unsigned long long *out, long max_recs) {
+  unsigned long long *b = fv3_stamp_buf();
+  if (!b || hipDeviceSynchronize() != hipSuccess) return -1;
+  unsigned long long n = 0;
+  (void)hipMemcpy(&n, b, sizeof(n), hipMemcpyDeviceToHost);
+  long m = (long)(n < FV3_STAMP_RECS ? n : FV3_STAMP_RECS);
+  if (m > max_recs) m = max_recs;
+  (void)hipMemcpy(out, b + 8, (size_t)m * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  return m;
+}
+#endif
+
 extern "C" {
 
 int fv3_version(void) { return FV3_ABI_VERSION; }

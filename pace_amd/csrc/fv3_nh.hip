@@ -6,6 +6,7 @@
 // per-level access of a wavefront is one coalesced row.  Per-level temporaries that do not fit
 // registers (tridiagonal gam / pp / w) live in context scratch fields with the same layout.
 #include "fv3_ops.h"
+#include "fv3_math.h"
 
 // column access: uniform (sub-domain, level) base + 32-bit in-plane offset
 #define K_(arr, k) ((arr) + tb + (long)(k)*g.sk)[pix]
@@ -37,7 +38,7 @@ struct Sim1 {
       Real pm_k, dz_k;
       setup(0, pm_k, dz_k);
       Real dm_m = (Real)0, dm_k = DM(0);
-      Real pe_k = exp(GM(0) * log(-dm_k / dz_k * rgas * K_(pt, 0))) - pm_k;
+      Real pe_k = fv3_exp(GM(0) * fv3_log(-dm_k / dz_k * rgas * K_(pt, 0))) - pm_k;
       Real bet = (Real)0;
       K_(PP, 0) = (Real)0;
       for (int k = 0; k < nz; ++k) {
@@ -48,7 +49,7 @@ struct Sim1 {
           setup(k + 1, pm_n, dz_n);
           dm_n = DM(k + 1);
           const Real g_rat = dm_k / dm_n;
-          pe_n = exp(GM(k + 1) * log(-dm_n / dz_n * rgas * K_(pt, k + 1))) - pm_n;
+          pe_n = fv3_exp(GM(k + 1) * fv3_log(-dm_n / dz_n * rgas * K_(pt, k + 1))) - pm_n;
           bb = (Real)2.0 * ((Real)1.0 + g_rat);
           dd = (Real)3.0 * (pe_k + g_rat * pe_n);
         } else {
@@ -115,7 +116,7 @@ struct Sim1 {
     // ---- sweep 6 (down): new layer thickness, handed to the caller's finish
     Real p1 = (K_(PE, nz - 1) + (Real)2.0 * K_(PE, nz)) * r3;
     {
-      const Real dzn = -DM(nz - 1) * rgas * K_(pt, nz - 1) * exp((K_(cappa, nz - 1) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, nz - 1), p1 + K_(PM, nz - 1))));
+      const Real dzn = -DM(nz - 1) * rgas * K_(pt, nz - 1) * fv3_exp((K_(cappa, nz - 1) - (Real)1.0) * fv3_log(fv3_max(p_fac * K_(PM, nz - 1), p1 + K_(PM, nz - 1))));
       K_(DZ, nz - 1) = dzn;
       finish(nz - 1, dzn);
     }
@@ -123,7 +124,7 @@ struct Sim1 {
       const Real g_rat = DM(k) / DM(k + 1);
       const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
       p1 = (K_(PE, k) + bb * K_(PE, k + 1) + g_rat * K_(PE, k + 2)) * r3 - g_rat * p1;
-      const Real dzn = -DM(k) * rgas * K_(pt, k) * exp((K_(cappa, k) - (Real)1.0) * log(fv3_max(p_fac * K_(PM, k), p1 + K_(PM, k))));
+      const Real dzn = -DM(k) * rgas * K_(pt, k) * fv3_exp((K_(cappa, k) - (Real)1.0) * fv3_log(fv3_max(p_fac * K_(PM, k), p1 + K_(PM, k))));
       K_(DZ, k) = dzn;
       finish(k, dzn);
     }
@@ -215,7 +216,7 @@ struct Sim1W {
             const Real dz_n = r.v[4] - z_top;
             z_top = r.v[4];
             const Real dm_n = r.v[0] * rgrav;
-            const Real pe_n = exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
+            const Real pe_n = fv3_exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * fv3_log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
             if (m >= 1) {
               const int k = m - 1;
               const Real g_rat = dm_k / dm_n;
@@ -375,7 +376,7 @@ struct Sim1W {
               const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
               p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
             }
-            const Real dzn = -dm * rgas * r.v[1] * exp((r.v[2] - (Real)1.0) * log(fv3_max(p_fac * r.v[3], p1 + r.v[3])));
+            const Real dzn = -dm * rgas * r.v[1] * fv3_exp((r.v[2] - (Real)1.0) * fv3_log(fv3_max(p_fac * r.v[3], p1 + r.v[3])));
             cl.finish(k, dzn);
             pe2 = pe1;
             pe1 = pe_k;
@@ -592,7 +593,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
           Real *pef, *gz;
           FV3_HD Real pm(int, Real dm, Real qc) {
             const Real peg_n = peg + dm * ((Real)1.0 - qc);
-            const Real v = (peg_n - peg) / log(peg_n / peg);
+            const Real v = (peg_n - peg) / fv3_log(peg_n / peg);
             peg = peg_n;
             return v;
           }
@@ -624,7 +625,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
     auto setup = [&](int k, Real &pm, Real &dz) {
       const Real dm = K_(delpc, k);
       const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
-      pm = (peg_n - peg) / log(peg_n / peg);
+      pm = (peg_n - peg) / fv3_log(peg_n / peg);
       dz = K_(gz, k + 1) - K_(gz, k);
       K_(PM, k) = pm;
       K_(DZ, k) = dz;
@@ -700,8 +701,8 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           FV3_HD Real pm(int k, Real dm, Real qc) {
             pem = pem + dm;
             const Real peg_n = peg + dm * ((Real)1.0 - qc);
-            const Real peln_n = log(pem), pelng_n = log(peg_n);
-            const Real pk3v = exp(akap * peln_n);
+            const Real peln_n = fv3_log(pem), pelng_n = fv3_log(peg_n);
+            const Real pk3v = fv3_exp(akap * peln_n);
             KW_(pk3, k + 1) = pk3v;
             if constexpr (LAST) {
               KW_(peln, k + 1) = peln_n;
@@ -721,9 +722,9 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           }
         };
         const Real z_bot = zs[t * st2 + pix];
-        const Real peln0 = log(ptop);
+        const Real peln0 = fv3_log(ptop);
         Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, pk3, LAST ? peln : nullptr, LAST ? pk : nullptr, LAST ? pe : nullptr, ppe, zh, delz};
-        KW_(pk3, 0) = exp(akap * peln0);
+        KW_(pk3, 0) = fv3_exp(akap * peln0);
         if constexpr (LAST) {
           KW_(peln, 0) = peln0;
           KW_(pk, 0) = KW_(pk3, 0);
@@ -747,8 +748,8 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const long p = tb + pix;
     (void)p;
     Real pem = ptop, peg = ptop;
-    Real peln_k = log(pem), pelng_k = log(peg);
-    K_(pk3, 0) = exp(akap * peln_k);
+    Real peln_k = fv3_log(pem), pelng_k = fv3_log(peg);
+    K_(pk3, 0) = fv3_exp(akap * peln_k);
     if (last) {
       K_(peln, 0) = peln_k;
       K_(pk, 0) = K_(pk3, 0);
@@ -760,8 +761,8 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
       const Real dm = K_(delp, k);
       pem = pem + dm;
       const Real peg_n = peg + dm * ((Real)1.0 - K_(q_con, k));
-      const Real peln_n = log(pem), pelng_n = log(peg_n);
-      const Real pk3v = exp(akap * peln_n);
+      const Real peln_n = fv3_log(pem), pelng_n = fv3_log(peg_n);
+      const Real pk3v = fv3_exp(akap * peln_n);
       K_(pk3, k + 1) = pk3v;
       if (last) {
         K_(peln, k + 1) = peln_n;
@@ -925,7 +926,7 @@ extern "C" int fv3_pk3_halo(fv3_ctx *c, const fv3_field *pk3_, const fv3_field *
     Real pei = ptop;
     for (int k = 0; k < g.nz; ++k) {
       pei = pei + K_(delp, k);
-      K_(pk3, k + 1) = exp(akap * log(pei));
+      K_(pk3, k + 1) = fv3_exp(akap * fv3_log(pei));
     }
   };
   fv3_stream_t s = (fv3_stream_t)stream;
@@ -1460,7 +1461,7 @@ extern "C" int fv3_apply_diffusive_heating(fv3_ctx *c, const fv3_field *delp_, c
   launch3(c, (fv3_stream_t)stream, Box{1, g.nx, 1, g.ny, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
     const long p = t * g.st + k * g.sk + IX(i, j);
     const Real cp = cappa[p];
-    const Real pkz = exp(cp / ((Real)1.0 - cp) * log(rdg * delp[p] / delz[p] * pt[p]));
+    const Real pkz = fv3_exp(cp / ((Real)1.0 - cp) * fv3_log(rdg * delp[p] / delz[p] * pt[p]));
     const Real dtmp = hs[p] / (cv_air * delp[p]);
     Real lim = lim0;
     if (k == 0) lim = lim * (Real)0.1;
@@ -1471,3 +1472,13 @@ extern "C" int fv3_apply_diffusive_heating(fv3_ctx *c, const fv3_field *delp_, c
   });
   return fv3_post(c, (fv3_stream_t)stream, "apply_diffusive_heating");
 }
+
+#ifdef FV3_HOST_EMU
+// test hook of the host-emulation library only (tests/test_fast_math.py): the solvers' log on an array
+extern "C" void fv3_hostemu_log(const double *x, double *y, long n) {
+  for (long i = 0; i < n; ++i) y[i] = fv3_log(x[i]);
+}
+extern "C" void fv3_hostemu_exp(const double *x, double *y, long n) {
+  for (long i = 0; i < n; ++i) y[i] = fv3_exp(x[i]);
+}
+#endif

@@ -563,6 +563,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : FV3_Q4_KB_DEFAULT;
   const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+  unsigned long long *const st_buf = fv3_stamp_buf();
+  constexpr unsigned long long st_kid = 2000ull + FEAT;
+#endif
   launch_waves<TS_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
     int t_, k_;
@@ -723,10 +727,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     }
 
     // XE: this strip reaches a cube-tile edge in x (one-sided PPM formulas among its faces)
+    FV3_STAMP_STATE;
     auto march = [&](auto xe_tag) {
       constexpr bool XE = decltype(xe_tag)::value;
       constexpr bool LX = XE || TS_LDS_ONLY;  // neighbour reads through the LDS lines (tile-edge strips; TS_LDS_ONLY: everywhere, the A/B form)
       auto step = [&](int r) {
+        FV3_STAMP(0);
         const int r3 = r - 3 < jsd ? jsd : r - 3;
         const int rn = r + TS_PF < r_end ? r + TS_PF : r_end;
         const int sy = r - 1;  // cell whose low edge value the y-windows complete at this step
@@ -796,6 +802,14 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           } else {
             nxt[l] = load_row(rn, l, lane);
           }
+          FV3_STAMP(1);
+          FV3_STAMP_USE(cur[l].yv);
+          FV3_STAMP_USE(cur[l].cy);
+          FV3_STAMP_USE(cur[l].cx);
+          FV3_STAMP_USE(cur[l].xv);
+          FV3_STAMP_USE(cur[l].ar);
+          FV3_STAMP_USE(cur[l].qy);
+          FV3_STAMP(2);
           if (XE && lane < 8) emr[(r & 3) * 8 + lane] = cur[l].em;
           const Real qraw = cur[l].qy;  // (the del-n chain runs on the field itself: no added term, no corner remap)
           Real qy = qraw, qx = qy;
@@ -873,6 +887,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           }
         }
         if constexpr (LX) blk.wave_sync();
+        FV3_STAMP(3);
         // ---- phase 2: inner x-flux on row r, outer x-flux on row r-3, fx(row r-3)
         const int jr = r - 3;
         const bool fx_row = jr >= ja && jr <= jb && jr <= ny;
@@ -991,6 +1006,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           }
         }
         if constexpr (LX) blk.wave_sync();
+        FV3_STAMP(4);
         // ---- phase 3: q_j on row r, outer y-flux at face r-2, fy(face r-2)
         const int jf = r - 2;
         const bool fy_row = jf >= ja && jf <= jb;
@@ -1083,6 +1099,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
           }
         }
         if constexpr (LX) blk.wave_sync();
+        FV3_STAMP(5);
       };
       // The prefetched rows rotate through TS_PF + 1 register sets (cur <- nxt <- nx2).  Rolled, the rotation is
       // register copies at the loop head, and a copy of a row still in flight is a full vmcnt(0) drain every
@@ -1106,6 +1123,9 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       march(std::true_type{});
     else
       march(std::false_type{});
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+    FV3_STAMP_FLUSH(st_buf, st_kid, blk.tid);
+#endif
   });
 }
 

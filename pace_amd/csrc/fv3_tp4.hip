@@ -142,6 +142,10 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : Q4_KB;
   const int KB = (PART == Q4_INTERIOR && kb_env > 0) ? (kb_env < nk ? kb_env : nk) : 0;
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+  unsigned long long *const st_buf = fv3_stamp_buf();
+  constexpr unsigned long long st_kid = 1000ull + 100ull * ROLE + 10ull * PART + (FD ? 1ull : 0ull);
+#endif
   launch_waves<WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
     int t, k;
@@ -346,9 +350,11 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       }
     }
 
+    FV3_STAMP_STATE;
     auto march = [&](auto xe_tag) {
       constexpr bool XE = decltype(xe_tag)::value;  // one-sided formulas among the L faces of this strip (evaluated per lane)
       auto step = [&](int r) {
+        FV3_STAMP(0);
         const int r3 = r - 3 < Msd ? Msd : r - 3;
         const int rn = r + Q4_PF < r_end ? r + Q4_PF : r_end;
         const int sy = r - 1;  // cell whose low edge value the M windows complete at this step
@@ -410,6 +416,15 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
           cur[l] = nxt[l];
           nxt[l] = nx2[l];
           nx2[l] = load_row(rn, l, lane);
+          FV3_STAMP(1);  // loads of the step issued (incl. the waits the register rotation forces)
+          FV3_STAMP_USE(cur[l].yv);
+          FV3_STAMP_USE(cur[l].cy);
+          FV3_STAMP_USE(cur[l].cx);
+          FV3_STAMP_USE(cur[l].xv);
+          FV3_STAMP_USE(cur[l].ar);
+          FV3_STAMP_USE(cur[l].qy[0]);
+          FV3_STAMP_USE(cur[l].qy[Q4_NT - 1]);
+          FV3_STAMP(2);  // row r in registers
           if (XE && lane < 8) emr[(r & 3) * 8 + lane] = cur[l].em;
           const Real yv = cur[l].yv;
           const Real ar3 = PARK ? RG(RG_AR, r - 3)[lane] : a3[l];
@@ -509,6 +524,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             exm[lane] = HAS_AIR ? w2[0][l] : mbk[l];  // old air mass of the cell (lc, r-3)
         }
         if constexpr (!DPP) blk.wave_sync();
+        FV3_STAMP(3);
         // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3
         const int jr = r - 3;
         const bool fx_row = jr >= ca && jr <= cb;
@@ -653,6 +669,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             exx[lane] = xv;
         }
         if constexpr (!DPP) blk.wave_sync();
+        FV3_STAMP(4);
         // ---- phase 3: the L-advected q on row r, outer M fluxes at face r-2, final M fluxes, the cell update of (lc, r-3)
         const int jf = r - 2;
         const bool fy_row = jf >= fa && jf <= fb;
@@ -778,6 +795,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
           }
         }
         if constexpr (!DPP) blk.wave_sync();
+        FV3_STAMP(5);
       };
       // The prefetched rows rotate through three register sets (cur <- nxt <- nx2).  Unrolled by the rotation period the
       // copies are renames (the four-tracer wave, which has the registers); rolled they wait for the row fetched one
@@ -800,6 +818,9 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       else
         march(std::false_type{});
     }
+#if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
+    FV3_STAMP_FLUSH(st_buf, st_kid, blk.tid);
+#endif
   });
 }
 
