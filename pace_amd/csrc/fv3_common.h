@@ -185,9 +185,11 @@ struct fv3_ctx {
   // Ping-pong of the four scalars d_sw rewrites (delp, pt, w, q_con; fv3_step.hip): d_sw's marches read the old fields through
   // their halo columns / rows while they produce the new ones, so they write beside them.  Inside fv3_acoustic_step the new
   // fields simply BECOME the state for the operators that follow (no copy-back); every second sub-step lands in the caller's
-  // arrays again.  pp_buf: the alternate buffers (allocated with the context); pp_from / pp_to: the pointer translation the
+  // arrays again.  pp_buf: the alternate buffers (allocated by the first eligible fv3_acoustic_step call: fv3_pp_ensure; pp_state
+  // 0 = not tried yet, 1 = allocated, -1 = switched off or the allocation failed); pp_from / pp_to: the pointer translation the
   // registered halo plans apply while the state lives in the alternates.
   Real *pp_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  int pp_state = 0;
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;
@@ -231,6 +233,7 @@ extern std::string g_fv3_create_error;
 int fv3_fail(fv3_ctx *c, int code, const std::string &msg);
 int fv3_halo_step(fv3_ctx *c, int update, int phase, void *stream);  // fv3_halo.hip
 void *fv3_dev_alloc(fv3_ctx *c, size_t bytes);
+bool fv3_pp_ensure(fv3_ctx *c);  // (fv3_ctx.hip) the ping-pong buffers of fv3_acoustic_step, allocated on first use
 void fv3_h2d(void *dst, const void *src, size_t bytes);
 int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what);
 // validate one field against the context layout; returns typed base pointer or nullptr

@@ -35,6 +35,45 @@ void *fv3_dev_alloc(fv3_ctx *c, size_t bytes) {
   return p;
 }
 
+// Alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong (four full 3-D fields: ~9 GB at C768 L79 fp64 on one
+// GPU).  Allocated on the first sequencer call that is eligible for the ping-pong, NOT with the context: contexts that only run
+// single operators, the Python sequencer or a host halo callback never need them.  FV3_PINGPONG=0 switches the ping-pong off; if the
+// allocation fails the sequencer keeps d_sw's copy-back form (same values, one pass more) instead of failing.
+bool fv3_pp_ensure(fv3_ctx *c) {
+  if (c->pp_buf[0]) return true;
+  if (c->pp_state < 0) return false;
+  const char *e = getenv("FV3_PINGPONG");
+  if (e && e[0] == '0') {
+    c->pp_state = -1;
+    return false;
+  }
+  const size_t bytes = (size_t)c->g.st * c->g.nsub * sizeof(Real);
+  const size_t owned0 = c->owned.size();
+  for (auto &pb : c->pp_buf) {
+    pb = (Real *)fv3_dev_alloc(c, bytes);
+    if (!pb) break;
+  }
+  if (!c->pp_buf[3]) {  // not all four: give back what was taken and stay with the copy-back form
+    while (c->owned.size() > owned0) {
+      raw_free(c->owned.back());
+      c->owned.pop_back();
+      c->scratch_bytes -= (int64_t)bytes;
+    }
+    for (auto &pb : c->pp_buf) pb = nullptr;
+#ifndef FV3_HOST_EMU
+    (void)hipGetLastError();  // (the failed hipMalloc must not surface as the next launch's error)
+#endif
+    c->pp_state = -1;
+    fprintf(stderr, "[fv3] ping-pong buffers (4 x %.2f GB) could not be allocated: d_sw keeps its copy-back form\n", bytes / 1.0e9);
+    return false;
+  }
+#ifndef FV3_HOST_EMU
+  (void)hipDeviceSynchronize();  // (the zero-fill runs on the null stream; the caller's stream may be non-blocking)
+#endif
+  c->pp_state = 1;
+  return true;
+}
+
 int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what) {
 #ifdef FV3_HOST_EMU
   (void)c;
@@ -322,19 +361,8 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
     }
     c->scratch.push_back(p);
   }
-  {
-    // alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong (FV3_PINGPONG=0: not allocated, the
-    // sequencer then uses d_sw's copy-back form)
-    const char *e = getenv("FV3_PINGPONG");
-    if (!(e && e[0] == '0'))
-      for (auto &pb : c->pp_buf) {
-        pb = (Real *)fv3_dev_alloc(c, (size_t)g.st * g.nsub * sizeof(Real));
-        if (!pb) {
-          fv3_ctx_destroy(c);
-          return fv3_fail(nullptr, FV3_ERR_NOMEM, "device allocation of the ping-pong buffers failed");
-        }
-      }
-  }
+  // (the alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong are allocated by the first call that can use
+  //  them: fv3_pp_ensure -- operator-level contexts and runs with a halo callback never pay for them)
   {
     Geo *gd = (Geo *)fv3_dev_alloc(c, sizeof(Geo));
     if (!gd) {

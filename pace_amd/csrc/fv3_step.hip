@@ -47,7 +47,8 @@ struct OpTimer {
   }
 };
 
-// part = 0: the whole allocation; 1: the compute cells of a cell-centred field only; 2: the frame around them (levels 0..nz-1)
+// part = 0: every plane cell of levels 0..nz-1 (the level nz of the allocation -- interface padding of a cell-centred field -- is the
+// caller's: the alternate buffers never hold it); 1: the compute cells of a cell-centred field only; 2: the frame around them
 int copy_part(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, int part, void *stream) {
   FV3_FIELD(a, src) FV3_FIELD(b, dst)
   const Geo g = c->g;
@@ -58,7 +59,7 @@ int copy_part(fv3_ctx *c, const fv3_field *src, const fv3_field *dst, int part, 
   fv3_stream_t s = (fv3_stream_t)stream;
   const int ia = -g.o, ib = g.ni - 1 - g.o, ja = -g.o, jb = g.nj - 1 - g.o;
   if (part == 0) {
-    launch3<4>(c, s, Box{ia, ib, ja, jb, 0, g.nz}, cp);
+    launch3<4>(c, s, Box{ia, ib, ja, jb, 0, g.nz - 1}, cp);
   } else if (part == 1) {
     launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, g.nz - 1}, cp);
   } else {
@@ -143,7 +144,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   // the operators that follow -- and the registered halo plans, through the pointer translation -- use that half; after an
   // even number of sub-steps the state is back in the caller's arrays, after an odd number one copy brings it there.
   // Only with the registered plans (a host callback moves the caller's own arrays) and when the buffers exist.
-  const bool pingpong = !halo && c->pp_buf[0] != nullptr;
+  const bool pingpong = !halo && fv3_pp_ensure(c);
   fv3_field f_delp[2] = {st->delp, st->delp}, f_pt[2] = {st->pt, st->pt}, f_w[2] = {st->w, st->w}, f_qc[2] = {st->q_con, st->q_con};
   if (pingpong) {
     f_delp[1].ptr = c->pp_buf[0];

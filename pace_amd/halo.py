@@ -120,15 +120,28 @@ class HaloExchanger:
         if ex is not None:
             if ex.layout.world_size != layout.world_size or ex.layout.proc != layout.proc or ex.part.total_ranks != layout.part.total_ranks:
                 raise ValueError("this StencilFactory already exchanges halos with a different process layout")
+            if group is not None and ex.group is not group:
+                raise ValueError("this StencilFactory already exchanges halos over another process group (one transport per context: build a second "
+                                 "StencilFactory for a second group)")
             return ex
         ex = cls(sf, layout, group=group)
         sf._halo_exchanger = ex
         return ex
 
+    @property
+    def sf(self):
+        """The StencilFactory this exchanger belongs to (held weakly, see __init__); a clear error instead of a ReferenceError deep
+        inside update() when a caller kept an updater but dropped the factory."""
+        sf = self._sf_ref()
+        if sf is None:
+            raise RuntimeError("the StencilFactory of this HaloExchanger has been released: keep the factory (or the harness / AcousticDynamics that "
+                               "owns it) alive as long as its halo updaters are used")
+        return sf
+
     def __init__(self, sf, layout: Layout, group=None, comm_stream=None):
         # (the factory keeps the exchanger -- `shared` -- so the way back is weak: a strong reference would close a cycle and the
         #  context's device memory would wait for the cycle collector instead of going when the last user drops the factory)
-        self.sf = sf if isinstance(sf, weakref.ProxyTypes) else weakref.proxy(sf)
+        self._sf_ref = weakref.ref(sf)
         self.layout = layout
         self.part = layout.part
         self.group = group

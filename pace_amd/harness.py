@@ -136,20 +136,28 @@ class DycoreHarness:
         self.cells_local = self.part.nx * self.part.ny * nz * len(self.grids)
         self.cells_global = nx_tile * nx_tile * 6 * nz
 
-    def step(self):
+    def step(self, timer=None):
         """One model step of the dycore-only driver: k_split acoustic-dynamics calls (each followed by tracer advection and the
-        vertical remap where the harness was built with them)."""
+        vertical remap where the harness was built with them).  ``timer`` (pace_amd.timer.Timer): the reference's timer names inside
+        ``DynamicalCore.step_dynamics`` -- "DynCore" around the acoustic dynamics, "TracerAdvection", "Remapping"
+        [REF tests/main/driver/test_driver.py:77-121]."""
+        from .timer import NullTimer
+
+        timer = timer or NullTimer()
         dt = self.cfg.dt_atmos / self.cfg.k_split
         for k in range(self.cfg.k_split):
             if self.tracers:
                 self.dp1.storage.copy_(self.state.delp.storage)  # the air mass the accumulated mass fluxes start from
-            self.dyn(self.state, dt, n_map=k + 1)
+            with timer.clock("DynCore"):
+                self.dyn(self.state, dt, n_map=k + 1)
             if self.tracers:
-                self._tracer_halo.update()
-                self.tracer_advection(self.tracers, self.dp1, self.state.mfxd, self.state.mfyd, self.state.cxd, self.state.cyd)
+                with timer.clock("TracerAdvection"):
+                    self._tracer_halo.update()
+                    self.tracer_advection(self.tracers, self.dp1, self.state.mfxd, self.state.mfyd, self.state.cxd, self.state.cyd)
             if self.remap is not None:
                 s = self.state
-                self.remap(self.tracers, s.pt, s.delp, s.delz, s.peln, s.pe, s.pk, s.pkz, s.u, s.v, s.w, s.cappa, self.ps, self.dyn._wsd)
+                with timer.clock("Remapping"):
+                    self.remap(self.tracers, s.pt, s.delp, s.delz, s.peln, s.pe, s.pk, s.pkz, s.u, s.v, s.w, s.cappa, self.ps, self.dyn._wsd)
 
     def close(self):
         """Destroy the library context now (scratch, streams, the RCCL communicator) instead of at garbage collection -- the end of a

@@ -71,6 +71,16 @@ def save_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str
     return out
 
 
+def _unmasked(a, path, name):
+    """A restart variable as a plain array.  The netCDF readers hand back masked arrays where a value equals the variable's
+    _FillValue: a restart with missing values is not a state -- refuse it instead of loading the fill value as data."""
+    if np.ma.isMaskedArray(a):
+        if np.ma.is_masked(a):
+            raise RuntimeError(f"{path}: variable {name} has {int(np.ma.count_masked(a))} masked (missing / _FillValue) entries")
+        a = a.filled()  # (nothing masked: filled() only drops the mask)
+    return np.asarray(a)
+
+
 def _open_variables(path: str):
     """{name: ndarray (native byte order)} of one restart file, with whatever reader fits its format."""
     with open(path, "rb") as fh:
@@ -84,24 +94,39 @@ def _open_variables(path: str):
         try:
             import netCDF4
 
-            with netCDF4.Dataset(path) as ds:
-                return {n: np.asarray(ds.variables[n][:]) for n in ds.variables}
+            reader = "netCDF4"
         except ImportError:
-            pass
+            reader = None
+        if reader:
+            try:
+                with netCDF4.Dataset(path) as ds:
+                    return {n: _unmasked(ds.variables[n][:], path, n) for n in ds.variables}
+            except (OSError, RuntimeError) as e:
+                raise RuntimeError(f"{path}: netCDF4 could not read the file ({e})") from e
         try:
             import h5netcdf
 
-            with h5netcdf.File(path, "r") as ds:
-                return {n: np.asarray(ds.variables[n][...]) for n in ds.variables}
+            reader = "h5netcdf"
         except ImportError:
             pass
+        if reader:
+            try:
+                with h5netcdf.File(path, "r") as ds:
+                    return {n: _unmasked(ds.variables[n][...], path, n) for n in ds.variables}
+            except (OSError, RuntimeError, KeyError) as e:
+                raise RuntimeError(f"{path}: h5netcdf could not read the file ({e})") from e
         try:
             import xarray as xr
 
-            with xr.open_dataset(path) as ds:
-                return {n: np.asarray(ds[n].data) for n in ds.variables}
+            reader = "xarray"
         except ImportError:
             pass
+        if reader:
+            try:
+                with xr.open_dataset(path, mask_and_scale=False) as ds:
+                    return {n: _unmasked(ds[n].data, path, n) for n in ds.variables}
+            except (OSError, RuntimeError, ValueError) as e:
+                raise RuntimeError(f"{path}: xarray could not read the file ({e})") from e
         raise RuntimeError(f"{path} is a netCDF-4 / HDF5 file (the reference's default restart format) and this environment has none of netCDF4, h5netcdf, "
                            "xarray to read it; convert it to classic netCDF (xarray: to_netcdf(format='NETCDF3_64BIT')) or install one of them")
     raise RuntimeError(f"{path}: not a netCDF file (magic {magic!r})")

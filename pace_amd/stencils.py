@@ -20,6 +20,46 @@ def _ref(q: Optional[Quantity]):
     return None if q is None else q.fref
 
 
+def _as_numpy(x):
+    """Host values of a 1-D / 2-D argument given as numpy array, torch tensor or Quantity; None when it cannot be inspected cheaply."""
+    import numpy as np
+
+    if isinstance(x, Quantity):
+        return None  # (per-sub-domain device field: see _check_metric)
+    if hasattr(x, "detach"):
+        return x.detach().cpu().numpy()
+    try:
+        return np.asarray(x, dtype=np.float64)
+    except Exception:
+        return None
+
+
+def _check_owned(sf: StencilFactory, op: str, name: str, given, expected, rtol=1.0e-12):
+    """The C side owns the level columns (``dp_ref``, ``pfull``, ``ks``) and the metric terms (``rdxc``, ``rdyc``): they are uploaded
+    once with the context and the kernels read them there.  The reference passes them at every call; a caller that passes
+    DIFFERENT values would silently get the context's -- refuse instead.  ``None`` = "use the context's" (accepted)."""
+    import numpy as np
+
+    if given is None:
+        return
+    if isinstance(given, Quantity):
+        own = sf.grid_fields.get(name)
+        if own is not None and given.storage.data_ptr() == own.storage.data_ptr():
+            return  # the context's own field
+        if own is not None and given.storage.shape == own.storage.shape:
+            import torch
+
+            if bool(torch.allclose(given.storage.double(), own.storage.double(), rtol=rtol, atol=0.0)):
+                return
+        raise ValueError(f"{op}: argument {name!r} differs from the metric term the context was created with (the kernels read the context's copy)")
+    g = _as_numpy(given)
+    if g is None or expected is None:
+        return
+    e = np.asarray(expected, dtype=np.float64)
+    if g.shape != e.shape or not np.allclose(g, e, rtol=rtol, atol=0.0):
+        raise ValueError(f"{op}: argument {name!r} differs from the values the context was created with (GridData.{name}; the kernels read the context's copy)")
+
+
 class _Op:
     def __init__(self, stencil_factory: StencilFactory, quantity_factory=None, grid_data=None, *_, **__):
         self.sf = stencil_factory
@@ -42,6 +82,7 @@ class CGridShallowWaterDynamics(_Op):
 
 class UpdateGeopotentialHeightOnCGrid(_Op):
     def __call__(self, dp_ref, zs, ut, vt, gz, ws, dt):
+        _check_owned(self.sf, "update_dz_c", "dp_ref", dp_ref, self.sf.grids[0].dp_ref)
         self.sf.call("update_dz_c", zs.fref, ut.fref, vt.fref, gz.fref, ws.fref, float(dt))
 
 
@@ -54,6 +95,8 @@ class PGradC(_Op):
     """The ``p_grad_c`` stencil of dyn_core."""
 
     def __call__(self, rdxc, rdyc, uc, vc, delpc, pkc, gz, dt2):
+        _check_owned(self.sf, "p_grad_c", "rdxc", rdxc, None)
+        _check_owned(self.sf, "p_grad_c", "rdyc", rdyc, None)
         self.sf.call("p_grad_c", uc.fref, vc.fref, delpc.fref, pkc.fref, gz.fref, float(dt2))
 
 
@@ -125,6 +168,10 @@ class NonHydrostaticPressureGradient(_Op):
 
 class RayleighDamping(_Op):
     def __call__(self, u, v, w, dp, pfull, dt, ptop, ks=None):
+        _check_owned(self.sf, "ray_fast", "dp_ref", dp, self.sf.grids[0].dp_ref)
+        _check_owned(self.sf, "ray_fast", "pfull", pfull, self.sf.grids[0].pfull)
+        if ks is not None and int(ks) != int(self.sf.grids[0].ks):
+            raise ValueError(f"ray_fast: ks = {ks} differs from the context's ({self.sf.grids[0].ks}: number of pure-pressure layers of ak / bk)")
         self.sf.call("ray_fast", u.fref, v.fref, w.fref, float(dt), float(ptop))
 
 

@@ -123,3 +123,30 @@ def test_loopback_share_runs_alone(hostemu):
     assert len(h.grids) == 3 and h.dyn.halo.transport_name.startswith("loopback")
     h.step()
     assert all(ok for _, _, ok in h.sanity().values())
+
+
+def test_halo_exchanger_reports_a_released_factory_and_a_foreign_group(hostemu):
+    """An updater kept beyond its StencilFactory gets a clear error (not a ReferenceError inside update()); a second user of
+    the shared exchanger with another process group is refused (one transport per context)."""
+    import gc
+
+    from pace_amd.halo import HaloExchanger, Layout
+    from pace_amd.harness import DycoreHarness
+
+    h = DycoreHarness(12, nz=4, layout=(1, 1), backend="hostemu")
+    ex = h.dyn.halo
+    assert HaloExchanger.shared(h.sf, h.layout) is ex
+    with pytest.raises(ValueError, match="process group"):
+        HaloExchanger.shared(h.sf, h.layout, group=object())
+    assert ex.sf is h.sf
+    import weakref
+
+    class Gone:
+        pass
+
+    g = Gone()
+    ex._sf_ref = weakref.ref(g)  # what the exchanger sees once its factory has been collected
+    del g
+    gc.collect()
+    with pytest.raises(RuntimeError, match="has been released"):
+        ex.sf

@@ -61,6 +61,8 @@ def test_driver_runs_the_reference_c12_config_shape(tmp_path):
     times = d["times"]["acoustic_mainloop"]["times"]
     assert len(times) == 6 and all(len(t) == 3 for t in times)  # one entry per rank and step, as the reference collector
     assert d["setup"]["finite"] and d["acoustic_simulated_days_per_day"] > 0
+    dc = d["times"]["DynCore"]  # the dycore's own clock around the acoustic dynamics [REF tests/main/driver/test_driver.py:81-85]
+    assert dc["hits"] == 3 and all(0 < a <= b for ta, tb in zip(dc["times"], times) for a, b in zip(ta, tb))
 
 
 @pytest.mark.gpu
@@ -72,3 +74,39 @@ def test_driver_runs_the_step_dynamics_body(tmp_path):
     assert driver.main([str(p), "--steps", "3", "--tracers", "2", "--remap", "--out", str(out)]) == 0
     d = json.load(open(out))
     assert not d["setup"]["acoustic_only"] and d["setup"]["tracers"] == 2 and d["setup"]["remap"] and d["setup"]["finite"]
+    # the reference's timer names, and its own performance script's arithmetic on the file [REF .jenkins/print_performance_number.py:11-15]
+    import numpy as np
+
+    assert set(d["times"]) == {"mainloop", "DynCore", "TracerAdvection", "Remapping"}
+    for rank in range(6):
+        m = np.mean(d["times"]["mainloop"]["times"][rank][1:])
+        parts = sum(np.mean(d["times"][n]["times"][rank][1:]) for n in ("DynCore", "TracerAdvection", "Remapping"))
+        assert 0 < parts <= m
+    assert d["times"]["mainloop"]["hits"] == 3
+
+
+
+def test_timer_has_the_reference_interface():
+    """ndsl.performance.timer.Timer as the reference driver uses it [REF driver/pace/driver/driver.py:630-643]."""
+    from pace_amd.timer import NullTimer, Timer
+
+    n = []
+    t = Timer(sync=lambda: n.append(1))
+    with t.clock("mainloop"):
+        with t.clock("DynCore"):
+            pass
+        with t.clock("DynCore"):
+            pass
+    assert t.hits == {"DynCore": 2, "mainloop": 1} and t.times["mainloop"] >= t.times["DynCore"] >= 0 and len(n) == 6
+    t.start("x")
+    with pytest.raises(RuntimeError):
+        t.times
+    with pytest.raises(ValueError):
+        t.start("x")
+    t.stop("x")
+    t.reset()
+    assert t.times == {} and t.hits == {}
+    z = NullTimer()
+    with z.clock("a"):
+        pass
+    assert z.times == {} and not z.enabled

@@ -292,3 +292,35 @@ def test_pair_debug_report(hostemu, capsys):
     assert pair_debug.main(["--nx", "12", "--nz", "6", "--backend", "hostemu", "--n-split", "2", "--tol", "1e-10"]) == 0
     out = capsys.readouterr().out
     assert "riem_solver3" in out and "d_sw" in out and "worst difference" in out
+
+
+def test_operator_wrappers_refuse_columns_that_differ_from_the_context():
+    """dp_ref / pfull / ks / rdxc / rdyc live in the context (uploaded once); the reference passes them at every call.  The
+    wrappers accept the context's values (or None) and refuse anything else instead of silently using their own copy."""
+    from helpers import Case
+
+    from pace_amd import stencils as st
+
+    cs = Case(nx_tile=12, nz=8)
+    sf, g = cs.sf, cs.grids[0]
+    s = cs.states[0]
+    u, v, w = cs.q([s["u"]]), cs.q([s["v"]]), cs.q([s["w"]])
+    ray = st.RayleighDamping(sf)
+    ray(u, v, w, g.dp_ref, g.pfull, 10.0, g.ptop, ks=g.ks)  # the context's values: accepted
+    ray(u, v, w, None, None, 10.0, g.ptop)
+    with pytest.raises(ValueError, match="pfull"):
+        ray(u, v, w, g.dp_ref, g.pfull * 1.001, 10.0, g.ptop)
+    with pytest.raises(ValueError, match="dp_ref"):
+        ray(u, v, w, g.dp_ref[:-1], g.pfull, 10.0, g.ptop)
+    with pytest.raises(ValueError, match="ks"):
+        ray(u, v, w, g.dp_ref, g.pfull, 10.0, g.ptop, ks=g.ks + 1)
+    pg = st.PGradC(sf)
+    uc, vc, dpc, pkc, gz = (cs.q() for _ in range(5))
+    dpc.storage.fill_(1.0)
+    pg(sf.grid_fields["rdxc"], sf.grid_fields["rdyc"], uc, vc, dpc, pkc, gz, 5.0)
+    other = cs.qf.zeros(("x", "y"))
+    other.storage.copy_(sf.grid_fields["rdxc"].storage * 2.0)
+    with pytest.raises(ValueError, match="rdxc"):
+        pg(other, sf.grid_fields["rdyc"], uc, vc, dpc, pkc, gz, 5.0)
+    with pytest.raises(ValueError, match="dp_ref"):
+        st.UpdateGeopotentialHeightOnCGrid(sf)(g.dp_ref * 2.0, None, None, None, None, None, 1.0)

@@ -12,6 +12,7 @@ import torch
 from helpers import Case, assert_close, compare_cubes, oracle_cube, run_device_cube
 from pace_amd.config import AcousticDynamicsConfig
 from pace_amd.constants import get_constants
+from pace_amd.context import StencilFactory
 from pace_amd.grid import make_grid
 from pace_amd.topology import CubedSpherePartitioner
 
@@ -240,6 +241,51 @@ def test_full_acoustic_call(backend, layout, n_split):
     odyn(ost, 225.0, 1)
     got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0)
     compare_cubes(got, ost, part, nz, STATE, TOL)
+
+
+@pytest.mark.parametrize("n_split", [1, 3])
+def test_scalar_pingpong_leaves_every_array_as_the_in_place_sequence_does(backend, n_split, monkeypatch):
+    """FV3_PINGPONG=0 (d_sw's copy-back form) against the default (the new delp / pt / w / q_con become the state, an odd sub-step
+    count copies them home): the WHOLE storages agree bit for bit -- halos, cube-corner blocks, padding and the level nz of the
+    allocation, which belongs to the caller (an edge-replicated plane there must survive the home-coming copy)."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(12, (1, 1), nz, dict(n_split=n_split))
+    res = {}
+    for pp in ("0", "1"):
+        monkeypatch.setenv("FV3_PINGPONG", pp)
+        init = [{k: v.copy() for k, v in s.items()} for s in ost]
+        from pace_amd.dyn_core import AcousticDynamics, DycoreState
+        from pace_amd.halo import Layout
+
+        sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+        st = DycoreState.from_arrays(sf.quantity_factory, [dict(s_, phis=p) for s_, p in zip(init, phis)])
+        for n in ("delp", "pt", "w", "q_con"):
+            getattr(st, n).storage[:, nz] = 12345.0 + len(n)  # the caller's level-nz plane (e.g. what restart_state puts there)
+        dyn = AcousticDynamics(Layout(part, 1, 0), grids, sf, config=cfg, phis=st.phis, state=st)
+        dyn(st, 225.0, n_map=1)
+        if backend != "hostemu":
+            torch.cuda.synchronize()
+        res[pp] = {n: getattr(st, n).storage.detach().cpu().numpy().copy() for n in STATE}
+        assert sf.scratch_bytes > 0
+        res[pp + "bytes"] = sf.scratch_bytes
+    for n in STATE:
+        assert np.array_equal(res["0"][n], res["1"][n]), n
+    for n in ("delp", "pt", "w", "q_con"):
+        assert np.all(res["1"][n][:, nz] == 12345.0 + len(n)), n
+    assert res["1bytes"] > res["0bytes"]  # the alternate buffers exist only in the context that used them
+
+
+def test_operator_contexts_do_not_allocate_the_pingpong_buffers(backend):
+    """The four alternate buffers of fv3_acoustic_step are allocated by the first sequencer call that is eligible for the
+    ping-pong, not with the context: a context that only runs single operators stays at the 24 + scratch fields."""
+    from helpers import Case
+
+    cs = Case(nx_tile=12, nz=8, backend=backend)
+    before = cs.sf.scratch_bytes
+    s0 = cs.states[0]
+    cs.sf.call("ray_fast", cs.q([s0["u"]]).fref, cs.q([s0["v"]]).fref, cs.q([s0["w"]]).fref, 10.0, float(cs.grids[0].ptop))
+    ni, nj, nk = cs.sf.sizer.storage_shape
+    assert cs.sf.scratch_bytes - before < ni * nj * nk * 8  # (small per-operator tables may appear; no full 3-D field)
 
 
 @pytest.mark.parametrize("layout", [(1, 2), (3, 1)])

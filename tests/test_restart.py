@@ -78,15 +78,25 @@ def test_restart_is_strict_about_missing_variables_and_foreign_formats(hostemu, 
     p.mkdir()
     for r in range(6):
         (p / f"restart_dycore_state_{r}.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    try:
-        import netCDF4  # noqa: F401
+    import importlib.util
 
-        have_reader = True
-    except ImportError:
-        have_reader = False
-    if not have_reader:
-        with pytest.raises(RuntimeError, match="netCDF-4 / HDF5"):
-            restart.load_state(b.state, b.layout.local_ranks, str(p))
+    have_reader = any(importlib.util.find_spec(m) is not None for m in ("netCDF4", "h5netcdf", "xarray"))
+    # no reader: the message names the format and what to install; a reader that chokes on the truncated file: its error is wrapped
+    with pytest.raises(RuntimeError, match="could not read the file" if have_reader else "netCDF-4 / HDF5"):
+        restart.load_state(b.state, b.layout.local_ranks, str(p))
+
+
+def test_restart_refuses_masked_values():
+    """A _FillValue in a restart variable comes back masked from the netCDF readers: not a state."""
+    import numpy as np
+
+    from pace_amd import restart
+
+    a = np.ma.masked_array(np.arange(6.0).reshape(2, 3), mask=False)
+    assert isinstance(restart._unmasked(a, "f.nc", "u"), np.ndarray) and not np.ma.isMaskedArray(restart._unmasked(a, "f.nc", "u"))
+    a.mask[1, 2] = True
+    with pytest.raises(RuntimeError, match="masked"):
+        restart._unmasked(a, "f.nc", "u")
 
 
 def test_restart_shape_mismatch_is_refused(hostemu, tmp_path):

@@ -21,6 +21,9 @@ import torch  # noqa: E402
 
 
 def main():
+    import faulthandler
+
+    faulthandler.enable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c768")
     ap.add_argument("--out", default=None)
@@ -30,15 +33,19 @@ def main():
 
     kw = dict(CONFIGS[a.config])
     kw["k_split"], kw["n_split"] = 1, 2
-    h = DycoreHarness(device="cuda:0", **kw)
+    print("[stamps] building the harness", flush=True)
+    h = DycoreHarness(device="cuda:0", verbose=True, **kw)
     lib = L.load(64)
+    print("[stamps] library", L._build.lib_path(64), flush=True)
     lib.fv3_stamps_read.restype = C.c_long
     lib.fv3_stamps_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_long]
     h.step()
     torch.cuda.synchronize()
-    lib.fv3_stamps_reset()
+    print("[stamps] warm-up step done", flush=True)
+    print("[stamps] reset ->", lib.fv3_stamps_reset(), flush=True)
     h.step()
     torch.cuda.synchronize()
+    print("[stamps] measured step done", flush=True)
     cap = 16384
     buf = (C.c_ulonglong * (cap * 8))()
     n = lib.fv3_stamps_read(buf, cap)
