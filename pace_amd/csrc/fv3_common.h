@@ -74,10 +74,12 @@ unsigned long long *fv3_stamp_buf();  // (fv3_ctx.hip) device buffer, allocated 
     }                                                                           \
   } while (0)
 #else
+// host pass of hipcc: the kernel lambda must capture exactly what the device pass captures (the closure is the kernel argument)
+inline void fv3_stamp_touch(unsigned long long *, unsigned long long, int) {}
 #define FV3_STAMP_STATE unsigned st_n = 0u
 #define FV3_STAMP(i) ((void)0)
 #define FV3_STAMP_USE(x) ((void)0)
-#define FV3_STAMP_FLUSH(buf, kid, tid) ((void)st_n)
+#define FV3_STAMP_FLUSH(buf, kid, tid) (fv3_stamp_touch((buf), (kid), (tid)), (void)st_n)
 #endif
 #else
 #define FV3_STAMP_STATE ((void)0)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round-4 experiment A: baseline vs -ffp-contract=fast (same box), in-kernel stamps of the marches, parity of the fast build
 set -u
+ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/r4a
 mkdir -p "$out"

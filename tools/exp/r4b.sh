@@ -1,6 +1,7 @@
 #!/bin/bash
 # round-4 experiment B: fast log / exp in the Riemann solvers vs libm (same box), in-kernel stamps of the marches
 set -u
+ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/r4b
 mkdir -p "$out"

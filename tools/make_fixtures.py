@@ -11,7 +11,7 @@ fixtures are *data* the reference tree holds, down-selected:
   tests/test_restart_six_tiles.py  [REF tests/main/data/c12_restart/fv_core.res.tile[1-6].nc, fv_tracer.res.tile[1-6].nc;
   read by the reference in tests/main/driver/test_restart_fortran.py:21-67]
 * reference_thresholds_fv_dynamics.json - the reference's own calibrated savepoint thresholds (absolute / relative per variable)
-  of the C_SW-Out, D_SW-Out, Tracer2D1L-In / Out and Remapping-In / Out savepoints
+  of the C_SW-Out, D_SW-Out, Tracer2D1L-In / Out, Remapping-In / Out and FVDynamics-Out savepoints
   [REF tests/savepoint/thresholds/fv_dynamics.yaml:2-360]
 """
 import json
@@ -68,7 +68,7 @@ def thresholds():
 
     d = yaml.safe_load(open(os.path.join(REF, "tests/savepoint/thresholds/fv_dynamics.yaml")))["savepoints"]
     out = {}
-    for sec in ("C_SW-Out", "D_SW-Out", "Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out"):
+    for sec in ("C_SW-Out", "D_SW-Out", "Tracer2D1L-In", "Tracer2D1L-Out", "Remapping-In", "Remapping-Out", "FVDynamics-Out"):
         for item in d[sec]:
             for var, v in item.items():
                 a, r = v.get("absolute"), v.get("relative")
