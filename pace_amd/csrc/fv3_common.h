@@ -88,6 +88,15 @@ inline void fv3_stamp_touch(unsigned long long *, unsigned long long, int) {}
 #define FV3_STAMP_FLUSH(buf, kid, tid) ((void)0)
 #endif
 
+// scheduling fence (no instruction): the compiler may not move code across it.  The branch-free marches (PPM order as a constant)
+// otherwise overlap the sweeps of a step until the register file overflows (12 - 14 spilled VGPRs); fenced at the points where the
+// branchy form had its basic-block ends they fit again.
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define FV3_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FV3_SCHED_FENCE() ((void)0)
+#endif
+
 #define FV3_W 1
 #define FV3_E 2
 #define FV3_S 4
@@ -351,8 +360,20 @@ inline GridMap fv3_grid(int gx, int gy, int nplanes, dim3 *grid) {
 // hundreds of live registers (c_sw stage B went to 255 VGPRs, 1 wave / SIMD, without it).
 #if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
 #define FV3_LAUNDER(x) asm volatile("" : "+v"(x))
+// FV3_LANDED(x): x is the result of a load issued inside a RARE, wave-uniform branch of a marching kernel's hot loop (cube-corner
+// remaps, tile-edge metric terms, corner-patch fluxes).  Without it the wait for that load is placed where the value is first used
+// -- behind the point where the branch rejoins the hot path -- and, the memory counter being one in-order counter, the hot path
+// then waits THERE for everything older than the rare load: the rows it has just requested for the next steps (seen in the ISA of
+// every march: `s_waitcnt vmcnt(1)` at the head of phase 1, `vmcnt(0)` in phase 2: the prefetch distance was zero).  Reading the
+// value through an empty asm inside the rare block makes the compiler put the wait there.
+#ifdef FV3_NO_LANDED  // (A/B build)
+#define FV3_LANDED(x) ((void)0)
+#else
+#define FV3_LANDED(x) asm volatile("" : "+v"(x))
+#endif
 #else
 #define FV3_LAUNDER(x) ((void)0)
+#define FV3_LANDED(x) ((void)0)
 #endif
 #ifndef FV3_KC
 #define FV3_KC 8  // measured at C768: 2 -> 105.6, 4 -> 107.5, 8 -> 108.0, 16 -> 108.4 SDPD (8 keeps more workgroups for the multi-GPU loads)

@@ -35,6 +35,11 @@ FV3_HD inline Real ppm_al(Q q, M m, int s, bool lo, bool hi, int np_) {
   return PPM_P1 * (q(s - 1) + q(s)) + PPM_P2 * (q(s - 2) + q(s + 1));
 }
 
+// (mord is wave-uniform: with a run-time mord the compiler keeps two scalar branches per reconstructed cell -- 16 cells per row
+//  of the two-tracer march.  The marching kernels therefore have instantiations with the order as a compile-time constant for
+//  the reference's default hord = 6 everywhere (template parameter HC of dsw_scalars_t / tp2d_stream_t): the test folds to one
+//  comparison.  Evaluating both tests and selecting the lane mask instead was measured too: +2 live SGPR pairs, 12 - 14 spilled
+//  VGPRs in the two-tracer marches.)
 FV3_HD inline bool ppm_smt5(Real bl, Real br, int mord) {
   const Real b0 = bl + br;
   return mord == 5 ? (bl * br) < (Real)0 : ((Real)3.0 * fabs(b0)) < fabs(bl - br);

@@ -511,9 +511,11 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 // pointers and branches it uses (the all-features kernel sat at 256 VGPRs with scratch and 131 spilled SGPRs).
 enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND = 32, TF_WFLUX = 64, TF_ACC = 128, TF_ALL = 255, TF_FD = 256 };
 
-template <unsigned FEAT>
+// HC: 0 = run-time PPM order; 6 = the order is that constant (see dsw_scalars_t in fv3_tp4.hip)
+template <unsigned FEAT, int HC = 0>
 static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-                        const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
+                        const Real *mfx, const Real *mfy, const Real *mass, int hord_, const Deln *dn, int k0, int k1, const TpEpi *epi) {
+  const int hord = HC ? HC : hord_;
   const Geo g = c->g;
   Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
   const bool damped = dn != nullptr;
@@ -565,7 +567,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
 #if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
   unsigned long long *const st_buf = fv3_stamp_buf();
-  constexpr unsigned long long st_kid = 2000ull + FEAT;
+  constexpr unsigned long long st_kid = 2000ull + FEAT + 10000ull * HC;
 #endif
   launch_waves<TS_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
@@ -833,6 +835,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 qx = qx + addb[ix];
               }
             }
+            FV3_LANDED(qy);
+            FV3_LANDED(qx);
             cur[l].qy = qy;
           }
           if constexpr (C_FD && !XE) {
@@ -863,6 +867,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             const MPtr dyab = gp->dya + m2;
             auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
             al_new = ppm_al_win(w2[l], w3[l], w4[l], w5[l], My, sy, S, N, npy);
+            FV3_LANDED(al_new);
           } else {
             al_new = PPM_P1 * (w3[l] + w4[l]) + PPM_P2 * (w2[l] + w5[l]);
           }
@@ -914,6 +919,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 const Real *pfx = C_AREA ? zfx : wind_dv_, *pfy = C_AREA ? zfy : wind_du_;  // the staged chain's fluxes on the patches
                 if (jr_ >= 1 && jr_ <= ny && on_patch(i, jr_)) ox = (pfx + b)[pcol[l] + (unsigned)(jr_ * sj32)];
                 if (i <= nx && on_patch(i, jf_)) oy = (pfy + b)[pcol[l] + (unsigned)(jf_ * sj32)];
+                FV3_LANDED(ox);
+                FV3_LANDED(oy);
               }
               if constexpr (C_AREA) {
                 zx0[l] = ox;
@@ -1044,6 +1051,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             const MPtr dyab = gp->dya + m2;
             auto My = [&](int s_) { return dyab[pcol[l] + (unsigned)(s_ * sj32)]; };
             al_new = ppm_al_win(v2[l], v3[l], v4[l], v5[l], My, sy, S, N, npy);
+            FV3_LANDED(al_new);
           } else {
             al_new = PPM_P1 * (v3[l] + v4[l]) + PPM_P2 * (v2[l] + v5[l]);
           }
@@ -1147,6 +1155,18 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   case (F):                                                                                                 \
     tp2d_stream_t<(F)>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi); \
     return;
+  // the two big launches of the acoustic sub-step with the PPM order as a constant (reference default 6; FV3_HORD_CONST=0: A/B)
+  static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
+  if (hord == 6 && !hc_off) {
+    if (m == (TF_EPI | TF_AREA | TF_FD)) {
+      tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      return;
+    }
+    if (m == (TF_WIND | TF_FD)) {
+      tp2d_stream_t<(TF_WIND | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      return;
+    }
+  }
   switch (m) {
     TP_CASE(TF_WFLUX)                                             // plain transport (C entry)
     TP_CASE(TF_DAMP | TF_WFLUX)                                   // damped (C entry)

@@ -83,7 +83,9 @@ FV3_HD inline void q4_for(F &&f) {
 // direction.  "lc" / "r" are the Fortran-local coordinates along L / M.
 // M8: the hord-8 (monotone) reconstruction for every slot (tracer_2d_1l with hord_tr = 8), a separate instantiation so
 // that the hord 5 / 6 kernels of d_sw carry none of it
-template <int ROLE, int PART, bool M8 = false, bool FD = false>
+// HC: 0 = the PPM orders are run-time values (hord_dp / hord_vt / hord_tm of the call); 5 / 6 = all three equal that constant (the
+// reference configs: 6 everywhere): the limiter test of ppm_cell folds to one comparison and the order occupies no register.
+template <int ROLE, int PART, bool M8 = false, bool FD = false, int HC = 0>
 static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi) {
   static_assert(!FD || (ROLE != Q4_QUAD && PART != Q4_ALL && !M8), "the fused del-n chains exist for the two-tracer interior / edge marches");
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
@@ -144,7 +146,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
 #if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
   unsigned long long *const st_buf = fv3_stamp_buf();
-  constexpr unsigned long long st_kid = 1000ull + 100ull * ROLE + 10ull * PART + (FD ? 1ull : 0ull);
+  constexpr unsigned long long st_kid = 1000ull + 100ull * ROLE + 10ull * PART + (FD ? 1ull : 0ull) + 10000ull * HC;
 #endif
   launch_waves<WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
@@ -205,16 +207,17 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
     int hord[Q4_NT];
     Q4_EACH(n)
       qin[n] = qall[id];
-      hord[n] = hall[id];
+      hord[n] = HC ? HC : hall[id];
     Q4_END
     const Real *crLb = a.crx + b, *crMb = a.cry + b, *afLb = a.xfx + b, *afMb = a.yfx + b;  // Courant numbers / area fluxes along L, M
     const MPtr areab = area + m2;
     const bool Llo = (fl & bitLlo) && l0 <= 3, Lhi = (fl & bitLhi) && l0 + Q4_OUT + 1 >= npL - 1;
     const bool Mlo = fl & bitMlo, Mhi = fl & bitMhi;
     const bool halo_cols = l0 - 3 < 1 || l0 + FV3_WAVE - 4 > nL;
-    const bool on_vt = deln_on(a.dn_vt, k), on_t = deln_on(a.dn_t, k);
+    // (FD launches cover only levels on which all three chains are switched on -- fd_k0 in fv3_d_sw_out --: the flags are constants there)
+    const bool on_vt = FD ? true : deln_on(a.dn_vt, k), on_t = FD ? true : deln_on(a.dn_t, k);
     const Real damp_vt = on_vt ? deln_damp(a.dn_vt, k) : (Real)0, damp_t = on_t ? deln_damp(a.dn_t, k) : (Real)0;
-    const bool on_w = damp_w_k[k] > (Real)1.0e-5;
+    const bool on_w = FD ? true : damp_w_k[k] > (Real)1.0e-5;
     // FD: d2 of iteration 0 = coef * q for delp / w (the damped quantity itself), q for q_con / pt (weighted by the air mass later)
     Real dcoef[Q4_NT];
     Q4_EACH(n)
@@ -451,6 +454,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                 qy = cc<2>(qin[n], *gp, fl, lcc, rc);
                 qx = cc<1>(qin[n], *gp, fl, lcc, rc);
               }
+              FV3_LANDED(qy);
+              FV3_LANDED(qx);
               cur[l].qy[n] = qy;
             }
             if constexpr (FD) {
@@ -492,12 +497,14 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
               al_new = ppm8_al_win(w2[n][l], w3[n][l], w4[n][l], w5[n][l], My, sy, m_edge && Mlo, m_edge && Mhi, npM);
+              if (m_edge) FV3_LANDED(al_new);
               co = ppm8_cell(al_q[n][l], al_new, w3[n][l], ppm8_dm(w2[n][l], w3[n][l], w4[n][l]), ppm8_edge_cell(sy - 1, Mlo, Mhi, npM));
             } else {
             if (m_edge) {
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
               al_new = ppm_al_win(w2[n][l], w3[n][l], w4[n][l], w5[n][l], My, sy, Mlo, Mhi, npM);
+              FV3_LANDED(al_new);
             } else {
               al_new = PPM_P1 * (w3[n][l] + w4[n][l]) + PPM_P2 * (w2[n][l] + w5[n][l]);
             }
@@ -516,6 +523,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               lq[n][3 + lane] = qx;
               lqi[n][3 + lane] = qi;
             }
+            if constexpr (HC != 0) FV3_SCHED_FENCE();
           Q4_END
           y_prev[l] = yv;
           if constexpr (DPP)
@@ -524,6 +532,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             exm[lane] = HAS_AIR ? w2[0][l] : mbk[l];  // old air mass of the cell (lc, r-3)
         }
         if constexpr (!DPP) blk.wave_sync();
+        if constexpr (HC != 0) FV3_SCHED_FENCE();
         FV3_STAMP(3);
         // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3
         const int jr = r - 3;
@@ -569,6 +578,11 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                 if (px_) o_dx[n][l] = dLall[id][pcol[l] + (unsigned)(jr_ * MS)];
                 if (py_) o_dy[n][l] = dMall[id][pcol[l] + (unsigned)(jf_ * MS)];
               Q4_END
+              // (FD marches carry two tracers; an asm operand cannot name a capture inside the generic lambda of Q4_EACH)
+              FV3_LANDED(o_dx[0][l]);
+              FV3_LANDED(o_dy[0][l]);
+              FV3_LANDED(o_dx[Q4_NT - 1][l]);
+              FV3_LANDED(o_dy[Q4_NT - 1][l]);
             }
             if constexpr (HAS_AIR) {
               zx0[l] = o_dx[1][l];
@@ -601,6 +615,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               fxin[n] = M8 ? ppm8_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx) : ppm_flux_int(aq[0], aq[1], aq[2], aq[3], aq[4], aq[5], cx, hord[n]);
               fxout[n] = M8 ? ppm8_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l]) : ppm_flux_int(bq[0], bq[1], bq[2], bq[3], bq[4], bq[5], cx3[l], hord[n]);
             }
+            if constexpr (HC != 0) FV3_SCHED_FENCE();
           Q4_END
           const Real mb = HAS_AIR ? w2[0][l] : mbk[l];                    // old delp(lc, r-3)
           Real mwest;
@@ -669,6 +684,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             exx[lane] = xv;
         }
         if constexpr (!DPP) blk.wave_sync();
+        if constexpr (HC != 0) FV3_SCHED_FENCE();
         FV3_STAMP(4);
         // ---- phase 3: the L-advected q on row r, outer M fluxes at face r-2, final M fluxes, the cell update of (lc, r-3)
         const int jf = r - 2;
@@ -699,12 +715,14 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
               al_new = ppm8_al_win(v2[n][l], v3[n][l], v4[n][l], v5[n][l], My, sy, m_edge && Mlo, m_edge && Mhi, npM);
+              if (m_edge) FV3_LANDED(al_new);
               co = ppm8_cell(al_v[n][l], al_new, v3[n][l], ppm8_dm(v2[n][l], v3[n][l], v4[n][l]), ppm8_edge_cell(sy - 1, Mlo, Mhi, npM));
             } else {
             if (m_edge) {
               const MPtr mmb = (TR ? gp->dxa : gp->dya) + m2;
               auto My = [&](int s_) { return mmb[pcol[l] + (unsigned)(s_ * MS)]; };
               al_new = ppm_al_win(v2[n][l], v3[n][l], v4[n][l], v5[n][l], My, sy, Mlo, Mhi, npM);
+              FV3_LANDED(al_new);
             } else {
               al_new = PPM_P1 * (v3[n][l] + v4[n][l]) + PPM_P2 * (v2[n][l] + v5[n][l]);
             }
@@ -713,6 +731,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             al_v[n][l] = al_new;
             fyout[n] = ppm_face(cv[n][l], co, cur[l].cy);
             cv[n][l] = co;
+            if constexpr (HC != 0) FV3_SCHED_FENCE();
           Q4_END
           const Real mb = HAS_AIR ? w2[0][l] : mbk[l], mc = HAS_AIR ? w3[0][l] : o_mc[l];  // old delp(lc, r-3), old delp(lc, r-2)
           Real vy[Q4_NT];
@@ -851,10 +870,20 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
     dsw_scalars_t<Q4_TRC, Q4_INTERIOR>(c, s2, a, 0, kf - 1);
     if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE>(c, s2, a, 0, kf - 1);
     if (s2 != s) fv3_signal(c, s2, 3);
-    dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
-    if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
-    dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
-    if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    // (the big launches: the instantiation with the PPM order as a constant when the configuration has the reference's 6 everywhere;
+    //  FV3_HORD_CONST=0 keeps the run-time form -- A/B, same values)
+    static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
+    if (!hc_off && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6) {
+      dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
+      if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+      dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
+      if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    } else {
+      dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+      if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+      dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+      if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+    }
     if (s2 != s) fv3_wait(c, s, 3);
   }
 }

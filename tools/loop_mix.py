@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Static instruction mix of a kernel's main loop, from the built library (no GPU): disassembles the gfx950 code object embedded
+in the .so, finds the kernel whose mangled name contains every given key, takes the largest backward branch as the march loop and
+counts its instructions by class -- branches, SALU, VALU, DPP moves, SGPR-spill lane moves, waits.
+    python tools/loop_mix.py <lib.so> key [key ...]
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+from collections import Counter
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(path, arch="gfx950"):
+    blob = open(path, "rb").read()
+    for m in re.finditer(MAGIC, blob):
+        po = m.start()
+        (n,) = struct.unpack_from("<Q", blob, po + len(MAGIC))
+        off = po + len(MAGIC) + 8
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off : off + ts].decode(errors="replace")
+            off += ts
+            if arch in triple and s:
+                yield blob[po + o : po + o + s]
+
+
+def kernel_asm(lib, keys):
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(co)
+            fn = f.name
+        try:
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", fn], capture_output=True, text=True, check=True).stdout
+        finally:
+            os.unlink(fn)
+        cur, out = None, {}
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                out[cur] = []
+            elif cur:
+                out[cur].append(line)
+        for name, lines in out.items():
+            if all(k in name for k in keys):
+                yield name, lines
+
+
+def main_loop(lines):
+    ins = []
+    for ln in lines:
+        m = re.match(r"\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):", ln)
+        if m:
+            ins.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    addr = {a: i for i, (a, _, _) in enumerate(ins)}
+    best = None
+    for i, (a, op, args) in enumerate(ins):
+        if op.startswith("s_cbranch") or op == "s_branch":
+            off = int(args.split()[0])
+            if off > 32767:
+                off -= 65536
+            tgt = a + 4 + off * 4
+            if tgt < a and tgt in addr and (best is None or a - tgt > best[0]):
+                best = (a - tgt, addr[tgt], i)
+    return ins, (ins[best[1] : best[2] + 1] if best else ins)
+
+
+def classify(op):
+    if op.startswith("s_cbranch") or op == "s_branch":
+        return "branch"
+    if op in ("v_readlane_b32", "v_writelane_b32"):
+        return "sgpr_spill_lane_move"
+    if op.endswith("_dpp"):
+        return "dpp_move"
+    if op.startswith("s_waitcnt") or op == "s_nop":
+        return "wait/nop"
+    if op.startswith("scratch_"):
+        return "scratch"
+    if op.startswith(("global_", "flat_", "buffer_")):
+        return "vmem"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("v_"):
+        return "valu_f64" if "f64" in op else "valu_other"
+    return "other"
+
+
+def main():
+    lib, keys = sys.argv[1], sys.argv[2:]
+    for name, lines in kernel_asm(lib, keys):
+        ins, body = main_loop(lines)
+        c = Counter(classify(op) for _, op, _ in body)
+        print(f"{name[:120]}\n  kernel {len(ins)} instructions, main loop {len(body)} (static; rare paths included): " + ", ".join(f"{k} {v}" for k, v in sorted(c.items(), key=lambda kv: -kv[1])))
+
+
+if __name__ == "__main__":
+    main()
