@@ -12,7 +12,9 @@ k_split 2, n_split 6, dycore-only.  The 24 sub-domains are split over the N proc
 
 Extra objects on the JSON line:
   roofline     d_sw (all launches of one fv3_d_sw call), algorithmic bytes = 33 field passes x 8 B x
-               local cells / mean HIP-event duration of the call, vs 8 TB/s HBM peak
+               local cells / mean HIP-event duration of the call, vs 8 TB/s HBM peak; beside it the two floors of the
+               call: hbm_floor_ms (algorithmic bytes at 8 TB/s) and valu_floor_ms (VALU wave-instructions x 4 cycles / 1024 SIMDs /
+               2.4 GHz, from the committed SQ-counter pass) -- the kernel is bound by whichever is larger
   cpu_baseline the numpy oracle on the host cores on a bounded sample: a C48 L79 cube, one pinned single-threaded process
                per tile (6 processes), a few acoustic sub-steps, scaled per cell to the C768 step -- baseline only
   operators    per-operator mean milliseconds per acoustic sub-step (HIP events recorded by fv3_acoustic_step)
@@ -312,6 +314,13 @@ def main():
             if os.path.exists(tj) and a.config == "c768" and world == 1 and a.precision == 64 and not a.nz:
                 tr = json.load(open(tj))
                 traffic, traffic_src = tr["bytes"], "profiles/traffic_d_sw.json (" + tr["source"] + ")"
+            # second roof: the VALU-issue floor of the same call (sum of VALU wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz) from the
+            # committed SQ-counter pass (profiles/valu_d_sw.json, tools/prof_sq.sh) -- d_sw cannot go below it however well memory overlaps
+            valu_floor, valu_src = None, None
+            vj = os.path.join(ROOT, "profiles", "valu_d_sw.json")
+            if os.path.exists(vj) and a.config == "c768" and world == 1 and a.precision == 64 and not a.nz:
+                vr = json.load(open(vj))
+                valu_floor, valu_src = vr["valu_floor_ms"], "profiles/valu_d_sw.json (" + vr["source"] + ")"
             line["roofline"] = {
                 "kernel": "d_sw (all launches of one fv3_d_sw call)",
                 "bound": "hbm",
@@ -323,6 +332,9 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_call": alg,
                 "ms_per_call": op_ms["d_sw"],
+                "hbm_floor_ms": alg / (HBM_PEAK_GBPS * 1e9) * 1e3,
+                "valu_floor_ms": valu_floor,
+                "valu_floor_source": valu_src,
             }
         # the same fraction for every operator with a pass count in SURVEY §8a (algorithmic bytes per cell = passes x sizeof(Real))
         passes = {"c_sw": 15, "update_dz_c": 4, "riem_solver_c": 8, "p_grad_c": 7, "d_sw": D_SW_PASSES, "update_dz_d": 6, "riem_solver3": 11, "nh_p_grad": 8}

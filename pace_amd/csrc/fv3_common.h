@@ -88,6 +88,23 @@ inline void fv3_stamp_touch(unsigned long long *, unsigned long long, int) {}
 #define FV3_STAMP_FLUSH(buf, kid, tid) ((void)0)
 #endif
 
+// Stores of the marching kernels: `if (owned) field[p] = v;`.  Because the block is conditional the compiler's wait for the rows
+// requested BEFORE the stores of a step (one in-order memory counter) has to assume none was issued: the wait at the top of every
+// step is `s_waitcnt vmcnt(0)`.  Round 4 measured the alternative -- every store issued, unowned lanes / rows writing to a per-wave
+// row of a sink buffer (c->trash), so that the compiler counts and the wait becomes vmcnt(number of stores) (-DFV3_USTORE; checked
+// in the ISA: vmcnt(7) / vmcnt(2) at the top of the two-tracer marches): d_sw 52.6 vs 52.6 ms, update_dz_d 11.2 vs 11.1 on the same
+// box -- the stores are acknowledged long before the rows arrive, the drain costs nothing.  The conditional form is the default.
+#define FV3_TRASH_SLOTS 4096
+FV3_HD inline void fv3_store_sel(Real *owned_dst, Real *sink, bool owned, Real v) {
+#ifdef FV3_USTORE
+  Real *d = owned ? owned_dst : sink;
+  *d = v;
+#else
+  if (owned) *owned_dst = v;
+  (void)sink;
+#endif
+}
+
 // scheduling fence (no instruction): the compiler may not move code across it.  The branch-free marches (PPM order as a constant)
 // otherwise overlap the sweeps of a step until the register file overflows (12 - 14 spilled VGPRs); fenced at the points where the
 // branchy form had its basic-block ends they fit again.
@@ -193,6 +210,8 @@ struct fv3_ctx {
   void *xfer_user = nullptr;
   fv3_halo_plan *halo_plans[FV3_HALO_COUNT] = {nullptr};
   Real *ak_dev = nullptr, *bk_dev = nullptr;  // hybrid-coordinate tables on the device (fv3_remap.hip)
+  // Sink for the stores of lanes / rows a marching wave does not own (-DFV3_USTORE experiment builds only; see fv3_store_sel)
+  Real *trash = nullptr;
   // Ping-pong of the four scalars d_sw rewrites (delp, pt, w, q_con; fv3_step.hip): d_sw's marches read the old fields through
   // their halo columns / rows while they produce the new ones, so they write beside them.  Inside fv3_acoustic_step the new
   // fields simply BECOME the state for the operators that follow (no copy-back); every second sub-step lands in the caller's

@@ -363,6 +363,13 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   }
   // (the alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong are allocated by the first call that can use
   //  them: fv3_pp_ensure -- operator-level contexts and runs with a halo callback never pay for them)
+#ifdef FV3_USTORE
+  c->trash = (Real *)fv3_dev_alloc(c, (size_t)FV3_TRASH_SLOTS * FV3_WAVE * sizeof(Real));
+  if (!c->trash) {
+    fv3_ctx_destroy(c);
+    return fv3_fail(nullptr, FV3_ERR_NOMEM, "device allocation of the store sink failed");
+  }
+#endif
   {
     Geo *gd = (Geo *)fv3_dev_alloc(c, sizeof(Geo));
     if (!gd) {

@@ -7,7 +7,7 @@
 // instruction counts from `hipcc -S`).  The arguments here are pressures in Pa, ratios of pressures and their powers: positive,
 // normal, finite.  fv3_log is the classic argument reduction to [sqrt(2)/2, sqrt(2)) + the degree-14 odd series in
 // s = f / (2 + f) (Sun fdlibm / musl e_log.c coefficients, error < 1 ulp), ~40 instructions; anything outside the positive
-// normal range takes the libm call (a wave-uniform branch that the solvers never take).  fv3_exp: see below.
+// normal range is handled like libm does (special values, subnormals scaled up) in a branch the solvers never take.  fv3_exp: below.
 // Same source on the device and in the host emulation: with -ffp-contract=off both give the same bits, so the host-emulation
 // parity suite keeps checking the device arithmetic.  Accuracy is pinned against 80-bit logl over the solvers' argument range
 // by tests/test_fast_math.py (<= 1 ulp).  -DFV3_LIBM_MATH selects the libm calls (A/B).
@@ -22,10 +22,19 @@ FV3_HD inline double fv3_log_f64(double x) {
   uint64_t ix;
   memcpy(&ix, &x, sizeof(ix));
   uint32_t hx = (uint32_t)(ix >> 32);
-  if (hx - 0x00100000u >= 0x7fe00000u) return log(x);  // zero, subnormal, negative, inf, nan: libm's answer
+  int k = 0;
+  if (hx - 0x00100000u >= 0x7fe00000u) {  // zero, subnormal, negative, inf, nan (the solvers never get here)
+    if (x != x || x < 0.0) return (x - x) / (x - x);  // nan
+    if (x == 0.0) return -HUGE_VAL;
+    if (hx >= 0x7ff00000u) return x;  // +inf
+    x *= 0x1p54;                      // subnormal: scale up
+    k = -54;
+    memcpy(&ix, &x, sizeof(ix));
+    hx = (uint32_t)(ix >> 32);
+  }
   // x = 2^k * m, m in [sqrt(2)/2, sqrt(2))
   hx += 0x3ff00000u - 0x3fe6a09eu;
-  const int k = (int)(hx >> 20) - 0x3ff;
+  k += (int)(hx >> 20) - 0x3ff;
   hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
   ix = ((uint64_t)hx << 32) | (ix & 0xffffffffu);
   double m;
@@ -42,11 +51,11 @@ FV3_HD inline double fv3_log_f64(double x) {
   return s * (hfsq + R) + dk * 1.90821492927058770002e-10 - hfsq + f + dk * 6.93147180369123816490e-01;
 }
 
-// exp(x) for |x| <= 700 (the solvers stay within +-20): x = k ln2 + r, |r| <= ln2 / 2 (two-term ln2, the product k * ln2_hi is
-// exact for |k| < 2^11), exp(r) by its Taylor polynomial of degree 13 in Horner form (remainder 4e-18 relative), scaled by 2^k.
-// ~20 instructions (libm's: ~35).  Anything else (overflow / underflow range, nan) takes the libm call.
+// exp(x) (the solvers stay within +-20): x = k ln2 + r, |r| <= ln2 / 2 (two-term ln2, the product k * ln2_hi is exact for
+// |k| < 2^11), exp(r) by its Taylor polynomial of degree 13 in Horner form (remainder 4e-18 relative), scaled by 2^k with ldexp
+// (which rounds into the subnormal range / overflows to inf by itself).  ~20 instructions (libm's: ~35).
 FV3_HD inline double fv3_exp_f64(double x) {
-  if (!(fabs(x) <= 700.0)) return exp(x);
+  if (!(fabs(x) <= 745.0)) return x != x ? x : (x > 0.0 ? HUGE_VAL : 0.0);  // (ldexp below covers the gradual over / underflow up to there)
   const double kf = rint(x * 1.44269504088896338700e+00);
   const double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
   double p = 1.0 / 6227020800.0;

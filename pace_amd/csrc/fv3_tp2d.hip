@@ -511,11 +511,17 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 // pointers and branches it uses (the all-features kernel sat at 256 VGPRs with scratch and 131 spilled SGPRs).
 enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND = 32, TF_WFLUX = 64, TF_ACC = 128, TF_ALL = 255, TF_FD = 256 };
 
-// HC: 0 = run-time PPM order; 6 = the order is that constant (see dsw_scalars_t in fv3_tp4.hip)
-template <unsigned FEAT, int HC = 0>
+// HC: 0 = run-time PPM order; 6 = the order is that constant (see dsw_scalars_t in fv3_tp4.hip).
+// FA ("all on", FD instantiations only): the caller's contract for epi->fd != 0 -- every level k0..k1 has its del-n chain switched on,
+// and the wind form comes with wind_u_pre / wind_v_pre -- is taken as a compile-time fact on the strips away from the W / E tile
+// edges: the chain / damping / epilogue tests fold away, every store of a step is issued (unowned lanes / rows write to the sink:
+// fv3_store_sel) and ke(i+1, jf) / ke(i, jr) come from the neighbouring lane / the previous step instead of two more loads.
+template <unsigned FEAT, int HC = 0, bool FA = false>
 static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
                         const Real *mfx, const Real *mfy, const Real *mass, int hord_, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   const int hord = HC ? HC : hord_;
+  static_assert(!FA || (FEAT & TF_FD), "FA is a property of the FD instantiations");
+  Real *const trash = c->trash;
   const Geo g = c->g;
   Real *dfx = c->scratch[SC_DN_FX], *dfy = c->scratch[SC_DN_FY];
   const bool damped = dn != nullptr;
@@ -636,11 +642,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     Real fxk[FV3_LPT], fyp[FV3_LPT], era[FV3_LPT], emu[FV3_LPT];  // epilogue: fx(r-3), fy(face r-3), rarea / mult at row r-3
     Real xjr[FV3_LPT], ypp[FV3_LPT];  // xfx(i, r-3), yfx(i, r-3) (area-form epilogue)
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // damping fluxes around the cell (i, r-3)
-    const bool zdamp = C_AREA && zfx && zon[k] > (Real)1.0e-5;
-    const bool wdamp = C_WIND && wind_du != nullptr && wind_don[k] > (Real)1.0e-5;
+    const bool zdamp = C_AREA && (FA || (zfx && zon[k] > (Real)1.0e-5));
+    const bool wdamp = C_WIND && (FA || (wind_du != nullptr && wind_don[k] > (Real)1.0e-5));
     // FD: the del-n chain of q inside the march (strips away from the W / E tile edges); see dsw_scalars_t in fv3_tp4.hip
     constexpr bool C_FD = (FEAT & TF_FD) != 0;
-    const bool fdm = C_FD && fd_on && (C_AREA ? zdamp : wdamp) && !(W || E);
+    const bool fdm = C_FD && (FA || fd_on) && (C_AREA ? zdamp : wdamp) && !(W || E);
+    Real *const sink0 = trash + (size_t)(((unsigned)blk_.bx + 61u * (unsigned)blk_.by + 127u * (unsigned)blk_.bz) & (FV3_TRASH_SLOTS - 1)) * FV3_WAVE;
     const Real dcoef = fdm ? fd_coef[k] : (Real)0;
     Real sd0[FV3_LPT], sd1[FV3_LPT], sd2[FV3_LPT], gx0[FV3_LPT], gx1[FV3_LPT], gy0[FV3_LPT], gy1[FV3_LPT], dxd[FV3_LPT], dxn[FV3_LPT], dyf[FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
     Real mdu_n[FV3_LPT], mdv_n[FV3_LPT], mra_n[FV3_LPT];
@@ -733,6 +740,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     auto march = [&](auto xe_tag) {
       constexpr bool XE = decltype(xe_tag)::value;
       constexpr bool LX = XE || TS_LDS_ONLY;  // neighbour reads through the LDS lines (tile-edge strips; TS_LDS_ONLY: everywhere, the A/B form)
+      constexpr bool UST = FA && !XE;         // unconditional stores, derived ke values (strips away from the W / E tile edges)
       auto step = [&](int r) {
         FV3_STAMP(0);
         const int r3 = r - 3 < jsd ? jsd : r - 3;
@@ -786,11 +794,12 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             if (wind_u_) {
               wu[l] = (wind_u_ + b)[pf];
               wdx[l] = (gdx + m2)[pf];
+              if constexpr (UST) wkr[l] = wkf[l];  // ke(i, jr) = the ke(i, jf) of the previous step (jr = jf - 1)
               wkf[l] = (wind_ke_ + b)[pf];      // ke(i, jf) -- also ke(i, jr + 1)
-              wke[l] = (wind_ke_ + b)[pf + 1];  // ke(i + 1, jf)
+              if constexpr (!UST) wke[l] = (wind_ke_ + b)[pf + 1];  // ke(i + 1, jf)  (UST: the neighbouring lane's wkf, below)
               wv[l] = (wind_v_ + b)[p3];
               wdy[l] = (gdy + m2)[p3];
-              wkr[l] = (wind_ke_ + b)[p3];      // ke(i, jr)
+              if constexpr (!UST) wkr[l] = (wind_ke_ + b)[p3];      // ke(i, jr)
               if (wdamp && !(C_FD && fdm)) {
                 wdu[l] = (wind_du_ + b)[pf];
                 wdv[l] = (wind_dv_ + b)[p3];
@@ -933,8 +942,13 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
                 wdv[l] = ox;
                 wdu[l] = oy;
                 const int jr_ = r - 3, jf_ = r - 2;
-                if (jr_ >= ja && jr_ <= jb && jr_ <= ny && own_x[l]) (const_cast<Real *>(wind_dv_) + b)[pcol[l] + (unsigned)(jr_ * sj32)] = ox;
-                if (jf_ >= ja && jf_ <= jb && own_y[l]) (const_cast<Real *>(wind_du_) + b)[pcol[l] + (unsigned)(jf_ * sj32)] = oy;
+                if constexpr (UST) {
+                  fv3_store_sel((const_cast<Real *>(wind_dv_) + b) + (pcol[l] + (unsigned)(jr_ * sj32)), sink0 + lane, jr_ >= ja && jr_ <= jb && jr_ <= ny && own_x[l], ox);
+                  fv3_store_sel((const_cast<Real *>(wind_du_) + b) + (pcol[l] + (unsigned)(jf_ * sj32)), sink0 + lane, jf_ >= ja && jf_ <= jb && own_y[l], oy);
+                } else {
+                  if (jr_ >= ja && jr_ <= jb && jr_ <= ny && own_x[l]) (const_cast<Real *>(wind_dv_) + b)[pcol[l] + (unsigned)(jr_ * sj32)] = ox;
+                  if (jf_ >= ja && jf_ <= jb && own_y[l]) (const_cast<Real *>(wind_du_) + b)[pcol[l] + (unsigned)(jf_ * sj32)] = oy;
+                }
               }
               dxd[l] = dxn[l];
             }
@@ -974,7 +988,13 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               (fx + b)[p] = v;
               if (acc_x_) (acc_x_ + b)[p] = o_ax[l] + v;
             }
-            if (wind_v_ && fx_row && own_x[l]) {
+            if constexpr (UST && C_WIND) {
+              const unsigned p = pcol[l] + (unsigned)(jr * sj32);
+              const bool ok = fx_row && own_x[l];
+              const Real vn = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
+              fv3_store_sel((wind_v_pre_ + b) + p, sink0 + lane, ok, vn);
+              fv3_store_sel((wind_v_ + b) + p, sink0 + lane, ok, vn - wdv[l]);
+            } else if (wind_v_ && fx_row && own_x[l]) {
               const unsigned p = pcol[l] + (unsigned)(jr * sj32);
               const Real vn = wv[l] * wdy[l] + wkr[l] - wkf[l] - v;
               if (wind_v_pre_) (wind_v_pre_ + b)[p] = vn;
@@ -1067,7 +1087,14 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
               (fy + b)[p] = v;
               if (acc_y_) (acc_y_ + b)[p] = o_ay[l] + v;
             }
-            if (wind_u_ && fy_row && own_y[l]) {
+            if constexpr (UST && C_WIND) {
+              const unsigned p = pcol[l] + (unsigned)(jf * sj32);
+              const bool ok = fy_row && own_y[l];
+              const Real ke_e = FV3_LANE_SHL(1, wkf, l, lane);  // ke(i + 1, jf): the neighbouring lane loaded it as its ke(i, jf)
+              const Real un = wu[l] * wdx[l] + wkf[l] - ke_e + v;
+              fv3_store_sel((wind_u_pre_ + b) + p, sink0 + lane, ok, un);
+              fv3_store_sel((wind_u_ + b) + p, sink0 + lane, ok, un + wdu[l]);
+            } else if (wind_u_ && fy_row && own_y[l]) {
               const unsigned p = pcol[l] + (unsigned)(jf * sj32);
               const Real un = wu[l] * wdx[l] + wkf[l] - wke[l] + v;
               if (wind_u_pre_) (wind_u_pre_ + b)[p] = un;
@@ -1075,7 +1102,14 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
             }
             if (epi_out_) {
               // flux-form update of the cell (i, r-3): its west / south fluxes are fxk / fyp, east from lane + 1, north = v
-              if (fx_row && own_y[l]) {
+              if constexpr (UST && C_AREA) {
+                const Real qc = w2[l];  // q(i, r-3)
+                const Real ar_ = RG(RG_AR, r - 3)[lane];
+                const Real ra_x = ar_ + xjr[l] - xje, ra_y = ar_ + ypp[l] - cur[l].yv;
+                Real z = (qc * ar_ + fxk[l] - fxe + fyp[l] - v) / (ra_x + ra_y - ar_);
+                z = z + (zx0[l] - zx1[l] + zy0[l] - zy1[l]) * era[l];
+                fv3_store_sel((epi_out_ + b) + (pcol[l] + (unsigned)(jr * sj32)), sink0 + lane, fx_row && own_y[l], z);
+              } else if (fx_row && own_y[l]) {
                 const Real qc = w2[l];  // q(i, r-3)
                 const Real mu = epi_mult_ ? (epi_mult_ == mass_ ? mb[l] : emu[l]) : (Real)1;
                 if (area_form_) {
@@ -1115,7 +1149,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       // Measured on MI355X: 1.5 % -- with every load of the march redirected to one cached row the kernel is
       // still 6 of its 8.3 ms, i.e. the march is bound by its own issue + LDS-exchange latency at 2 waves / SIMD,
       // not by HBM latency (prefetching the optional inputs as well, at one or two steps, changed nothing).
-      if constexpr (XE) {
+      // (the FA instantiation of the wind form: rolled too -- unrolled it spilled 15 - 17 registers: d_sw 53.1 -> 52.1 ms rolled; the
+      //  area form has the registers and is faster unrolled: update_dz_d 11.15 ms against 11.6 rolled -- same-box A/B, round 4)
+      constexpr bool ROLLED = XE || (FA && C_WIND);
+      if constexpr (ROLLED) {
         for (int r = ja - 3; r <= r_end; ++r) step(r);
       } else {
         // (trailing steps past r_end: their loads are clamped to r_end and every store is masked by the
@@ -1157,13 +1194,21 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     return;
   // the two big launches of the acoustic sub-step with the PPM order as a constant (reference default 6; FV3_HORD_CONST=0: A/B)
   static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
-  if (hord == 6 && !hc_off) {
+  // (FA: what the two callers of the FD forms guarantee -- fv3_update_dz_d / fv3_d_sw_out pass only levels whose chain is on)
+  static const bool fa_off = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
+  if (hord == 6 && !hc_off && !TS_LDS_ONLY) {
     if (m == (TF_EPI | TF_AREA | TF_FD)) {
-      tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      if (!fa_off && epi->area_form && epi->zfx && epi->out)
+        tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      else
+        tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       return;
     }
     if (m == (TF_WIND | TF_FD)) {
-      tp2d_stream_t<(TF_WIND | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      if (!fa_off && epi->wind_du && epi->wind_u_pre && epi->wind_v_pre)
+        tp2d_stream_t<(TF_WIND | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
+      else
+        tp2d_stream_t<(TF_WIND | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       return;
     }
   }

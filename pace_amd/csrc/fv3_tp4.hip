@@ -126,6 +126,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   const size_t smem_lines = DPP ? 0 : (size_t)(Q4_NT * (2 * Q4_LINE + 2 * (FV3_WAVE + 1)) + 2 * (FV3_WAVE + 1) + 32);
   const size_t smem = sizeof(Real) * (smem_lines + (size_t)FDL * (FV3_WAVE + 2) + (size_t)NRING * 4 * FV3_WAVE);
   const Geo *gp = c->g_dev;
+  Real *const trash = c->trash;
   const int nh = g.nh, sj32 = g.sj32, go = g.o;
   const int LS = TR ? sj32 : 1, MS = TR ? 1 : sj32;  // element strides of one step along L / along M
   const long st = g.st, sk = g.sk, st2 = g.st2;
@@ -245,6 +246,10 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
     // them leaves the prefetched rows in flight)
     Real o_ax[FV3_LPT], o_ay[FV3_LPT];                  // accumulated mass fluxes (AIR / QUAD)
     Real o_mx[FV3_LPT], o_my[FV3_LPT], o_mc[FV3_LPT], o_dn[FV3_LPT], mbk[FV3_LPT];  // TRC: air-mass fluxes, old delp(lc, r-2) / (lc, r-3), new delp(lc, r-3)
+    // ... of the NEXT step.  These inputs are consumed at the end of a step; requested at the top of the same step the wait for
+    // them (one in-order memory counter, and the compiler orders the loads of a step as it likes) drained the row prefetch in
+    // phase 2 of every step.  Requested one step ahead they are covered by the wait at the top of the step, like the rows.
+    Real n_ax[FV3_LPT], n_ay[FV3_LPT], n_mx[FV3_LPT], n_my[FV3_LPT], n_mc[FV3_LPT], n_dn[FV3_LPT];
     Real o_dx[Q4_NT][FV3_LPT], o_dy[Q4_NT][FV3_LPT];    // damping fluxes along L / M (w's enter as an increment instead)
     Real era[FV3_LPT];                                  // rarea(lc, r-3)
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // w's damping fluxes around the cell (lc, r-3): x, x + 1, y, y + 1
@@ -261,6 +266,14 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
     Real sqx[Q4_NT][FV3_LPT], sqi[Q4_NT][FV3_LPT], smb[FV3_LPT], sxv[FV3_LPT];  // DPP form: the values the neighbouring lanes read (q on the new row, the M-advected q, old delp, L area flux)
     unsigned pcol[FV3_LPT];  // in-plane offset of (lc, M coordinate 0)
     bool own_x[FV3_LPT], own_y[FV3_LPT];
+    // (-DFV3_USTORE experiment builds: on the interior strips every store of a step is issued, unowned lanes / rows write to the
+    //  wave's row of the sink -- fv3_store_sel in fv3_common.h has the measurement)
+#ifdef FV3_USTORE
+    constexpr bool UST = PART == Q4_INTERIOR;
+#else
+    constexpr bool UST = false;
+#endif
+    Real *const sink0 = trash + (size_t)(((unsigned)blk_.bx + 61u * (unsigned)blk_.by + 127u * (unsigned)blk_.bz) & (FV3_TRASH_SLOTS - 1)) * FV3_WAVE;
     // FD: the chain's state.  sd0 / sd1 / sd2: d2 of iterations 0 / 1 / 2 on rows r / r-1 / r-2 (read by lane + 1, and at the next
     // step as the row below); gx0 / gx1: L fluxes of iterations 0 / 1 on rows r / r-1 (read by lane - 1 at the next step);
     // gy0 / gy1: their M fluxes at faces r / r-1; dxd: the final L flux of row r-3; dyf: the final M flux of face r-2 (this step);
@@ -291,6 +304,20 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
         if (have) w.em = metLb[pbase + (unsigned)(sc * LS + r * MS)];
       }
       return w;
+    };
+    // the inputs step r consumes at its end (rows r-3 / faces r-2), into the n_* registers
+    auto load_opt = [&](int r, int l) {
+      const int r3 = r - 3 < Msd ? Msd : r - 3, rf = r - 2 < Msd ? Msd : r - 2;
+      const unsigned p3 = pcol[l] + (unsigned)(r3 * MS), pf = pcol[l] + (unsigned)(rf * MS);
+      if constexpr (HAS_AIR) {
+        n_ax[l] = (a.mfx + b)[p3];
+        n_ay[l] = (a.mfy + b)[pf];
+      } else {
+        n_mx[l] = (a.fx + b)[p3];
+        n_my[l] = (a.fy + b)[pf];
+        n_mc[l] = (a.delp + b)[pf];
+        n_dn[l] = (a.o_delp + b)[p3];
+      }
     };
     FV3_LANES(blk, lane, l) {
       const int lc = l0 - 3 + lane, lcc = lc < Led ? lc : Led;
@@ -345,6 +372,9 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
         mdv_n[l] = d6Lb[pm];
         mra_n[l] = rab[pm];
       }
+      n_ax[l] = n_ay[l] = n_mx[l] = n_my[l] = n_mc[l] = (Real)0;
+      n_dn[l] = (Real)1;
+      load_opt(ca - 3, l);
       nxt[l] = load_row(ca - 3, l, lane);
       nx2[l] = load_row(ca - 2 < r_end ? ca - 2 : r_end, l, lane);
       if constexpr (!DPP) {
@@ -369,8 +399,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             const int rf = r - 2 < Msd ? Msd : r - 2;
             const unsigned p3 = pcol[l] + (unsigned)(r3 * MS), pf = pcol[l] + (unsigned)(rf * MS);
             if constexpr (HAS_AIR) {
-              o_ax[l] = (a.mfx + b)[p3];
-              o_ay[l] = (a.mfy + b)[pf];
+              o_ax[l] = n_ax[l];
+              o_ay[l] = n_ay[l];
               if constexpr (!FD) {
                 if (on_vt) {
                   o_dx[0][l] = (a.dpx + b)[p3];
@@ -384,11 +414,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                 }
               }
             } else {
-              o_mx[l] = (a.fx + b)[p3];
-              o_my[l] = (a.fy + b)[pf];
-              o_mc[l] = (a.delp + b)[pf];
-              o_dn[l] = (a.o_delp + b)[p3];
+              o_mx[l] = n_mx[l];
+              o_my[l] = n_my[l];
+              o_mc[l] = n_mc[l];
+              o_dn[l] = n_dn[l];
             }
+            load_opt(r + 1 < r_end ? r + 1 : r_end, l);
             if constexpr (ROLE != Q4_AIR && !FD) {
               constexpr int nq = ROLE == Q4_QUAD ? 2 : 0, np_ = nq + 1;  // slots of q_con / pt
               if (on_vt) {
@@ -630,7 +661,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             if constexpr (id == 0) {  // air mass: area-flux weighted, plain damping flux
               Real v = (Real)0.5 * (fxout[n] + fi3[n][l]) * xv3[l];
               if (on_vt) v = v + o_dx[n][l];
-              if (fx_row && own_x[l]) {
+              if constexpr (UST) {
+                const unsigned p = pcol[l] + (unsigned)(jr * MS);
+                const bool ok = fx_row && own_x[l];
+                fv3_store_sel((a.mfx + b) + p, sink0 + lane, ok, o_ax[l] + v);
+                if constexpr (ROLE == Q4_AIR) fv3_store_sel((a.fx + b) + p, sink0 + lane, ok, v);
+              } else if (fx_row && own_x[l]) {
                 const unsigned p = pcol[l] + (unsigned)(jr * MS);
                 (a.mfx + b)[p] = o_ax[l] + v;
                 if constexpr (ROLE == Q4_AIR) (a.fx + b)[p] = v;
@@ -740,7 +776,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             if constexpr (id == 0) {
               Real v = (Real)0.5 * (fyout[n] + fyin[n][l]) * cur[l].yv;
               if (on_vt) v = v + o_dy[n][l];
-              if (fy_row && own_y[l]) {
+              if constexpr (UST) {
+                const unsigned p = pcol[l] + (unsigned)(jf * MS);
+                const bool ok = fy_row && own_y[l];
+                fv3_store_sel((a.mfy + b) + p, sink0 + lane, ok, o_ay[l] + v);
+                if constexpr (ROLE == Q4_AIR) fv3_store_sel((a.fy + b) + p, sink0 + lane, ok, v);
+              } else if (fy_row && own_y[l]) {
                 const unsigned p = pcol[l] + (unsigned)(jf * MS);
                 (a.mfy + b)[p] = o_ay[l] + v;
                 if constexpr (ROLE == Q4_AIR) (a.fy + b)[p] = v;
@@ -770,10 +811,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             else
               zx1[l] = lzx[lane + 1];
           }
-          if (fx_row && own_y[l]) {
+          const bool cell_ok = fx_row && own_y[l];
+          if (UST || cell_ok) {
             // flux-form updates of the cell (lc, r-3): low L / M fluxes fxk / fyp, high L flux from lane + 1, high M flux = vy
             // (x terms first, as the reference writes the divergence)
             const unsigned p = pcol[l] + (unsigned)(jr * MS);
+            Real *const sk = sink0 + lane;
             Real up[Q4_NT];
             Q4_EACH(n)
               const Real fe = fxe[n];  // L flux of the high L face: the neighbouring lane's
@@ -783,7 +826,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             const Real dpn = HAS_AIR ? up[0] : o_dn[l];  // new air mass of the cell
             Q4_EACH(n)
               if constexpr (id == 0) {
-                (a.o_delp + b)[p] = dpn;
+                fv3_store_sel((a.o_delp + b) + p, sk, cell_ok, dpn);
               } else if constexpr (id == 1) {
                 Real wn = up[n] / dpn, hs = (Real)0;
                 if (on_w) {
@@ -791,12 +834,12 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                   hs = dd8 - dwv * (w2[n][l] + (Real)0.5 * dwv);
                   wn = wn + dwv;
                 }
-                (a.o_w + b)[p] = wn;
-                (a.heat + b)[p] = hs;
+                fv3_store_sel((a.o_w + b) + p, sk, cell_ok, wn);
+                fv3_store_sel((a.heat + b) + p, sk, cell_ok, hs);
               } else if constexpr (id == 2) {
-                (a.o_q_con + b)[p] = up[n] / dpn;
+                fv3_store_sel((a.o_q_con + b) + p, sk, cell_ok, up[n] / dpn);
               } else {
-                (a.o_pt + b)[p] = up[n] / dpn;
+                fv3_store_sel((a.o_pt + b) + p, sk, cell_ok, up[n] / dpn);
               }
             Q4_END
           }
@@ -872,8 +915,10 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
     if (s2 != s) fv3_signal(c, s2, 3);
     // (the big launches: the instantiation with the PPM order as a constant when the configuration has the reference's 6 everywhere;
     //  FV3_HORD_CONST=0 keeps the run-time form -- A/B, same values)
-    static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
-    if (!hc_off && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6) {
+    //  Measured: -0.15 ms of d_sw for 12 spilled VGPRs in the two-tracer marches (the branch-free limiter needs ~24 more registers):
+    //  off by default here (FV3_HORD_CONST=1 selects it), on in the single-tracer marches of fv3_tp2d.hip.
+    static const bool hc_on = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '1';
+    if (hc_on && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6) {
       dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
       if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
       dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);

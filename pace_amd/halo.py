@@ -142,6 +142,7 @@ class HaloExchanger:
         # (the factory keeps the exchanger -- `shared` -- so the way back is weak: a strong reference would close a cycle and the
         #  context's device memory would wait for the cycle collector instead of going when the last user drops the factory)
         self._sf_ref = weakref.ref(sf)
+        self._sf_proxy = weakref.proxy(sf)  # what the exchanger's own plan objects hold (they live and die with the exchanger)
         self.layout = layout
         self.part = layout.part
         self.group = group
@@ -359,14 +360,14 @@ class HaloExchanger:
                     recv.setdefault(o, []).append((int(m.dst_comp[e]), doff))
         for k, (d, s_, g) in loc.items():
             if d:
-                ph.local[k] = _Plan(self.sf, d, s_, g)
+                ph.local[k] = _Plan(self._sf_proxy, d, s_, g)
         for peer, items in recv.items():
             ph.recv_count[peer] = len(items)
             ph.recv[peer] = {}
             for comp in range(ncomp):
                 idx = [i for i, (cc, _) in enumerate(items) if cc == comp]
                 if idx:
-                    ph.recv[peer][comp] = _Plan(self.sf, [items[i][1] for i in idx], idx, [1] * len(idx))
+                    ph.recv[peer][comp] = _Plan(self._sf_proxy, [items[i][1] for i in idx], idx, [1] * len(idx))
         # what the peers need from me: walk their maps in the same (rank, entry) order
         if lay.world_size > 1:
             send = {}
@@ -385,7 +386,7 @@ class HaloExchanger:
                 for comp in range(ncomp):
                     idx = [i for i, (cc, _, _) in enumerate(items) if cc == comp]
                     if idx:
-                        ph.send[peer][comp] = _Plan(self.sf, idx, [items[i][1] for i in idx], [items[i][2] for i in idx])
+                        ph.send[peer][comp] = _Plan(self._sf_proxy, idx, [items[i][1] for i in idx], [items[i][2] for i in idx])
         self._phases[pkey] = ph
         return ph
 

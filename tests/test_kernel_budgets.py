@@ -17,23 +17,27 @@ Q4_AIR, Q4_TRC, Q4_INTERIOR = 1, 2, 1
 TF_EPI, TF_AREA, TF_WIND, TF_FD = 8, 16, 32, 256
 
 
-def _q4(role, part, m8, fd):
-    return f"dsw_scalars_tILi{role}ELi{part}ELb{int(m8)}ELb{int(fd)}E"
+def _q4(role, part, m8, fd, hc=0):
+    return f"dsw_scalars_tILi{role}ELi{part}ELb{int(m8)}ELb{int(fd)}ELi{hc}E"
 
 
-def _tp(feat):
-    return f"tp2d_stream_tILj{feat}E"
+def _tp(feat, hc=0, fa=False):
+    return f"tp2d_stream_tILj{feat}ELi{hc}ELb{int(fa)}E"
 
 
 # (substrings that identify the kernel, kernels expected to match, VGPR limit, spilled-VGPR limit, scratch-byte limit)
 BUDGETS = [
     ((_q4(Q4_AIR, Q4_INTERIOR, False, True),), 1, 256, 0, 0),   # delp + w march, interior strips, del-n chain inside: two waves / SIMD
     ((_q4(Q4_TRC, Q4_INTERIOR, False, True),), 1, 256, 0, 0),   # q_con + pt march, likewise
+    ((_q4(Q4_AIR, Q4_INTERIOR, False, True, 6),), 1, 256, 32, 128),  # ... with the PPM order as a constant (opt-in, FV3_HORD_CONST=1): spills, measured neutral
+    ((_q4(Q4_TRC, Q4_INTERIOR, False, True, 6),), 1, 256, 32, 128),
     ((_q4(Q4_AIR, Q4_INTERIOR, False, False),), 1, 256, 0, 0),  # the same marches without the chain (sponge layers)
     ((_q4(Q4_TRC, Q4_INTERIOR, False, False),), 1, 256, 0, 0),
     ((_q4(Q4_TRC, Q4_INTERIOR, True, False),), 1, 256, 0, 0),   # tracer pairs, hord 8
-    ((_tp(TF_EPI | TF_AREA | TF_FD),), 1, 256, 0, 0),           # interface-height transport (area form + del-n chain)
-    ((_tp(TF_WIND | TF_FD),), 1, 256, 8, 32),                   # vorticity transport + wind epilogue + del-n chain: AT the limit (documented: 4 - 8 spilled)
+    ((_tp(TF_EPI | TF_AREA | TF_FD, 6, True),), 1, 256, 0, 0),  # interface-height transport, product form (order constant, chain always on)
+    ((_tp(TF_WIND | TF_FD, 6, True),), 1, 256, 0, 0),           # vorticity transport + wind epilogue, product form (rolled: no spill)
+    ((_tp(TF_EPI | TF_AREA | TF_FD),), 1, 256, 0, 0),           # ... the general forms (run-time order / flags)
+    ((_tp(TF_WIND | TF_FD),), 1, 256, 8, 32),                   # AT the limit (documented: 4 - 8 spilled)
     (("csw_fused_stream", "fv3_kwgILi2ELi4E"), 1, 256, 0, 0),   # c_sw interior march
     (("nh_pgf_fused", "fv3_kwILi2E"), 1, 256, 0, 0),            # fused nh_p_grad march
     (("ke_stream", "fv3_kwILi4E"), 1, 128, 0, 0),               # corner kinetic energy: four waves / SIMD

@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_AC
 cd "$R"
 python tools/summarize_rocprof.py "$out/stats/s_kernel_stats.csv" 40 > "$out/kernel_stats.md" 2>&1
 python tools/pmc_sq.py "$out/pmc_a/p_counter_collection.csv" "" 30 > "$out/sq_a.md" 2>&1
+python tools/pmc_sq.py --valu-window "$out/pmc_a/p_counter_collection.csv" fxadv "fv3_d_sw_out#" "$out/valu_d_sw.json" > "$out/valu_d_sw.log" 2>&1
 python tools/pmc_sq.py "$out/pmc_b/p_counter_collection.csv" "" 30 > "$out/sq_b.md" 2>&1
 find "$out" -name "*kernel_trace.csv" -delete
 find "$out" -name "*counter_collection.csv" -delete
