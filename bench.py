@@ -164,6 +164,21 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     group = None
+    # Test hook for a 1-GPU box (tests/test_gpu_invariants.py): FV3_BENCH_FORCE_PG=1 with WORLD_SIZE=1 creates the torch process group
+    # of ONE rank in the order and with the arguments of a real N-GPU launch and runs the N-GPU teardown at the end; with
+    # --emulate-share N and FV3_LOOPBACK_TRANSPORT=rccl the library's own one-rank RCCL communicator then lives beside torch's, is
+    # created after it and destroyed before it -- the init-order / teardown sequence of the 8-GPU run, minus the peers.
+    force_pg = world == 1 and os.environ.get("FV3_BENCH_FORCE_PG") == "1"
+    if force_pg:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if world > 1:
         import torch.distributed as dist
 
@@ -356,7 +371,7 @@ def main():
             }
         _flush_c_stdio()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         import gc
 
         import torch.distributed as dist

@@ -198,4 +198,6 @@ class OracleAcousticDynamics:
                 s, t, D = states[r], self.tmp[r], self.doms[r]
                 hs = t["heat_source"][:, :, :nz]
                 _nh.del2_cubed(D, hs, cd, nmax=min(3, cfg.nord + 1))
-                _nh.apply_diffusive_heating(D, s["delp"], s["delz"], s["cappa"], t["heat_source"], s["pt"], abs(dt * cfg.delt_max))
+                from .util import alt
+
+                _nh.apply_diffusive_heating(D, s["delp"], s["delz"], s["cappa"], t["heat_source"], s["pt"], abs((timestep if alt("heat_dt_full") else dt) * cfg.delt_max))

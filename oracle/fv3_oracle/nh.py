@@ -99,6 +99,11 @@ def update_dz_d(D: Dom, cfg, col, dp_ref, zs, zh, crx, cry, xfx, yfx, ws, dt):
     dz_min = D.c.DZ_MIN
     damp = np.append(col["damp_vt"], col["damp_vt"][-1])
     ndif = np.append(col["nord_v"], col["nord_v"][-1]).astype(int)
+    from .util import alt
+
+    damp_on = damp.copy()  # (the switch "is this interface damped" is the raw coefficient in both forms)
+    if alt("dz_damp_scaled"):  # FV3_ALT=dz_damp_scaled: the coefficient d_sw's vorticity damping uses
+        damp = (damp * D.grid.da_min_c) ** (ndif + 1)
     shp = zh.shape[:2] + (nz + 1,)
     crx_adv = np.zeros(shp)
     xfx_adv = np.zeros(shp)
@@ -122,12 +127,12 @@ def update_dz_d(D: Dom, cfg, col, dp_ref, zs, zh, crx, cry, xfx, yfx, ws, dt):
     # group interfaces by (ndif, damp) so each group is one vectorised call
     k0 = 0
     for k in range(1, nz + 2):
-        if k == nz + 1 or damp[k] != damp[k0] or ndif[k] != ndif[k0]:
+        if k == nz + 1 or damp[k] != damp[k0] or ndif[k] != ndif[k0] or damp_on[k] != damp_on[k0]:
             ks = slice(k0, k)
             z2 = zh[:, :, ks].copy()
             fx, fy = fv_tp_2d(D, z2, crx_adv[:, :, ks], cry_adv[:, :, ks], xfx_adv[:, :, ks], yfx_adv[:, :, ks], ra_x[:, :, ks], ra_y[:, :, ks], cfg.hord_tm)
             new = (z2[Rc] * m.area[Rc] + fx[Rc] - fx[Rcx] + fy[Rc] - fy[Rcy]) / (ra_x[:, :, ks][Rc] + ra_y[:, :, ks][Rc] - m.area[Rc])
-            if damp[k0] > 1.0e-5:
+            if damp_on[k0] > 1.0e-5:
                 fx2, fy2, _ = del6_vt_flux(D, int(ndif[k0]), float(damp[k0]), z2)
                 new = new + (fx2[Rc] - fx2[Rcx] + fy2[Rc] - fy2[Rcy]) * m.rarea[Rc]
             zh[:, :, ks][Rc] = new

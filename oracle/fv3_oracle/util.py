@@ -221,3 +221,26 @@ def fill_corners_dgrid_vector(D: Dom, x, y, sign=-1.0):
                 y[npx + j + o, 1 - i + o] = x0[npx - i + o, 1 - j + o]
             if D.ne:
                 y[npx + j + o, npy - 1 + i + o] = sign * x0[npx - i + o, npy + j + o]
+
+
+# ---------------------------------------------------------------------------------------------
+# Named alternatives for the restatements DESIGN.md §2 lists as uncertain.  One environment variable, read by the oracle
+# (here) AND by the library (fv3_alt in csrc/fv3_common.h): FV3_ALT="name[,name...]".  Default (unset) = the choice both were
+# written with.  The point: the first run against real reference savepoints (tools/gen_golden.py + tests/test_reference_golden*.py)
+# can try the alternatives in one pass -- `FV3_ALT=dz_damp_scaled pytest tests/test_reference_golden_dynamics.py` -- instead of one
+# debugging session per suspect.  Known names:
+#   dz_damp_scaled   update_dz_d hands del6_vt_flux (damp_vt * da_min_c)^(nord_v + 1) instead of the raw damp_vt column value
+#   heat_dt_full     apply_diffusive_heating limits with |timestep * delt_max| (the whole acoustic call) instead of the sub-step dt
+# ---------------------------------------------------------------------------------------------
+ALT_NAMES = ("dz_damp_scaled", "heat_dt_full")
+
+
+def alt(name: str) -> bool:
+    import os
+
+    assert name in ALT_NAMES, name
+    chosen = [x.strip() for x in os.environ.get("FV3_ALT", "").split(",") if x.strip()]
+    unknown = [x for x in chosen if x not in ALT_NAMES]
+    if unknown:
+        raise ValueError(f"FV3_ALT: unknown alternative(s) {unknown}; known: {ALT_NAMES}")
+    return name in chosen

@@ -44,7 +44,8 @@ typedef FV3_REAL Real;
 // In-kernel phase stamps (diagnostic builds only: -DFV3_STAMPS, never the product library).  rocprofv3's thread trace needs a
 // decoder library this image does not ship, so the marches are timed from inside: s_memtime (shader clock) at the phase
 // boundaries of a step, pinned with sched_barriers, the per-phase sums of a wave written to a record at its end.
-// Record = {kernel id, steps, sum[0..5]} (32-bit cycle sums); word 0 of the buffer counts the records.
+// Record = {kernel id, steps, sum[0..5]} (32-bit cycle sums); word 0 of the buffer counts the records, word 1 selects one kernel
+// id (0 = all: the buffer then fills with the first launches of a call).
 // ---------------------------------------------------------------------------------------------
 #if defined(FV3_STAMPS) && !defined(FV3_HOST_EMU)
 #define FV3_STAMP_RECS 16384
@@ -63,7 +64,7 @@ unsigned long long *fv3_stamp_buf();  // (fv3_ctx.hip) device buffer, allocated 
 #define FV3_STAMP_USE(x) asm volatile("" ::"v"(x))
 #define FV3_STAMP_FLUSH(buf, kid, tid)                                          \
   do {                                                                          \
-    if ((tid) == 0) {                                                           \
+    if ((tid) == 0 && ((buf)[1] == 0ull || (buf)[1] == (kid))) {                \
       const unsigned long long slot_ = atomicAdd((buf), 1ull);                  \
       if (slot_ < FV3_STAMP_RECS) {                                             \
         unsigned long long *r_ = (buf) + 8 + slot_ * 8;                         \
@@ -263,6 +264,16 @@ extern std::string g_fv3_create_error;
 int fv3_fail(fv3_ctx *c, int code, const std::string &msg);
 int fv3_halo_step(fv3_ctx *c, int update, int phase, void *stream);  // fv3_halo.hip
 void *fv3_dev_alloc(fv3_ctx *c, size_t bytes);
+// FV3_ALT="name[,name...]": the named alternatives of the restatements DESIGN §2 lists as uncertain -- the same variable and names the
+// oracle reads (oracle/fv3_oracle/util.py: alt), so that one run against reference savepoints can try them.  Read per call.
+inline bool fv3_alt(const char *name) {
+  const char *e = getenv("FV3_ALT");
+  if (!e) return false;
+  const size_t n = strlen(name);
+  for (const char *p = e; (p = strstr(p, name)) != nullptr; p += n)
+    if ((p == e || p[-1] == ',' || p[-1] == ' ') && (p[n] == 0 || p[n] == ',' || p[n] == ' ')) return true;
+  return false;
+}
 bool fv3_pp_ensure(fv3_ctx *c);  // (fv3_ctx.hip) the ping-pong buffers of fv3_acoustic_step, allocated on first use
 void fv3_h2d(void *dst, const void *src, size_t bytes);
 int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what);

@@ -178,9 +178,10 @@ unsigned long long *fv3_stamp_buf() {
   }
   return buf;
 }
-extern "C" int fv3_stamps_reset(void) {
+extern "C" int fv3_stamps_reset(unsigned long long only_kernel_id) {
   unsigned long long *b = fv3_stamp_buf();
-  return b && hipMemset(b, 0, 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+  if (!b || hipMemset(b, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  return hipMemcpy(b + 1, &only_kernel_id, sizeof(only_kernel_id), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
 }
 // out[0] = number of records written (may exceed the capacity), then up to max_recs records of 8 words
 extern "C" long fv3_stamps_read(unsigned long long *out, long max_recs) {

@@ -1234,7 +1234,10 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
   // damping term are the transport kernel's epilogue (znew; the height fluxes are never stored)
   int nord_max = 0;
   for (int k = 0; k <= nz; ++k) nord_max = std::max(nord_max, c->nord_v_h[k]);
-  Deln dn{g.nord_v, g.damp_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
+  // (FV3_ALT=dz_damp_scaled -- DESIGN §2, uncertain restatement 1: the coefficient d_sw's vorticity damping uses,
+  //  (damp_vt * da_min_c)^(nord_v + 1), instead of the raw column value; the on / off test stays the raw coefficient)
+  const Real *dz_coef = fv3_alt("dz_damp_scaled") ? c->tab.d6_vt : g.damp_vt;
+  Deln dn{g.nord_v, dz_coef, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max};
   // Interfaces from fd_k0 on (chain of order 2 and switched on: all but the sponge layers) run the chain INSIDE the transport march
   // on the strips away from the W / E tile edges (tp2d_stream_t, TF_FD); del6_stream then only serves the tile-edge strips and
   // the cube-corner patches there.  FV3_DZ_DELN=arrays: the chain of every interface as one del6_stream launch (A/B reference).
@@ -1263,7 +1266,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
     tp2d(c, sa, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, fd_k0 - 1, &e);
     if (sa != s) fv3_signal(c, sa, 3);
     e.fd = 1;
-    e.fd_coef = g.damp_vt;
+    e.fd_coef = dz_coef;
     tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, fd_k0, nz, &e);
     if (sa != s) fv3_wait(c, s, 3);
   }

@@ -344,7 +344,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     int nmax = cf.nord + 1;
     if (nmax > 3) nmax = 3;
     RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_del2_cubed(c, &ws->heat_source, cd, nmax, stream));
-    const double delt = dt * cf.delt_max;
+    const double delt = (fv3_alt("heat_dt_full") ? timestep : dt) * cf.delt_max;  // (FV3_ALT: DESIGN §2, uncertain restatement 2)
     RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_apply_diffusive_heating(c, &st->delp, &st->delz, &st->cappa, &ws->heat_source, &st->pt, delt < 0 ? -delt : delt, stream));
   }
   return FV3_OK;

@@ -13,6 +13,8 @@ RCCL point-to-point messages (``pace_amd.halo``).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -328,4 +330,5 @@ class AcousticDynamics:
             up["heat_source"].update()
             cd = self.c.CNST_0P20 * self._da_min
             self._hyperdiffusion(self._heat_source, cd)
-            self._apply_diffusive_heating(state.delp, state.delz, state.cappa, self._heat_source, state.pt, abs(dt * cfg.delt_max))
+            heat_dt = timestep if "heat_dt_full" in [x.strip() for x in os.environ.get("FV3_ALT", "").split(",")] else dt  # (FV3_ALT: fv3_oracle/util.py)
+            self._apply_diffusive_heating(state.delp, state.delz, state.cappa, self._heat_source, state.pt, abs(heat_dt * cfg.delt_max))

@@ -193,3 +193,27 @@ def test_rccl_calls_execute_on_a_one_rank_communicator(gpu_backend, monkeypatch)
     for n, a in res["copy"].items():
         assert torch.isfinite(a).all(), n
         assert torch.equal(a, res["rccl"][n]), f"{n}: the RCCL self-loop moved different bytes than the device copies"
+
+
+@pytest.mark.gpu
+def test_bench_init_and_teardown_order_with_both_rccl_users(tmp_path):
+    """The 8-GPU run has TWO users of RCCL in one process: torch's NCCL process group (launcher-side barriers / reductions) and the
+    library's own communicator (the halo messages).  bench.py creates the process group first, the communicator inside the harness,
+    and at the end destroys the communicator (with the context) BEFORE the process group.  What one GPU can execute of that: both
+    with ONE rank each (FV3_BENCH_FORCE_PG=1: the process group of a real launch, world size 1; --emulate-share 8 with
+    FV3_LOOPBACK_TRANSPORT=rccl: the library's communicator, every message an ncclSend / ncclRecv to self), the share's acoustic
+    steps in between, then the teardown -- the process must print its line and exit 0 within the timeout (an init-order or
+    teardown hang is what the driver's 8-GPU run would otherwise find first)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
+    env.update(FV3_BENCH_FORCE_PG="1", FV3_LOOPBACK_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c48", "--emulate-share", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["finite"] and line["halo_transport"].startswith("loopback-rccl"), line["halo_transport"]

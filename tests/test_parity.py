@@ -288,6 +288,36 @@ def test_operator_contexts_do_not_allocate_the_pingpong_buffers(backend):
     assert cs.sf.scratch_bytes - before < ni * nj * nk * 8  # (small per-operator tables may appear; no full 3-D field)
 
 
+@pytest.mark.parametrize("name", ["dz_damp_scaled", "heat_dt_full"])
+def test_named_alternatives_switch_oracle_and_library_together(backend, name, monkeypatch):
+    """FV3_ALT=<name> selects the alternative form of a restatement DESIGN §2 lists as uncertain in the oracle AND in the library
+    (native sequencer and its Python twin): under the switch the two still agree to the usual tolerances, and the switch does
+    change the result where it is expected to (so that a run against reference savepoints can tell the forms apart)."""
+    nz = 8
+    base = None
+    for env in ("", name):
+        if env:
+            monkeypatch.setenv("FV3_ALT", env)
+        else:
+            monkeypatch.delenv("FV3_ALT", raising=False)
+        part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=2))
+        init = [{k: v.copy() for k, v in s.items()} for s in ost]
+        odyn(ost, 225.0, 1)
+        got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0)
+        compare_cubes(got, ost, part, nz, STATE, TOL)
+        got_py, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0, native=False)
+        for r in range(part.total_ranks):
+            for n in ("delz", "w", "pt"):
+                assert np.array_equal(got[r][n], got_py[r][n]), n
+        if not env:
+            base = ost
+        elif name == "dz_damp_scaled":  # the interface-height damping changes: the thickness differs from the default form
+            assert max(np.abs(a["delz"] - b["delz"]).max() for a, b in zip(ost, base)) > 1e-9
+    monkeypatch.setenv("FV3_ALT", "no_such_form")
+    with pytest.raises(ValueError, match="unknown alternative"):
+        oracle_cube(12, (1, 1), 3, dict(n_split=1))[5]([{k: v.copy() for k, v in s.items()} for s in oracle_cube(12, (1, 1), 3, dict(n_split=1))[3]], 10.0, 1)
+
+
 @pytest.mark.parametrize("layout", [(1, 2), (3, 1)])
 def test_full_acoustic_call_non_square_subdomains(backend, layout):
     """Layouts with nx != ny per sub-domain (24 x 12, 8 x 24)."""

@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c768")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--kernels", default="1111,1211,62288,62280", help="kernel ids to record, one measured step each (0 = whatever comes first)")
     a = ap.parse_args()
     from pace_amd import lib as L
     from pace_amd.harness import CONFIGS, DycoreHarness
@@ -42,23 +43,26 @@ def main():
     h.step()
     torch.cuda.synchronize()
     print("[stamps] warm-up step done", flush=True)
-    print("[stamps] reset ->", lib.fv3_stamps_reset(), flush=True)
-    h.step()
-    torch.cuda.synchronize()
-    print("[stamps] measured step done", flush=True)
+    lib.fv3_stamps_reset.argtypes = [C.c_ulonglong]
     cap = 16384
-    buf = (C.c_ulonglong * (cap * 8))()
-    n = lib.fv3_stamps_read(buf, cap)
-    rec = np.frombuffer(buf, dtype=np.uint64).reshape(cap, 8)[:n].astype(np.float64)
     names = {1111: "dsw_scalars AIR interior FD", 1211: "dsw_scalars TRC interior FD", 1121: "dsw_scalars AIR edge FD", 1221: "dsw_scalars TRC edge FD",
-             2000 + 288: "tp2d<288> vorticity + winds FD", 2000 + 280: "tp2d<280> interface heights FD"}
-    lines = [f"records {n} (first {cap} waves of the call that finished), config {a.config}, 2 acoustic sub-steps", "",
+             2000 + 288: "tp2d<288> vorticity + winds FD", 2000 + 280: "tp2d<280> interface heights FD", 62288: "tp2d<288, HC 6> vorticity + winds (FA)",
+             62280: "tp2d<280, HC 6> interface heights (FA)"}
+    lines = [f"config {a.config}, one model step of 2 acoustic sub-steps per kernel, up to {cap} waves recorded each; shader-clock cycles per wave and step", "",
              "| kernel | waves | steps/wave | cycles/step | between | issue loads | wait row | phase 1 | phase 2 | phase 3 |", "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
-    for kid in sorted(set(rec[:, 0].astype(int))):
-        r = rec[rec[:, 0] == kid]
-        steps = r[:, 1].sum()
-        ph = r[:, 2:8].sum(axis=0) / max(steps, 1)
-        lines.append(f"| {names.get(kid, kid)} | {len(r)} | {steps / len(r):.1f} | {ph.sum():.0f} | " + " | ".join(f"{v:.0f} ({100 * v / ph.sum():.0f} %)" for v in ph) + " |")
+    for want in [int(x) for x in a.kernels.split(",")]:
+        print("[stamps] reset ->", lib.fv3_stamps_reset(want), flush=True)
+        h.step()
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * (cap * 8))()
+        n = lib.fv3_stamps_read(buf, cap)
+        rec = np.frombuffer(buf, dtype=np.uint64).reshape(cap, 8)[:n].astype(np.float64)
+        print(f"[stamps] kernel {want}: {n} records", flush=True)
+        for kid in sorted(set(rec[:, 0].astype(int))):
+            r = rec[rec[:, 0] == kid]
+            steps = r[:, 1].sum()
+            ph = r[:, 2:8].sum(axis=0) / max(steps, 1)
+            lines.append(f"| {names.get(kid, kid)} | {len(r)} | {steps / len(r):.1f} | {ph.sum():.0f} | " + " | ".join(f"{v:.0f} ({100 * v / ph.sum():.0f} %)" for v in ph) + " |")
     txt = "\n".join(lines)
     print(txt)
     if a.out:
