@@ -3,6 +3,9 @@
 in the .so, finds the kernel whose mangled name contains every given key, takes the largest backward branch as the march loop and
 counts its instructions by class -- branches, SALU, VALU, DPP moves, SGPR-spill lane moves, waits.
     python tools/loop_mix.py <lib.so> key [key ...]
+    python tools/loop_mix.py --waits <lib.so> key [key ...]     every `s_waitcnt vmcnt` of the loop with the instruction behind it and the positions of
+                                                                the loop's vector loads / stores (how far the wait reaches: vmcnt(0 / 1) right before fp64
+                                                                arithmetic of the hot path = the step's own prefetch is being waited for)
 """
 import os
 import re
@@ -94,7 +97,22 @@ def classify(op):
     return "other"
 
 
+def waits(lib, keys):
+    for name, lines in kernel_asm(lib, keys):
+        ins, body = main_loop(lines)
+        print(f"{name[:110]}\n  main loop: {len(body)} instructions")
+        print("  vector loads at", [i for i, (_, op, a) in enumerate(body) if op.startswith(("global_load", "flat_load"))])
+        print("  vector stores at", [i for i, (_, op, a) in enumerate(body) if op.startswith("global_store")])
+        for i, (_, op, args) in enumerate(body):
+            if op == "s_waitcnt" and "vmcnt" in args:
+                n = body[i + 1] if i + 1 < len(body) else ("", "", "")
+                hot = "f64" in n[1] or "dpp" in n[1] or n[1].startswith(("v_mov_b64", "ds_", "v_cndmask", "global_store"))
+                print(f"  {i:5d}  s_waitcnt {args:24s} -> {n[1]} {n[2][:48]}" + ("   <-- in front of hot-path arithmetic" if hot else ""))
+
+
 def main():
+    if sys.argv[1] == "--waits":
+        return waits(sys.argv[2], sys.argv[3:])
     lib, keys = sys.argv[1], sys.argv[2:]
     for name, lines in kernel_asm(lib, keys):
         ins, body = main_loop(lines)
