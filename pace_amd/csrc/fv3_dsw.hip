@@ -838,6 +838,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] fd_k0 = %d of %d\n", fd_k0, g.nz);
     fv3_signal(c, s, 0);
     fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
+    fv3_signal(c, s, 5);  // (fxadv done: what the wind branch on the auxiliary stream waits for, see below)
     fv3_wait(c, s2, 0);
     // (the patches first: they are all the marches of the levels from fd_k0 on wait for; the chains of the sponge layers are read by
     //  the sponge-layer marches, which follow them on the auxiliary stream)
@@ -933,27 +934,29 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     });
   }
 
-  // The new delp / w / q_con / pt are final here; the winds take the second half of the operator.  The sequencer starts the
-  // halo update of delp / pt / q_con at this point (out-of-place form only: nothing below writes them, and the one later read --
-  // the new delp of the damping-heat kernel -- is on compute cells, which a halo update does not touch), so that the exchange
-  // overlaps the whole wind part instead of following the operator.
-  if (after_scalars) {
-    const int hst = after_scalars(after_user);
-    if (hst != FV3_OK) return hst;
-  }
-
-  // ---- cell-mean relative vorticity (+ absolute vorticity)
+  // ---- The wind branch up to the divergence-damping coefficient: cell-mean vorticity, corner kinetic energy, divergence damping, corner
+  //      interpolation of the vorticity.  It needs fxadv's contravariant winds and the D-grid winds, NOT the scalar transports -- and its
+  //      kernels are bandwidth-bound thread-per-point / light marching kernels, while the scalar marches next to them are bound by
+  //      instruction issue at two waves per SIMD.  Round 4: with an auxiliary stream it is queued THERE, behind the sponge-layer launches,
+  //      and can run beside the scalar marches of the main stream (FV3_DSW_WIND_OVERLAP=1; default: in program order behind them, the round-3
+  //      sequence; same values).  Arrays: it writes wk / vabs / ke / the damping field (scratch the marches do not touch: the del-n work
+  //      array is free once the corner patches are done, and the sponge-layer chains that still use it precede the branch on the same
+  //      stream), delpc, divgd and the dead C-grid winds; the flux slots SC_E / SC_F it would share with the air-mass fluxes are only used
+  //      in the keep_uv_dx configuration, which keeps the program order.
   Real *vabs = c->scratch[SC_R];
+  Real *vdamp = c->scratch[SC_DN_D2];  // damping field "vort" on corners
+  int fdw_k0 = g.nz;
+  bool keep_uv_dx = false;
+  auto wind_branch = [&](fv3_stream_t s) {
+  // ---- cell-mean relative vorticity (+ absolute vorticity)
   // Levels that form the damping heat (d_con > 1e-5) WITHOUT vorticity damping (damp_vt <= 1e-5) read the
   // pre-update u*dx / v*dy where the damping fluxes would be (the work arrays keep those values in the
   // reference's data flow); only non-default configs (do_vort_damp off / vtdm4 = 0) have such levels.
-  bool keep_uv_dx = false;
   for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
   Real *ut2 = c->scratch[SC_E], *vt2 = c->scratch[SC_F];  // = the utd / vtd slots below (damping fluxes overwrite them on damped levels)
   // Levels from fdw_k0 on (vorticity damping of order 2: all but the sponge layers): the vorticity transport loads wk and adds f0
   // itself and runs wk's del-n chain inside its march (tp2d TF_WIND | TF_FD) -- no absolute-vorticity field, no del6_stream launch
   // over those levels but for the tile-edge strips.  FV3_DSW_VORT_DELN=arrays: the round-2 form (A/B reference).
-  int fdw_k0 = g.nz;
   {
     const char *e = getenv("FV3_DSW_VORT_DELN"), *m = getenv("FV3_TP2D_MODE"), *m6 = getenv("FV3_DEL6_MODE");
     const bool off = (e && !strcmp(e, "arrays")) || (m && !strcmp(m, "staged")) || (m6 && !strcmp(m6, "staged")) || keep_uv_dx;
@@ -1065,7 +1068,6 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
 
   // ---- divergence damping.  delpc: un-iterated divergence; divgd iterated in place; uc / vc are
   //      the work arrays of the iteration exactly as in the reference (their C-grid values are dead).
-  Real *vdamp = c->scratch[SC_DN_D2];  // damping field "vort" on corners (free: del-n chains are done)
   // nord == 0 levels: divergence of the D-grid wind on the fly; nord > 0 levels: delpc = divgd
   static const bool staged_dd = getenv("FV3_DIVDAMP_STAGED") != nullptr;  // A/B switch for profiling
   // the marching iteration writes its result beside divgd, so the un-iterated divergence stays readable there and
@@ -1147,6 +1149,32 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       (ke + b)[p] += vd;
     });
   }
+
+  };
+  // Measured (same box, alternating runs, C768): d_sw 51.6 -> 50.8 ms, but the halo copies that run inside d_sw 1.96 -> 2.5 and the sub-step
+  // 113.6 -> 114.0 ms: the branch takes from the marches what it gains -- one d_sw call moves 252 GB in 51 ms = 4.9 TB/s, i.e. the operator
+  // as a whole is at the bandwidth the chip sustains; overlapping its parts creates no capacity.  Off by default (FV3_DSW_WIND_OVERLAP=1).
+  static const bool wind_overlap_off = !(getenv("FV3_DSW_WIND_OVERLAP") && getenv("FV3_DSW_WIND_OVERLAP")[0] == '1');
+  for (int k = 0; k < g.nz; ++k) keep_uv_dx = keep_uv_dx || (c->d_con_h[k] > 1.0e-5 && !(c->damp_vt_h[k] > 1.0e-5));
+  const bool wind_overlap = fused_scalars && s2 != s && !wind_overlap_off && !keep_uv_dx;
+  if (wind_overlap) {
+    fv3_wait(c, s2, 5);
+    wind_branch(s2);
+    fv3_signal(c, s2, 6);
+  }
+
+  // The new delp / w / q_con / pt are final here; the winds take the second half of the operator.  The sequencer starts the
+  // halo update of delp / pt / q_con at this point (out-of-place form only: nothing below writes them, and the one later read --
+  // the new delp of the damping-heat kernel -- is on compute cells, which a halo update does not touch), so that the exchange
+  // overlaps the whole wind part instead of following the operator.
+  if (after_scalars) {
+    const int hst = after_scalars(after_user);
+    if (hst != FV3_OK) return hst;
+  }
+  if (wind_overlap)
+    fv3_wait(c, s, 6);
+  else
+    wind_branch(s);
 
   // ---- del-n damping fluxes of the relative vorticity (they depend on wk alone): ahead of the transport, whose wind
   //      epilogue applies them
