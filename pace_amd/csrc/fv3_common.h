@@ -221,6 +221,8 @@ struct fv3_ctx {
   // registered halo plans apply while the state lives in the alternates.
   Real *pp_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_state = 0;
+  // set by fv3_acoustic_step around its d_sw call: the workspace divgd is dead after the operator (the next c_sw overwrites it)
+  bool seq_divgd_dead = false;
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;

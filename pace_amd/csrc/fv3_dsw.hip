@@ -384,8 +384,27 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr cosa = g.cosa, rsina = g.rsina, rdx = g.rdx, rdy = g.rdy;
-  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+  // Level-major launch geometry (round 4; as in the transport marches, fv3_tp4.hip): KB levels of one (strip, segment) tile are consecutive
+  // workgroups of an XCD, so the tile's four metric rows (cosa, rsina, rdx, rdy: 4 of the 9 row reads of a step) are fetched into that XCD's L2
+  // once per KB levels -- plane-major, the 4.8 MB of metric terms of a 384^2 sub-domain do not survive a 4 MB L2 from one level to the next.
+  // FV3_KE_KB=0: plane-major (A/B).
+  static const int kb_env = getenv("FV3_KE_KB") ? atoi(getenv("FV3_KE_KB")) : 16;
+  const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  launch_waves<4>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    Blk blk = blk_;
+    int t, k;
+    if (KB) {
+      t = blk_.bz / nblk;
+      const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k = k0 + kk;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
+    } else {
+      t = blk.bz / nk;
+      k = k0 + (blk.bz - t * nk);
+    }
     const int fl = gp->flags[t];
     const long b = t * st + k * sk, m2 = t * st2;
     // corners of this sub-domain that take the interior formulas
@@ -592,8 +611,24 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const int *nord_k = g.nord;
   const MPtr divg_u = g.divg_u, divg_v = g.divg_v, rarea_c = g.rarea_c;
-  launch_waves<4>(c, s, nstrip, nseg, g.nsub * nk, smem, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const int t = blk.bz / nk, k = k0 + (blk.bz - t * nk);
+  // level-major launch geometry (see ke_stream): the three metric rows are 3 of the 4 row reads of a step
+  static const int kb_env = getenv("FV3_KE_KB") ? atoi(getenv("FV3_KE_KB")) : 16;
+  const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  launch_waves<4>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    Blk blk = blk_;
+    int t, k;
+    if (KB) {
+      t = blk_.bz / nblk;
+      const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k = k0 + kk;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
+    } else {
+      t = blk.bz / nk;
+      k = k0 + (blk.bz - t * nk);
+    }
     const int nord = nord_k[k];
     if (nord == 0) return;
     const long b = t * st + k * sk, m2 = t * st2;
@@ -1134,6 +1169,10 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   // kernel runs as the epilogue of the corner interpolation and the corner field is never stored.
   {
     const Real dddmp = (Real)cf.dddmp;
+    // The operator's contract leaves the iterated divergence in divgd (D_SW-Out carries it).  Inside fv3_acoustic_step nobody reads it: the
+    // next c_sw overwrites the workspace field -- the sequencer says so (seq_divgd_dead) and the copy of the iteration's result into divgd
+    // (one field write per call) is skipped when the iteration wrote beside it.
+    const bool keep_divgd = !(c->seq_divgd_dead && dd_sep);
     a2b_ord4_t<8>(c, s, wk, 0, 0, g.nz, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
       const int nord = g.nord[k];
       if (nord == 0) return;
@@ -1143,7 +1182,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       if (dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkbv * wkbv);
       const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, dddmp * vo));
       const Real dn_ = (dnew + b)[p];
-      (divgd + b)[p] = dn_;  // (no-op for the in-place staged form)
+      if (keep_divgd) (divgd + b)[p] = dn_;  // (no-op for the in-place staged form; skipped inside the sequencer: see seq_divgd_dead)
       const Real vd = damp2 * dpc + tab.dd8[k] * dn_;
       (vdamp + b)[p] = vd;
       (ke + b)[p] += vd;

@@ -172,6 +172,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     ~PpGuard() {
       c->pp_n = 0;
       c->frame_pass = 0;
+      c->seq_divgd_dead = false;
     }
   } pp_guard{c};
 
@@ -260,9 +261,11 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
         c->prof_parent = -1;
         return st_;
       };
+      c->seq_divgd_dead = getenv("FV3_SEQ_KEEP_DIVGD") == nullptr;
       RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
                                     &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
                                     stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt], +start_halo, &mid));
+      c->seq_divgd_dead = false;
       cur = nxt;
       c->pp_n = cur ? 4 : 0;
     } else {
