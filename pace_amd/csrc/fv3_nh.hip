@@ -171,12 +171,70 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
   }
 }
 
+// k_walk as a statement macro: the body (the trailing block, which sees the level K and the record r) is expanded INSIDE the function
+// that owns the register arrays -- a lambda that captures them by reference sends them to scratch memory (the element store turns into a
+// scalar store through a pointer before the closure is dissolved, and nothing promotes the array afterwards).  `load` may be a lambda:
+// it touches no register array.
+#define KWALK(N, U, UP, load, ...)                                           \
+  {                                                                          \
+    KRec<N> buf_[U];                                                         \
+    _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                       \
+      const int kk_ = u_ < nz ? u_ : nz - 1;                                 \
+      buf_[u_] = load(UP ? kk_ : nz - 1 - kk_);                              \
+    }                                                                        \
+    for (int c_ = 0; c_ < nz; c_ += U) {                                     \
+      KRec<N> nxt_[U];                                                       \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                     \
+        int kk_ = c_ + U + u_;                                               \
+        kk_ = kk_ < nz ? kk_ : nz - 1;                                       \
+        nxt_[u_] = load(UP ? kk_ : nz - 1 - kk_);                            \
+      }                                                                      \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) if (c_ + u_ < nz) {   \
+        const int K = UP ? c_ + u_ : nz - 1 - (c_ + u_);                     \
+        const KRec<N> &r = buf_[u_];                                         \
+        __VA_ARGS__                                                          \
+      }                                                                      \
+      _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) buf_[u_] = nxt_[u_];  \
+    }                                                                        \
+  }
+
 #define KW_(arr, k) ((arr) + tb + (long)(k)*sk)[pix]
 #ifndef FV3_RIEM_U
 #define FV3_RIEM_U 4   // levels in flight in the sweeps with 4-5 inputs
 #endif
 #ifndef FV3_RIEM_U1
 #define FV3_RIEM_U1 8  // ... in the sweeps with 1-2 inputs
+#endif
+
+// A column's worth of one tridiagonal temporary in the lane's REGISTERS (RA form of Sim1W::run).  At one wave per SIMD (what the LDS
+// line allows) a wave owns 512 registers per lane and the solver's working set is ~110: the register file is the largest idle on-chip
+// memory.  The compiler can index at most a 32-dword register tuple with a wave-uniform index (`s_set_gpr_idx_on`), so a column is five
+// 16-level chunks picked by a wave-uniform branch; chunks that do not fit beside the working set live in the accumulation registers and
+// are moved in and out around an access (all register moves: no memory traffic).  80 levels at most; deeper columns keep the scratch fields.
+#define FV3_KREG_LEVELS 80
+#ifndef FV3_RIEM_RP
+#define FV3_RIEM_RP 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef Real fv3_kreg_chunk __attribute__((ext_vector_type(16)));
+#define KREG_DECL(n) fv3_kreg_chunk n##0 = (Real)0, n##1 = (Real)0, n##2 = (Real)0, n##3 = (Real)0, n##4 = (Real)0
+#define KREG_SET(n, k, v)                \
+  do {                                   \
+    const int i_ = (k)&15;               \
+    switch ((k) >> 4) {                  \
+      case 0: n##0[i_] = (v); break;     \
+      case 1: n##1[i_] = (v); break;     \
+      case 2: n##2[i_] = (v); break;     \
+      case 3: n##3[i_] = (v); break;     \
+      default: n##4[i_] = (v); break;    \
+    }                                    \
+  } while (0)
+#define KREG_GET(n, k) \
+  (((k) >> 4) == 0 ? n##0[(k)&15] : ((k) >> 4) == 1 ? n##1[(k)&15] : ((k) >> 4) == 2 ? n##2[(k)&15] : ((k) >> 4) == 3 ? n##3[(k)&15] : n##4[(k)&15])
+#else
+#define KREG_DECL(n) Real n[FV3_KREG_LEVELS]
+#define KREG_SET(n, k, v) n[k] = (v)
+#define KREG_GET(n, k) n[k]
 #endif
 
 struct Sim1W {
@@ -189,200 +247,202 @@ struct Sim1W {
   // A = this lane's LDS line (stride FV3_WAVE); zint = interface heights (nz + 1 levels) the old
   // thickness comes from; wout (optional, may alias w1) receives the new w.
   // GL: the gam arrays live in a second LDS line B (2 waves / CU at L79) instead of the scratch field GAM.
-  template <bool GL, class C>
+  // RA: gam and PM live in the lane's registers (KREG_*; nz <= FV3_KREG_LEVELS): six field passes less per call.
+  template <bool GL, bool RA, class C>
   FV3_HD void run(Real *A, Real *B, long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *qcon, const Real *zint, const Real *w1,
                   Real ws, Real *PM, Real *GAM, Real *wout, C &cl) const {
     const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
     constexpr int U = FV3_RIEM_U, U1 = FV3_RIEM_U1;
     Real pp_nz;
+    constexpr bool RP = RA && FV3_RIEM_RP;  // PM in registers too
+    KREG_DECL(rg);  // gam
+    KREG_DECL(rp);  // PM
+#define GAM_PUT(k, v)                       \
+  do {                                      \
+    if constexpr (RA) KREG_SET(rg, k, v);   \
+    else if (GL) B[(k)*FV3_WAVE] = (v);     \
+    else KW_(GAM, k) = (v);                 \
+  } while (0)
     // ---- sweep 1 (up): layer pressures, forward elimination for pp.  PP(k+1) -> slot k
     {
       Real g_prev = (Real)0, dm_k = (Real)0, pe_k = (Real)0, bet = (Real)0, pp_k = (Real)0;  // g_prev = dm(k-1) / dm(k) = the previous step's g_rat
       Real z_top = KW_(zint, 0);
-      k_walk<5, U, true>(
-          nz,
-          [&](int k) {
-            KRec<5> r;
-            r.v[0] = KW_(delp, k);
-            r.v[1] = KW_(cappa, k);
-            r.v[2] = KW_(pt, k);
-            r.v[3] = KW_(qcon, k);
-            r.v[4] = KW_(zint, k + 1);
-            return r;
-          },
-          [&](int m, const KRec<5> &r) {
-            const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
-            KW_(PM, m) = pm_n;
-            const Real dz_n = r.v[4] - z_top;
-            z_top = r.v[4];
-            const Real dm_n = r.v[0] * rgrav;
-            const Real pe_n = fv3_exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * fv3_log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
-            if (m >= 1) {
-              const int k = m - 1;
-              const Real g_rat = dm_k / dm_n;
-              const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
-              const Real dd = (Real)3.0 * (pe_k + g_rat * pe_n);
-              if (k == 0) {
-                bet = bb;
-                pp_k = dd / bet;
-              } else {
-                const Real gam = g_prev / bet;
-                if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
-                bet = bb - gam;
-                pp_k = (dd - pp_k) / bet;
-              }
-              A[k * FV3_WAVE] = pp_k;
-              g_prev = g_rat;
-            }
-            dm_k = dm_n;
-            pe_k = pe_n;
-          });
+      auto ld = [&](int k) {
+        KRec<5> q;
+        q.v[0] = KW_(delp, k);
+        q.v[1] = KW_(cappa, k);
+        q.v[2] = KW_(pt, k);
+        q.v[3] = KW_(qcon, k);
+        q.v[4] = KW_(zint, k + 1);
+        return q;
+      };
+      KWALK(5, U, true, ld, {
+        const int m = K;
+        const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
+        if constexpr (RP) KREG_SET(rp, m, pm_n); else KW_(PM, m) = pm_n;
+        const Real dz_n = r.v[4] - z_top;
+        z_top = r.v[4];
+        const Real dm_n = r.v[0] * rgrav;
+        const Real pe_n = fv3_exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * fv3_log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
+        if (m >= 1) {
+          const int k = m - 1;
+          const Real g_rat = dm_k / dm_n;
+          const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
+          const Real dd = (Real)3.0 * (pe_k + g_rat * pe_n);
+          if (k == 0) {
+            bet = bb;
+            pp_k = dd / bet;
+          } else {
+            const Real gam = g_prev / bet;
+            GAM_PUT(k, gam);
+            bet = bb - gam;
+            pp_k = (dd - pp_k) / bet;
+          }
+          A[k * FV3_WAVE] = pp_k;
+          g_prev = g_rat;
+        }
+        dm_k = dm_n;
+        pe_k = pe_n;
+      })
       {
         const int k = nz - 1;
         const Real bb = (Real)2.0, dd = (Real)3.0 * pe_k;
         const Real gam = g_prev / bet;
-        if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
+        GAM_PUT(k, gam);
         bet = bb - gam;
         pp_k = (dd - pp_k) / bet;
         A[k * FV3_WAVE] = pp_k;
       }
       pp_nz = pp_k;
     }
+    auto ld_gam = [&](int k) {
+      KRec<1> q;
+      q.v[0] = GL || RA ? (Real)0 : KW_(GAM, k > 0 ? k : 1);
+      return q;
+    };
     // ---- sweep 2 (down): back substitution, PP(k) = PP(k) - gam(k) PP(k+1), k = nz-1 .. 1
     {
       Real pp_next = pp_nz;
-      k_walk<1, U1, false>(
-          nz,
-          [&](int k) {
-            KRec<1> r;
-            r.v[0] = GL ? (Real)0 : KW_(GAM, k > 0 ? k : 1);
-            return r;
-          },
-          [&](int k, const KRec<1> &r) {
-            if (k >= 1) {
-              const Real ppv = A[(k - 1) * FV3_WAVE] - (GL ? B[k * FV3_WAVE] : r.v[0]) * pp_next;
-              A[(k - 1) * FV3_WAVE] = ppv;
-              pp_next = ppv;
-            }
-          });
+      KWALK(1, U1, false, ld_gam, {
+        if (K >= 1) {
+          Real gk;
+          if constexpr (RA) gk = KREG_GET(rg, K); else gk = GL ? B[K * FV3_WAVE] : r.v[0];
+          const Real ppv = A[(K - 1) * FV3_WAVE] - gk * pp_next;
+          A[(K - 1) * FV3_WAVE] = ppv;
+          pp_next = ppv;
+        }
+      })
     }
     // ---- sweep 3 (up): forward elimination for w.  W2(k) -> slot k (PP(k+1) has been taken out one level earlier)
     {
       Real pem = ptop, gm_p = (Real)0, dz_p = (Real)0, aa_k = (Real)0, dmp = (Real)0, w1p = (Real)0, pp_lo = (Real)0, pp_lo2 = (Real)0, bet = (Real)0,
            w2_prev = (Real)0;
       Real z_top = KW_(zint, 0);
-      k_walk<4, U, true>(
-          nz,
-          [&](int k) {
-            KRec<4> r;
-            r.v[0] = KW_(delp, k);
-            r.v[1] = KW_(cappa, k);
-            r.v[2] = KW_(zint, k + 1);
-            r.v[3] = KW_(w1, k);
-            return r;
-          },
-          [&](int m, const KRec<4> &r) {
-            const Real gm_n = (Real)1.0 / ((Real)1.0 - r.v[1]);
-            const Real dz_n = r.v[2] - z_top;
-            z_top = r.v[2];
-            const Real pp_hi = A[m * FV3_WAVE];  // PP(m+1)
-            if (m >= 1) {
-              const Real aa_n = t1g * (Real)0.5 * (gm_p + gm_n) / (dz_p + dz_n) * (pem + pp_lo);
-              const int k = m - 1;
-              if (k == 0) {
-                bet = dmp - aa_n;
-                w2_prev = (dmp * w1p + dt * pp_lo) / bet;
-              } else {
-                const Real gam = aa_k / bet;
-                if (GL) B[k * FV3_WAVE] = gam; else KW_(GAM, k) = gam;
-                bet = dmp - (aa_k + aa_n + aa_k * gam);
-                w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev) / bet;
-              }
-              A[k * FV3_WAVE] = w2_prev;
-              aa_k = aa_n;
-            }
-            pem = pem + r.v[0];
-            gm_p = gm_n;
-            dz_p = dz_n;
-            dmp = r.v[0] * rgrav;
-            w1p = r.v[3];
-            pp_lo2 = pp_lo;
-            pp_lo = pp_hi;
-          });
+      auto ld = [&](int k) {
+        KRec<4> q;
+        q.v[0] = KW_(delp, k);
+        q.v[1] = KW_(cappa, k);
+        q.v[2] = KW_(zint, k + 1);
+        q.v[3] = KW_(w1, k);
+        return q;
+      };
+      KWALK(4, U, true, ld, {
+        const int m = K;
+        const Real gm_n = (Real)1.0 / ((Real)1.0 - r.v[1]);
+        const Real dz_n = r.v[2] - z_top;
+        z_top = r.v[2];
+        const Real pp_hi = A[m * FV3_WAVE];  // PP(m+1)
+        if (m >= 1) {
+          const Real aa_n = t1g * (Real)0.5 * (gm_p + gm_n) / (dz_p + dz_n) * (pem + pp_lo);
+          const int k = m - 1;
+          if (k == 0) {
+            bet = dmp - aa_n;
+            w2_prev = (dmp * w1p + dt * pp_lo) / bet;
+          } else {
+            const Real gam = aa_k / bet;
+            GAM_PUT(k, gam);
+            bet = dmp - (aa_k + aa_n + aa_k * gam);
+            w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev) / bet;
+          }
+          A[k * FV3_WAVE] = w2_prev;
+          aa_k = aa_n;
+        }
+        pem = pem + r.v[0];
+        gm_p = gm_n;
+        dz_p = dz_n;
+        dmp = r.v[0] * rgrav;
+        w1p = r.v[3];
+        pp_lo2 = pp_lo;
+        pp_lo = pp_hi;
+      })
       {
         const Real p1 = t1g * gm_p / dz_p * (pem + pp_lo);
         const Real gam = aa_k / bet;
-        if (GL) B[(nz - 1) * FV3_WAVE] = gam; else KW_(GAM, nz - 1) = gam;
+        GAM_PUT(nz - 1, gam);
         bet = dmp - (aa_k + p1 + aa_k * gam);
         w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - p1 * ws - aa_k * w2_prev) / bet;
         A[(nz - 1) * FV3_WAVE] = w2_prev;
       }
       // ---- sweep 4 (down): back substitution, W2(k) = W2(k) - gam(k+1) W2(k+1), k = nz-2 .. 0
       Real w2_next = w2_prev;
-      k_walk<1, U1, false>(
-          nz,
-          [&](int k) {
-            KRec<1> r;
-            r.v[0] = GL ? (Real)0 : KW_(GAM, k > 0 ? k : 1);
-            return r;
-          },
-          [&](int kk, const KRec<1> &r) {
-            if (kk >= 1) {
-              const Real wv = A[(kk - 1) * FV3_WAVE] - (GL ? B[kk * FV3_WAVE] : r.v[0]) * w2_next;
-              A[(kk - 1) * FV3_WAVE] = wv;
-              w2_next = wv;
-            }
-          });
+      KWALK(1, U1, false, ld_gam, {
+        if (K >= 1) {
+          Real gk;
+          if constexpr (RA) gk = KREG_GET(rg, K); else gk = GL ? B[K * FV3_WAVE] : r.v[0];
+          const Real wv = A[(K - 1) * FV3_WAVE] - gk * w2_next;
+          A[(K - 1) * FV3_WAVE] = wv;
+          w2_next = wv;
+        }
+      })
     }
     // ---- sweep 5 (up): new pressure perturbation.  PE(k+1) -> slot k; the new w leaves through wout
     {
       Real pe_run = (Real)0;
-      k_walk<2, U1, true>(
-          nz,
-          [&](int k) {
-            KRec<2> r;
-            r.v[0] = KW_(delp, k);
-            r.v[1] = KW_(w1, k);
-            return r;
-          },
-          [&](int k, const KRec<2> &r) {
-            const Real w2k = A[k * FV3_WAVE];
-            pe_run = pe_run + r.v[0] * rgrav * (w2k - r.v[1]) * rdt;
-            A[k * FV3_WAVE] = pe_run;
-            if (wout) KW_(wout, k) = w2k;
-            cl.out_pe(k + 1, pe_run, r.v[0]);
-          });
+      auto ld = [&](int k) {
+        KRec<2> q;
+        q.v[0] = KW_(delp, k);
+        q.v[1] = KW_(w1, k);
+        return q;
+      };
+      KWALK(2, U1, true, ld, {
+        const Real w2k = A[K * FV3_WAVE];
+        pe_run = pe_run + r.v[0] * rgrav * (w2k - r.v[1]) * rdt;
+        A[K * FV3_WAVE] = pe_run;
+        if (wout) KW_(wout, K) = w2k;
+        cl.out_pe(K + 1, pe_run, r.v[0]);
+      })
     }
     // ---- sweep 6 (down): new layer thickness, handed to the caller's finish
     {
       Real p1 = (Real)0, dm_below = (Real)0, pe1 = A[(nz - 1) * FV3_WAVE], pe2 = (Real)0;
-      k_walk<4, U, false>(
-          nz,
-          [&](int k) {
-            KRec<4> r;
-            r.v[0] = KW_(delp, k);
-            r.v[1] = KW_(pt, k);
-            r.v[2] = KW_(cappa, k);
-            r.v[3] = KW_(PM, k);
-            return r;
-          },
-          [&](int k, const KRec<4> &r) {
-            const Real dm = r.v[0] * rgrav;
-            const Real pe_k = k >= 1 ? A[(k - 1) * FV3_WAVE] : (Real)0;
-            if (k == nz - 1) {
-              p1 = (pe_k + (Real)2.0 * pe1) * r3;
-            } else {
-              const Real g_rat = dm / dm_below;
-              const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
-              p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
-            }
-            const Real dzn = -dm * rgas * r.v[1] * fv3_exp((r.v[2] - (Real)1.0) * fv3_log(fv3_max(p_fac * r.v[3], p1 + r.v[3])));
-            cl.finish(k, dzn);
-            pe2 = pe1;
-            pe1 = pe_k;
-            dm_below = dm;
-          });
+      auto ld = [&](int k) {
+        KRec<4> q;
+        q.v[0] = KW_(delp, k);
+        q.v[1] = KW_(pt, k);
+        q.v[2] = KW_(cappa, k);
+        q.v[3] = RP ? (Real)0 : KW_(PM, k);
+        return q;
+      };
+      KWALK(4, U, false, ld, {
+        const Real dm = r.v[0] * rgrav;
+        const Real pe_k = K >= 1 ? A[(K - 1) * FV3_WAVE] : (Real)0;
+        if (K == nz - 1) {
+          p1 = (pe_k + (Real)2.0 * pe1) * r3;
+        } else {
+          const Real g_rat = dm / dm_below;
+          const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
+          p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
+        }
+        Real pmk;
+        if constexpr (RP) pmk = KREG_GET(rp, K); else pmk = r.v[3];
+        const Real dzn = -dm * rgas * r.v[1] * fv3_exp((r.v[2] - (Real)1.0) * fv3_log(fv3_max(p_fac * pmk, p1 + pmk)));
+        cl.finish(K, dzn);
+        pe2 = pe1;
+        pe1 = pe_k;
+        dm_below = dm;
+      })
     }
+#undef GAM_PUT
   }
 };
 
@@ -400,6 +460,15 @@ inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
   return line <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
+// gam (and PM, -DFV3_RIEM_RP=1) in registers: FV3_RIEM_REGS=1 opts in.  Same values, six field passes less -- and SLOWER (C768 L79 fp64,
+// same box: riem_solver_c 9.64 -> 13.84 ms, riem_solver3 11.32 -> 15.74; with PM as well 19.4 / 25.2): the working set (157 registers)
+// + the array (160) exceed the 256 architectural registers, the compiler keeps the chunks in the accumulation registers and moves 32 of
+// them in and out around EVERY access (5 000 v_accvgpr_read in the kernel).  A form with one "current" chunk that is swapped at the
+// 16-level boundaries compiles to even more whole-chunk copies (the vector phis are not coalesced).  Kept as the A/B form.
+inline bool riem_reg_arrays(const Geo &g) {
+  static const bool on = getenv("FV3_RIEM_REGS") && getenv("FV3_RIEM_REGS")[0] == '1';
+  return on && !FV3_RIEM_GL && g.nz <= FV3_KREG_LEVELS;
+}
 
 #ifndef PG_KC
 #define PG_KC 16  // levels one thread of the pressure-gradient kernels walks
@@ -578,6 +647,8 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
     const long st = g.st, st2 = g.st2, sk = g.sk;
     const int sj32 = g.sj32, go = g.o;
     const bool gl = riem_gam_lds(g);
+    auto go_ = [&](auto ra_tag) {
+    constexpr bool RA = decltype(ra_tag)::value;
     launch_waves<1>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
       const int t = blk.bz;
       const long tb = t * st;
@@ -609,10 +680,15 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
         const Real z_bot = phis[t * st2 + pix];
         Cl cl{tb, sk, pix, ptop, ptop, z_bot, grav, pef, gz};
         KW_(pef, 0) = ptop;
-        sw.run<FV3_RIEM_GL != 0>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt2, delpc, cappa, ptc, q_con, gz, w3, ws[t * st2 + pix], PM, GAM, (Real *)nullptr, cl);
+        sw.run<FV3_RIEM_GL != 0, RA>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt2, delpc, cappa, ptc, q_con, gz, w3, ws[t * st2 + pix], PM, GAM, (Real *)nullptr, cl);
         KW_(gz, nz) = z_bot;
       }
     });
+    };
+    if (riem_reg_arrays(g))
+      go_(std::true_type{});
+    else
+      go_(std::false_type{});
     return fv3_post(c, s, "riem_solver_c");
   }
   launch2(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, 0}, [=] FV3_HD(int t, int i, int j) {
@@ -682,8 +758,9 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const int nwave = (ncol + FV3_WAVE - 1) / FV3_WAVE;
     const int nwave_frame = c->frame_pass != 0 ? (ord.n_frame() + FV3_WAVE - 1) / FV3_WAVE : 0;
     const int w_lo = c->frame_pass == 2 ? nwave_frame : 0, w_hi = c->frame_pass == 1 ? nwave_frame : nwave;  // waves [w_lo, w_hi)
-    auto go_ = [&](auto last_tag) {
+    auto go_ = [&](auto last_tag, auto ra_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
+    constexpr bool RA = decltype(ra_tag)::value;
     launch_waves<1>(c, s, w_hi - w_lo, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
       const int t = blk.bz;
       const long tb = t * st;
@@ -731,15 +808,20 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           KW_(pe, 0) = ptop;
         }
         KW_(ppe, 0) = (Real)0;
-        sw.run<FV3_RIEM_GL != 0>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt, delp, cappa, pt, q_con, zh, w, wsd[t * st2 + pix], PM, GAM, w, cl);
+        sw.run<FV3_RIEM_GL != 0, RA>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt, delp, cappa, pt, q_con, zh, w, wsd[t * st2 + pix], PM, GAM, w, cl);
         KW_(zh, nz) = z_bot;
       }
     });
     };
-    if (last)
-      go_(std::true_type{});
+    const bool ra = riem_reg_arrays(g);
+    if (last && ra)
+      go_(std::true_type{}, std::true_type{});
+    else if (last)
+      go_(std::true_type{}, std::false_type{});
+    else if (ra)
+      go_(std::false_type{}, std::true_type{});
     else
-      go_(std::false_type{});
+      go_(std::false_type{}, std::false_type{});
     return fv3_post(c, s, "riem_solver3");
   }
   launch2_pass(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, c->frame_pass, [=] FV3_HD(int t, int i, int j) {

@@ -250,6 +250,15 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
     // them (one in-order memory counter, and the compiler orders the loads of a step as it likes) drained the row prefetch in
     // phase 2 of every step.  Requested one step ahead they are covered by the wait at the top of the step, like the rows.
     Real n_ax[FV3_LPT], n_ay[FV3_LPT], n_mx[FV3_LPT], n_my[FV3_LPT], n_mc[FV3_LPT], n_dn[FV3_LPT];
+    // TRC, interior strips: the new air mass of a cell is RECOMPUTED from the air-mass fluxes the wave holds anyway -- old delp + (fx - fx[i+1] +
+    // fy[face r-3] - fy[face r-2]) * rarea, the very expression (and operands) of the delp + w march that stored it -- instead of being read back:
+    // one field stream less (2.75 GB per call at C768).  fyp_air = the air-mass M flux of the previous step's face.  FV3_NO_DN_RECOMP: the load (A/B).
+#ifdef FV3_NO_DN_RECOMP
+    constexpr bool DN_RECOMP = false;
+#else
+    constexpr bool DN_RECOMP = !HAS_AIR && DPP;
+#endif
+    Real fyp_air[FV3_LPT];
     Real o_dx[Q4_NT][FV3_LPT], o_dy[Q4_NT][FV3_LPT];    // damping fluxes along L / M (w's enter as an increment instead)
     Real era[FV3_LPT];                                  // rarea(lc, r-3)
     Real zx0[FV3_LPT], zx1[FV3_LPT], zy0[FV3_LPT], zy1[FV3_LPT];  // w's damping fluxes around the cell (lc, r-3): x, x + 1, y, y + 1
@@ -316,7 +325,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
         n_mx[l] = (a.fx + b)[p3];
         n_my[l] = (a.fy + b)[pf];
         n_mc[l] = (a.delp + b)[pf];
-        n_dn[l] = (a.o_delp + b)[p3];
+        if constexpr (!DN_RECOMP) n_dn[l] = (a.o_delp + b)[p3];
       }
     };
     FV3_LANES(blk, lane, l) {
@@ -374,6 +383,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       }
       n_ax[l] = n_ay[l] = n_mx[l] = n_my[l] = n_mc[l] = (Real)0;
       n_dn[l] = (Real)1;
+      fyp_air[l] = (Real)0;
       load_opt(ca - 3, l);
       nxt[l] = load_row(ca - 3, l, lane);
       nx2[l] = load_row(ca - 2 < r_end ? ca - 2 : r_end, l, lane);
@@ -805,6 +815,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             else
               fxe[n] = exf[n][lane + 1];
           Q4_END
+          Real fe_air = (Real)0;
+          if constexpr (DN_RECOMP) fe_air = FV3_LANE_SHL(1, o_mx, l, lane);  // air-mass flux through the cell's high L face
           if constexpr (FD && HAS_AIR) {  // w's damping flux through the high L face of the cell: the neighbouring lane's
             if constexpr (DPP)
               zx1[l] = FV3_LANE_SHL(1, zxo, l, lane);
@@ -823,7 +835,13 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
               const Real dv_ = TR ? (fyp[n][l] - vy[n] + fxk[n][l] - fe) * era[l] : (fxk[n][l] - fe + fyp[n][l] - vy[n]) * era[l];
               up[n] = id == 0 ? w2[n][l] + dv_ : mb * w2[n][l] + dv_;
             Q4_END
-            const Real dpn = HAS_AIR ? up[0] : o_dn[l];  // new air mass of the cell
+            Real dpn;  // new air mass of the cell
+            if constexpr (HAS_AIR)
+              dpn = up[0];
+            else if constexpr (DN_RECOMP)
+              dpn = mb + (o_mx[l] - fe_air + fyp_air[l] - o_my[l]) * era[l];
+            else
+              dpn = o_dn[l];
             Q4_EACH(n)
               if constexpr (id == 0) {
                 fv3_store_sel((a.o_delp + b) + p, sk, cell_ok, dpn);
@@ -844,6 +862,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
             Q4_END
           }
           if constexpr (!HAS_AIR) mbk[l] = o_mc[l];
+          if constexpr (DN_RECOMP) fyp_air[l] = o_my[l];
           Q4_EACH(n)
             fyp[n][l] = vy[n];
           Q4_END
@@ -924,6 +943,7 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
       dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
       if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
     } else {
+      // (measured and dropped: the transposed tile-edge marches on the auxiliary stream beside the interior ones -- d_sw 51.5 ms either way)
       dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
       if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
       dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);

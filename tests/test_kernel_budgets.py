@@ -41,8 +41,9 @@ BUDGETS = [
     (("csw_fused_stream", "fv3_kwgILi2ELi4E"), 1, 256, 0, 0),   # c_sw interior march
     (("nh_pgf_fused", "fv3_kwILi2E"), 1, 256, 0, 0),            # fused nh_p_grad march
     (("ke_stream", "fv3_kwILi4E"), 1, 128, 0, 0),               # corner kinetic energy: four waves / SIMD
-    (("fv3_riem_solver_c", "fv3_kwILi1E"), 1, 256, 0, 0),       # wave Riemann solvers: the LDS line, not the registers, sets their occupancy
-    (("fv3_riem_solver3", "fv3_kwILi1E", "Lb0E"), 1, 256, 0, 0),
+    (("fv3_riem_solver_c", "fv3_kwILi1E", "IbLb0E"), 1, 256, 0, 0),       # wave Riemann solvers: the LDS line, not the registers, sets their occupancy
+    (("fv3_riem_solver3", "fv3_kwILi1E", "IbLb0EES5_"), 1, 256, 0, 0),      # (not the last sub-step, gam through the scratch field)
+    (("fv3_riem_solver_c", "fv3_kwILi1E", "IbLb1E"), 1, 512, 0, 0),       # ... the opt-in form with gam in registers (FV3_RIEM_REGS=1): no memory spill
 ]
 
 
