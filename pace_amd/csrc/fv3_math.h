@@ -8,7 +8,8 @@
 // normal, finite.  fv3_log is the classic argument reduction to [sqrt(2)/2, sqrt(2)) + the degree-14 odd series in
 // s = f / (2 + f) (Sun fdlibm / musl e_log.c coefficients, error < 1 ulp), ~40 instructions; anything outside the positive
 // normal range is handled like libm does (special values, subnormals scaled up) in a branch the solvers never take.  fv3_exp: below.
-// Same source on the device and in the host emulation: with -ffp-contract=off both give the same bits, so the host-emulation
+// Same source on the device and in the host emulation: with -ffp-contract=off and the polynomials written with explicit fused multiply-adds
+// (correctly rounded on both sides; -DFV3_MATH_NO_FMA: the separate multiply / add form, A/B) both give the same bits, so the host-emulation
 // parity suite keeps checking the device arithmetic.  Accuracy is pinned against 80-bit logl over the solvers' argument range
 // by tests/test_fast_math.py (<= 1 ulp).  -DFV3_LIBM_MATH selects the libm calls (A/B).
 #pragma once
@@ -17,6 +18,8 @@
 #include <cstring>
 
 #include "fv3_common.h"
+
+FV3_HD inline double fv3_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 FV3_HD inline double fv3_log_f64(double x) {
   uint64_t ix;
@@ -44,11 +47,21 @@ FV3_HD inline double fv3_log_f64(double x) {
   const double s = f / (2.0 + f);
   const double z = s * s;
   const double w = z * z;
+#if defined(FV3_MATH_NO_FMA)
   const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
   const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
   const double R = t2 + t1;
   const double dk = (double)k;
   return s * (hfsq + R) + dk * 1.90821492927058770002e-10 - hfsq + f + dk * 6.93147180369123816490e-01;
+#else
+  // (explicit fused multiply-adds: one correctly rounded operation on the device and in the host emulation alike, so the two still agree to
+  //  the bit while the rest of the library is built with contraction off)
+  const double t1 = w * fv3_fma(w, fv3_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fv3_fma(w, fv3_fma(w, fv3_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double dk = (double)k;
+  return fv3_fma(dk, 6.93147180369123816490e-01, fv3_fma(s, hfsq + R, dk * 1.90821492927058770002e-10) - hfsq + f);
+#endif
 }
 
 // exp(x) (the solvers stay within +-20): x = k ln2 + r, |r| <= ln2 / 2 (two-term ln2, the product k * ln2_hi is exact for
@@ -57,6 +70,7 @@ FV3_HD inline double fv3_log_f64(double x) {
 FV3_HD inline double fv3_exp_f64(double x) {
   if (!(fabs(x) <= 745.0)) return x != x ? x : (x > 0.0 ? HUGE_VAL : 0.0);  // (ldexp below covers the gradual over / underflow up to there)
   const double kf = rint(x * 1.44269504088896338700e+00);
+#if defined(FV3_MATH_NO_FMA)
   const double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
   double p = 1.0 / 6227020800.0;
   p = p * r + 1.0 / 479001600.0;
@@ -72,6 +86,23 @@ FV3_HD inline double fv3_exp_f64(double x) {
   p = p * r + 0.5;
   // exp(r) = 1 + (r + r^2 p): the last addition carries the only rounding of order ulp(1)
   return ldexp(1.0 + (r + (r * r) * p), (int)kf);
+#else
+  const double r = fv3_fma(-kf, 1.90821492927058770002e-10, fv3_fma(-kf, 6.93147180369123816490e-01, x));
+  double p = 1.0 / 6227020800.0;
+  p = fv3_fma(p, r, 1.0 / 479001600.0);
+  p = fv3_fma(p, r, 1.0 / 39916800.0);
+  p = fv3_fma(p, r, 1.0 / 3628800.0);
+  p = fv3_fma(p, r, 1.0 / 362880.0);
+  p = fv3_fma(p, r, 1.0 / 40320.0);
+  p = fv3_fma(p, r, 1.0 / 5040.0);
+  p = fv3_fma(p, r, 1.0 / 720.0);
+  p = fv3_fma(p, r, 1.0 / 120.0);
+  p = fv3_fma(p, r, 1.0 / 24.0);
+  p = fv3_fma(p, r, 1.0 / 6.0);
+  p = fv3_fma(p, r, 0.5);
+  // exp(r) = 1 + (r + r^2 p): the last addition carries the only rounding of order ulp(1)
+  return ldexp(1.0 + fv3_fma(r * r, p, r), (int)kf);
+#endif
 }
 
 #if defined(FV3_LIBM_MATH)
