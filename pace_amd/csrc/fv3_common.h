@@ -96,6 +96,16 @@ inline void fv3_stamp_touch(unsigned long long *, unsigned long long, int) {}
 // in the ISA: vmcnt(7) / vmcnt(2) at the top of the two-tracer marches): d_sw 52.6 vs 52.6 ms, update_dz_d 11.2 vs 11.1 on the same
 // box -- the stores are acknowledged long before the rows arrive, the drain costs nothing.  The conditional form is the default.
 #define FV3_TRASH_SLOTS 4096
+// element at a wave-uniform base + a per-lane byte offset of 32 bits (scalar-base addressing: see KW_ in fv3_nh.hip)
+template <class T>
+FV3_HD inline T *fv3_at(T *base, unsigned byte_off) {
+  return (T *)((char *)base + byte_off);
+}
+template <class T>
+FV3_HD inline const T *fv3_at(const T *base, unsigned byte_off) {
+  return (const T *)((const char *)base + byte_off);
+}
+
 FV3_HD inline void fv3_store_sel(Real *owned_dst, Real *sink, bool owned, Real v) {
 #ifdef FV3_USTORE
   Real *d = owned ? owned_dst : sink;

@@ -198,7 +198,16 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
     }                                                                        \
   }
 
+// Scalar-base addressing: a wave-uniform 64-bit base (the field of the sub-domain) + a 32-bit BYTE offset per lane that carries the level too.
+// With the plain `(arr + tb + k * sk)[pix]` the compiler forms a 64-bit address per access with a vector instruction (it cannot prove that
+// pix * 8 fits 32 bits, and `global_load v, v_off, s[base]` is only selected when the zero-extension of the offset is in the same basic
+// block as the access: a loop-invariant offset never is); here the offset changes with the level, so one 32-bit add per level serves every
+// field of that level.  riem_wave_ok() checks that a sub-domain's field stays below 4 GB.  -DFV3_RIEM_ADDR64: the plain form (A/B).
+#ifdef FV3_RIEM_ADDR64
 #define KW_(arr, k) ((arr) + tb + (long)(k)*sk)[pix]
+#else
+#define KW_(arr, k) (*fv3_at((arr) + tb, pix * (unsigned)sizeof(Real) + (unsigned)(k) * (unsigned)(sk * (long)sizeof(Real))))
+#endif
 #ifndef FV3_RIEM_U
 #define FV3_RIEM_U 4   // levels in flight in the sweeps with 4-5 inputs
 #endif
@@ -457,6 +466,7 @@ inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
   // heavy = riem_solver3 (7 exp/log per level): below 4 waves per CU (line > 40 KB: 127 levels in fp64) the
   // bandwidth-bound column form is faster (25.7 vs 29.1 ms at C768 L127 fp64); riem_solver_c still gains (24.7 vs 29.2)
   if (heavy && !(e && !strcmp(e, "wave")) && line > 40 * 1024) return false;
+  if ((g.nz + 2) * g.sk * (long)sizeof(Real) >= (1L << 32)) return false;  // (KW_: 32-bit byte offsets inside a sub-domain's field)
   return line <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
