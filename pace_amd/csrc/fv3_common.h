@@ -106,12 +106,33 @@ FV3_HD inline const T *fv3_at(const T *base, unsigned byte_off) {
   return (const T *)((const char *)base + byte_off);
 }
 
+// element `idx` (unsigned, 32 bits) of a WAVE-UNIFORM pointer, addressed as scalar base + 32-bit byte offset.  `ptr[idx]` makes the
+// compiler extend idx to 64 bits and shift it (it cannot prove idx * 8 fits 32 bits): a 64-bit vector add per access and a live
+// 64-bit address; with the byte offset formed in 32 bits the access becomes `global_load v, v_off, s[base:base+1]`.  A plane of a
+// sub-domain is far below 4 GB (the marches index inside one plane; the level / sub-domain offset is part of the uniform base).
+#ifdef FV3_EL_PLAIN  // (A/B: the plain element access, per translation unit)
+#define FV3_EL(ptr, idx) ((ptr)[idx])
+#else
+#define FV3_EL(ptr, idx) (*fv3_at((ptr), (unsigned)(idx) * (unsigned)sizeof(*(ptr))))
+#endif
+
 FV3_HD inline void fv3_store_sel(Real *owned_dst, Real *sink, bool owned, Real v) {
 #ifdef FV3_USTORE
   Real *d = owned ? owned_dst : sink;
   *d = v;
 #else
   if (owned) *owned_dst = v;
+  (void)sink;
+#endif
+}
+
+// ... the same with the destination as (wave-uniform base, 32-bit element index): scalar-base addressing (FV3_EL)
+FV3_HD inline void fv3_store_el(Real *base, unsigned idx, Real *sink, bool owned, Real v) {
+#ifdef FV3_USTORE
+  Real *d = owned ? fv3_at(base, idx * (unsigned)sizeof(Real)) : sink;
+  *d = v;
+#else
+  if (owned) FV3_EL(base, idx) = v;
   (void)sink;
 #endif
 }

@@ -181,7 +181,7 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
     const int r_beg = j0 - 2, r_end = j1 + 2 < jed ? j1 + 2 : jed;
     auto ld = [&](int f, int r, int l) -> Real {
       if (top_level && (f == 2 || f == 4)) return (Real)0;  // (never used: the constants replace the corner values)
-      return src[f][pcol[l] + (unsigned)(r * sj32)];
+      return FV3_EL(src[f], pcol[l] + (unsigned)(r * sj32));
     };
     FV3_LANES(blk, lane, l) {
       const int i = i0 - 2 + lane, ic = i < ied ? i : ied;
@@ -244,13 +244,13 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
           const bool interior = i >= ((fl & FV3_W) ? 3 : 1) && i <= ((fl & FV3_E) ? nx - 1 : nx + 1) && jc >= ((fl & FV3_S) ? 3 : 1) && jc <= ((fl & FV3_N) ? ny - 1 : ny + 1);
           if ((ecol || erow) && interior && lane >= 2 && lane <= FV3_WAVE - 2 && jc >= j0 && jc <= j1 + 1) {
             const unsigned p = pcol[l] + (unsigned)(jc * sj32);
-            (gzb + b)[p] = cc[0][l];
-            (gzb + b + sk)[p] = cc[1][l];
-            (pk3b + b)[p] = cc[2][l];
-            (pk3b + b + sk)[p] = cc[3][l];
-            (ppb + b)[p] = cc[4][l];
-            (ppb + b + sk)[p] = cc[5][l];
-            (wk1 + b)[p] = cc[6][l];
+            FV3_EL(gzb + b, p) = cc[0][l];
+            FV3_EL(gzb + b + sk, p) = cc[1][l];
+            FV3_EL(pk3b + b, p) = cc[2][l];
+            FV3_EL(pk3b + b + sk, p) = cc[3][l];
+            FV3_EL(ppb + b, p) = cc[4][l];
+            FV3_EL(ppb + b + sk, p) = cc[5][l];
+            FV3_EL(wk1 + b, p) = cc[6][l];
           }
         }
       }
@@ -273,19 +273,19 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
           const Real wkp = pc.k1 - pc.k0;
           if (i <= nx) {
             const Real du = a.dt / (wkp + (pe_.k1 - pe_.k0)) * ((pc.g1 - pe_.g0) * (pe_.k1 - pc.k0) + (pc.g0 - pe_.g1) * (pc.k1 - pe_.k0));
-            (a.u + b)[p] = (o_u[l] + du + a.dt / (pc.w + pe_.w) * ((pc.g1 - pe_.g0) * (pe_.q1 - pc.q0) + (pc.g0 - pe_.g1) * (pc.q1 - pe_.q0))) * o_rx[l];
+            FV3_EL(a.u + b, p) = (o_u[l] + du + a.dt / (pc.w + pe_.w) * ((pc.g1 - pe_.g0) * (pe_.q1 - pc.q0) + (pc.g0 - pe_.g1) * (pc.q1 - pe_.q0))) * o_rx[l];
           }
           if (jw <= ny) {
             const Real dv = a.dt / (wkp + (pn.k1 - pn.k0)) * ((pc.g1 - pn.g0) * (pn.k1 - pc.k0) + (pc.g0 - pn.g1) * (pc.k1 - pn.k0));
-            (a.v + b)[p] = (o_v[l] + dv + a.dt / (pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
+            FV3_EL(a.v + b, p) = (o_v[l] + dv + a.dt / (pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
           }
         }
         if (next_ok) {  // (the winds of row r-1 and their metric terms: consumed in phase C of the next step)
           const unsigned p = pcol[l] + (unsigned)((jw + 1) * sj32);
-          o_u[l] = (a.u + b)[p];
-          o_v[l] = (a.v + b)[p];
-          o_rx[l] = (rdx + m2)[p];
-          o_ry[l] = (rdy + m2)[p];
+          o_u[l] = FV3_EL(a.u + b, p);
+          o_v[l] = FV3_EL(a.v + b, p);
+          o_rx[l] = FV3_EL(rdx + m2, p);
+          o_ry[l] = FV3_EL(rdy + m2, p);
         }
       }
     };
