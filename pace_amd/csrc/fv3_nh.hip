@@ -292,20 +292,20 @@ struct Sim1W {
         const Real dz_n = r.v[4] - z_top;
         z_top = r.v[4];
         const Real dm_n = r.v[0] * rgrav;
-        const Real pe_n = fv3_exp(((Real)1.0 / ((Real)1.0 - r.v[1])) * fv3_log(-dm_n / dz_n * rgas * r.v[2])) - pm_n;
+        const Real pe_n = fv3_exp(fv3_div((Real)1.0, (Real)1.0 - r.v[1]) * fv3_log(fv3_div(-dm_n, dz_n) * rgas * r.v[2])) - pm_n;
         if (m >= 1) {
           const int k = m - 1;
-          const Real g_rat = dm_k / dm_n;
+          const Real g_rat = fv3_div(dm_k, dm_n);
           const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
           const Real dd = (Real)3.0 * (pe_k + g_rat * pe_n);
           if (k == 0) {
             bet = bb;
-            pp_k = dd / bet;
+            pp_k = fv3_div(dd, bet);
           } else {
-            const Real gam = g_prev / bet;
+            const Real gam = fv3_div(g_prev, bet);
             GAM_PUT(k, gam);
             bet = bb - gam;
-            pp_k = (dd - pp_k) / bet;
+            pp_k = fv3_div(dd - pp_k, bet);
           }
           A[k * FV3_WAVE] = pp_k;
           g_prev = g_rat;
@@ -316,10 +316,10 @@ struct Sim1W {
       {
         const int k = nz - 1;
         const Real bb = (Real)2.0, dd = (Real)3.0 * pe_k;
-        const Real gam = g_prev / bet;
+        const Real gam = fv3_div(g_prev, bet);
         GAM_PUT(k, gam);
         bet = bb - gam;
-        pp_k = (dd - pp_k) / bet;
+        pp_k = fv3_div(dd - pp_k, bet);
         A[k * FV3_WAVE] = pp_k;
       }
       pp_nz = pp_k;
@@ -357,21 +357,21 @@ struct Sim1W {
       };
       KWALK(4, U, true, ld, {
         const int m = K;
-        const Real gm_n = (Real)1.0 / ((Real)1.0 - r.v[1]);
+        const Real gm_n = fv3_div((Real)1.0, (Real)1.0 - r.v[1]);
         const Real dz_n = r.v[2] - z_top;
         z_top = r.v[2];
         const Real pp_hi = A[m * FV3_WAVE];  // PP(m+1)
         if (m >= 1) {
-          const Real aa_n = t1g * (Real)0.5 * (gm_p + gm_n) / (dz_p + dz_n) * (pem + pp_lo);
+          const Real aa_n = fv3_div(t1g * (Real)0.5 * (gm_p + gm_n), dz_p + dz_n) * (pem + pp_lo);
           const int k = m - 1;
           if (k == 0) {
             bet = dmp - aa_n;
-            w2_prev = (dmp * w1p + dt * pp_lo) / bet;
+            w2_prev = fv3_div(dmp * w1p + dt * pp_lo, bet);
           } else {
-            const Real gam = aa_k / bet;
+            const Real gam = fv3_div(aa_k, bet);
             GAM_PUT(k, gam);
             bet = dmp - (aa_k + aa_n + aa_k * gam);
-            w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev) / bet;
+            w2_prev = fv3_div(dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev, bet);
           }
           A[k * FV3_WAVE] = w2_prev;
           aa_k = aa_n;
@@ -385,11 +385,11 @@ struct Sim1W {
         pp_lo = pp_hi;
       })
       {
-        const Real p1 = t1g * gm_p / dz_p * (pem + pp_lo);
-        const Real gam = aa_k / bet;
+        const Real p1 = fv3_div(t1g * gm_p, dz_p) * (pem + pp_lo);
+        const Real gam = fv3_div(aa_k, bet);
         GAM_PUT(nz - 1, gam);
         bet = dmp - (aa_k + p1 + aa_k * gam);
-        w2_prev = (dmp * w1p + dt * (pp_lo - pp_lo2) - p1 * ws - aa_k * w2_prev) / bet;
+        w2_prev = fv3_div(dmp * w1p + dt * (pp_lo - pp_lo2) - p1 * ws - aa_k * w2_prev, bet);
         A[(nz - 1) * FV3_WAVE] = w2_prev;
       }
       // ---- sweep 4 (down): back substitution, W2(k) = W2(k) - gam(k+1) W2(k+1), k = nz-2 .. 0
@@ -438,7 +438,7 @@ struct Sim1W {
         if (K == nz - 1) {
           p1 = (pe_k + (Real)2.0 * pe1) * r3;
         } else {
-          const Real g_rat = dm / dm_below;
+          const Real g_rat = fv3_div(dm, dm_below);
           const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
           p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
         }
@@ -674,7 +674,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
           Real *pef, *gz;
           FV3_HD Real pm(int, Real dm, Real qc) {
             const Real peg_n = peg + dm * ((Real)1.0 - qc);
-            const Real v = (peg_n - peg) / fv3_log(peg_n / peg);
+            const Real v = fv3_div(peg_n - peg, fv3_log(fv3_div(peg_n, peg)));
             peg = peg_n;
             return v;
           }
@@ -796,7 +796,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
               KW_(pk, k + 1) = pk3v;
               KW_(pe, k + 1) = pem;
             }
-            const Real v = (peg_n - peg) / (pelng_n - pelng_k);
+            const Real v = fv3_div(peg_n - peg, pelng_n - pelng_k);
             peg = peg_n;
             pelng_k = pelng_n;
             return v;
