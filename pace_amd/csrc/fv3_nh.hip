@@ -7,6 +7,7 @@
 // registers (tridiagonal gam / pp / w) live in context scratch fields with the same layout.
 #include "fv3_ops.h"
 #include "fv3_math.h"
+#include "fv3_agpr.h"
 
 // column access: uniform (sub-domain, level) base + 32-bit in-plane offset
 #define K_(arr, k) ((arr) + tb + (long)(k)*g.sk)[pix]
@@ -215,31 +216,13 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
 #define FV3_RIEM_U1 8  // ... in the sweeps with 1-2 inputs
 #endif
 
-// A column's worth of one tridiagonal temporary in the lane's REGISTERS (RA form of Sim1W::run).  At one wave per SIMD (what the LDS
-// line allows) a wave owns 512 registers per lane and the solver's working set is ~110: the register file is the largest idle on-chip
-// memory.  The compiler can index at most a 32-dword register tuple with a wave-uniform index (`s_set_gpr_idx_on`), so a column is five
-// 16-level chunks picked by a wave-uniform branch; chunks that do not fit beside the working set live in the accumulation registers and
-// are moved in and out around an access (all register moves: no memory traffic).  80 levels at most; deeper columns keep the scratch fields.
-#define FV3_KREG_LEVELS 80
-#ifndef FV3_RIEM_RP
-#define FV3_RIEM_RP 0
-#endif
+// RA form of Sim1W::run: the tridiagonal `gam` of a column lives in the lane's accumulation registers (fv3_agpr.h) instead of going
+// through the scratch field GAM -- four field passes less per call.  80 levels at most, fp64 build; deeper columns keep the scratch field.
+#define FV3_KREG_LEVELS FV3_AGPR_LEVELS
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef Real fv3_kreg_chunk __attribute__((ext_vector_type(16)));
-#define KREG_DECL(n) fv3_kreg_chunk n##0 = (Real)0, n##1 = (Real)0, n##2 = (Real)0, n##3 = (Real)0, n##4 = (Real)0
-#define KREG_SET(n, k, v)                \
-  do {                                   \
-    const int i_ = (k)&15;               \
-    switch ((k) >> 4) {                  \
-      case 0: n##0[i_] = (v); break;     \
-      case 1: n##1[i_] = (v); break;     \
-      case 2: n##2[i_] = (v); break;     \
-      case 3: n##3[i_] = (v); break;     \
-      default: n##4[i_] = (v); break;    \
-    }                                    \
-  } while (0)
-#define KREG_GET(n, k) \
-  (((k) >> 4) == 0 ? n##0[(k)&15] : ((k) >> 4) == 1 ? n##1[(k)&15] : ((k) >> 4) == 2 ? n##2[(k)&15] : ((k) >> 4) == 3 ? n##3[(k)&15] : n##4[(k)&15])
+#define KREG_DECL(n)
+#define KREG_SET(n, k, v) fv3_agpr_set(k, (double)(v))
+#define KREG_GET(n, k) ((Real)fv3_agpr_get(k))
 #else
 #define KREG_DECL(n) Real n[FV3_KREG_LEVELS]
 #define KREG_SET(n, k, v) n[k] = (v)
@@ -256,16 +239,15 @@ struct Sim1W {
   // A = this lane's LDS line (stride FV3_WAVE); zint = interface heights (nz + 1 levels) the old
   // thickness comes from; wout (optional, may alias w1) receives the new w.
   // GL: the gam arrays live in a second LDS line B (2 waves / CU at L79) instead of the scratch field GAM.
-  // RA: gam and PM live in the lane's registers (KREG_*; nz <= FV3_KREG_LEVELS): six field passes less per call.
+  // RA: gam lives in the lane's accumulation registers (KREG_*; nz <= FV3_KREG_LEVELS): four field passes less per call.
   template <bool GL, bool RA, class C>
   FV3_HD void run(Real *A, Real *B, long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *qcon, const Real *zint, const Real *w1,
                   Real ws, Real *PM, Real *GAM, Real *wout, C &cl) const {
     const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
     constexpr int U = FV3_RIEM_U, U1 = FV3_RIEM_U1;
+    constexpr int UB = RA ? 1 : U1;  // the back substitutions: nothing to prefetch when gam is in registers (one access site)
     Real pp_nz;
-    constexpr bool RP = RA && FV3_RIEM_RP;  // PM in registers too
     KREG_DECL(rg);  // gam
-    KREG_DECL(rp);  // PM
 #define GAM_PUT(k, v)                       \
   do {                                      \
     if constexpr (RA) KREG_SET(rg, k, v);   \
@@ -288,7 +270,7 @@ struct Sim1W {
       KWALK(5, U, true, ld, {
         const int m = K;
         const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
-        if constexpr (RP) KREG_SET(rp, m, pm_n); else KW_(PM, m) = pm_n;
+        KW_(PM, m) = pm_n;
         const Real dz_n = r.v[4] - z_top;
         z_top = r.v[4];
         const Real dm_n = r.v[0] * rgrav;
@@ -332,7 +314,7 @@ struct Sim1W {
     // ---- sweep 2 (down): back substitution, PP(k) = PP(k) - gam(k) PP(k+1), k = nz-1 .. 1
     {
       Real pp_next = pp_nz;
-      KWALK(1, U1, false, ld_gam, {
+      KWALK(1, UB, false, ld_gam, {
         if (K >= 1) {
           Real gk;
           if constexpr (RA) gk = KREG_GET(rg, K); else gk = GL ? B[K * FV3_WAVE] : r.v[0];
@@ -394,7 +376,7 @@ struct Sim1W {
       }
       // ---- sweep 4 (down): back substitution, W2(k) = W2(k) - gam(k+1) W2(k+1), k = nz-2 .. 0
       Real w2_next = w2_prev;
-      KWALK(1, U1, false, ld_gam, {
+      KWALK(1, UB, false, ld_gam, {
         if (K >= 1) {
           Real gk;
           if constexpr (RA) gk = KREG_GET(rg, K); else gk = GL ? B[K * FV3_WAVE] : r.v[0];
@@ -429,7 +411,7 @@ struct Sim1W {
         q.v[0] = KW_(delp, k);
         q.v[1] = KW_(pt, k);
         q.v[2] = KW_(cappa, k);
-        q.v[3] = RP ? (Real)0 : KW_(PM, k);
+        q.v[3] = KW_(PM, k);
         return q;
       };
       KWALK(4, U, false, ld, {
@@ -442,8 +424,7 @@ struct Sim1W {
           const Real bb = (Real)2.0 * ((Real)1.0 + g_rat);
           p1 = (pe_k + bb * pe1 + g_rat * pe2) * r3 - g_rat * p1;
         }
-        Real pmk;
-        if constexpr (RP) pmk = KREG_GET(rp, K); else pmk = r.v[3];
+        const Real pmk = r.v[3];
         const Real dzn = -dm * rgas * r.v[1] * fv3_exp((r.v[2] - (Real)1.0) * fv3_log(fv3_max(p_fac * pmk, p1 + pmk)));
         cl.finish(K, dzn);
         pe2 = pe1;
@@ -470,14 +451,11 @@ inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
   return line <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
-// gam (and PM, -DFV3_RIEM_RP=1) in registers: FV3_RIEM_REGS=1 opts in.  Same values, six field passes less -- and SLOWER (C768 L79 fp64,
-// same box: riem_solver_c 9.64 -> 13.84 ms, riem_solver3 11.32 -> 15.74; with PM as well 19.4 / 25.2): the working set (157 registers)
-// + the array (160) exceed the 256 architectural registers, the compiler keeps the chunks in the accumulation registers and moves 32 of
-// them in and out around EVERY access (5 000 v_accvgpr_read in the kernel).  A form with one "current" chunk that is swapped at the
-// 16-level boundaries compiles to even more whole-chunk copies (the vector phis are not coalesced).  Kept as the A/B form.
+// gam in the accumulation registers (fv3_agpr.h); FV3_RIEM_REGS=0: through the scratch field (A/B, same values).  fp64 build only.
+// (A first attempt let the COMPILER index a register-tuple array: riem_solver_c 9.64 -> 13.84 ms -- DESIGN §7.)
 inline bool riem_reg_arrays(const Geo &g) {
-  static const bool on = getenv("FV3_RIEM_REGS") && getenv("FV3_RIEM_REGS")[0] == '1';
-  return on && !FV3_RIEM_GL && g.nz <= FV3_KREG_LEVELS;
+  static const bool off = getenv("FV3_RIEM_REGS") && getenv("FV3_RIEM_REGS")[0] == '0';
+  return !off && sizeof(Real) == 8 && !FV3_RIEM_GL && g.nz <= FV3_KREG_LEVELS;
 }
 
 #ifndef PG_KC

@@ -45,7 +45,8 @@ def kernels(lib_path, arch="gfx950"):
 
                 name = g("name")
                 if name:
-                    out[name] = dict(vgpr=int(g("vgpr_count")), spill=int(g("vgpr_spill_count")), scratch=int(g("private_segment_fixed_size")), sgpr=int(g("sgpr_count")),
+                    # (.vgpr_count is the unified total: architectural registers rounded up to the accumulation offset + .agpr_count)
+                    out[name] = dict(vgpr=int(g("vgpr_count")), agpr=int(blk.split()[0]), spill=int(g("vgpr_spill_count")), scratch=int(g("private_segment_fixed_size")), sgpr=int(g("sgpr_count")),
                                      lds=int(g("group_segment_fixed_size")))
     return out
 
@@ -58,7 +59,7 @@ def main():
     print(f"{len(ks)} kernels in {lib}")
     for name, k in sorted(ks.items(), key=lambda kv: -kv[1]["vgpr"]):
         if flt in name:
-            print(f"{k['vgpr']:4d} VGPR  {k['spill']:3d} spilled  {k['scratch']:4d} B scratch  {k['sgpr']:3d} SGPR  {name[:110]}")
+            print(f"{k['vgpr']:4d} VGPR ({k['agpr']:3d} acc)  {k['spill']:3d} spilled  {k['scratch']:4d} B scratch  {k['sgpr']:3d} SGPR  {name[:110]}")
 
 
 if __name__ == "__main__":
