@@ -13,7 +13,8 @@
 #pragma once
 #include "fv3_common.h"
 
-#define FV3_AGPR_LEVELS 80
+#define FV3_AGPR_LEVELS 80      // fp64: two registers per level
+#define FV3_AGPR_LEVELS_F32 128  // fp32: one
 #if defined(__HIP_DEVICE_COMPILE__)
 // clang-format off
 #define FV3_AG_CASES(X) \
@@ -54,5 +55,40 @@ __device__ __attribute__((always_inline)) inline double fv3_agpr_get(int k) {
   const int t = k * 20 + 12;
   asm volatile(FV3_AG_JUMP FV3_AG_CASES(FV3_AG_R) ".LFV3AG%=:\n" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [t] "s"(t) : "vcc", "scc");
   return __hiloint2double(hi, lo);
+}
+
+// fp32 build: one register per level, 128 levels (the L127 configurations), 12-byte cases
+// clang-format off
+#define FV3_AG_CASES1(X) \
+  X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+  X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) \
+  X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) \
+  X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) \
+  X(64) X(65) X(66) X(67) X(68) X(69) X(70) X(71) X(72) X(73) X(74) X(75) X(76) X(77) X(78) X(79) \
+  X(80) X(81) X(82) X(83) X(84) X(85) X(86) X(87) X(88) X(89) X(90) X(91) X(92) X(93) X(94) X(95) \
+  X(96) X(97) X(98) X(99) X(100) X(101) X(102) X(103) X(104) X(105) X(106) X(107) X(108) X(109) X(110) X(111) \
+  X(112) X(113) X(114) X(115) X(116) X(117) X(118) X(119) X(120) X(121) X(122) X(123) X(124) X(125) X(126) X(127)
+#define FV3_AG_CLOBBERS1 \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+  "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+  "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+  "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+  "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+  "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+  "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+  "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+// clang-format on
+#define FV3_AG_W1(n0) "v_accvgpr_write_b32 a" #n0 ", %[lo]\n s_branch .LFV3AG%=\n"
+#define FV3_AG_R1(n0) "v_accvgpr_read_b32 %[lo], a" #n0 "\n s_branch .LFV3AG%=\n"
+__device__ __attribute__((always_inline)) inline void fv3_agpr_set(int k, float v) {
+  const int lo = __float_as_int(v);
+  const int t = k * 12 + 12;
+  asm volatile(FV3_AG_JUMP FV3_AG_CASES1(FV3_AG_W1) ".LFV3AG%=:\n" : : [t] "s"(t), [lo] "v"(lo) : "vcc", "scc", FV3_AG_CLOBBERS1);
+}
+__device__ __attribute__((always_inline)) inline float fv3_agpr_get_f32(int k) {
+  int lo;
+  const int t = k * 12 + 12;
+  asm volatile(FV3_AG_JUMP FV3_AG_CASES1(FV3_AG_R1) ".LFV3AG%=:\n" : [lo] "=&v"(lo) : [t] "s"(t) : "vcc", "scc");
+  return __int_as_float(lo);
 }
 #endif

@@ -218,13 +218,15 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
 
 // RA form of Sim1W::run: the tridiagonal `gam` of a column lives in the lane's accumulation registers (fv3_agpr.h) instead of going
 // through the scratch field GAM -- four field passes less per call.  80 levels at most, fp64 build; deeper columns keep the scratch field.
-#define FV3_KREG_LEVELS FV3_AGPR_LEVELS
+#define FV3_KREG_LEVELS (sizeof(Real) == 8 ? FV3_AGPR_LEVELS : FV3_AGPR_LEVELS_F32)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KREG_DECL(n)
-#define KREG_SET(n, k, v) fv3_agpr_set(k, (double)(v))
-#define KREG_GET(n, k) ((Real)fv3_agpr_get(k))
+#define KREG_SET(n, k, v) fv3_agpr_set(k, (Real)(v))
+#define KREG_GET(n, k) fv3_kreg_get((Real)0, k)
+__device__ __attribute__((always_inline)) inline double fv3_kreg_get(double, int k) { return fv3_agpr_get(k); }
+__device__ __attribute__((always_inline)) inline float fv3_kreg_get(float, int k) { return fv3_agpr_get_f32(k); }
 #else
-#define KREG_DECL(n) Real n[FV3_KREG_LEVELS]
+#define KREG_DECL(n) Real n[FV3_AGPR_LEVELS_F32]
 #define KREG_SET(n, k, v) n[k] = (v)
 #define KREG_GET(n, k) n[k]
 #endif
@@ -451,11 +453,11 @@ inline bool riem_wave_ok(const Geo &g, bool heavy = false) {
   return line <= (FV3_RIEM_GL ? 160 : 64) * 1024 && g.nz >= 3;
 }
 inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
-// gam in the accumulation registers (fv3_agpr.h); FV3_RIEM_REGS=0: through the scratch field (A/B, same values).  fp64 build only.
+// gam in the accumulation registers (fv3_agpr.h; 80 levels in fp64, 128 in fp32); FV3_RIEM_REGS=0: through the scratch field (A/B, same values).
 // (A first attempt let the COMPILER index a register-tuple array: riem_solver_c 9.64 -> 13.84 ms -- DESIGN §7.)
 inline bool riem_reg_arrays(const Geo &g) {
   static const bool off = getenv("FV3_RIEM_REGS") && getenv("FV3_RIEM_REGS")[0] == '0';
-  return !off && sizeof(Real) == 8 && !FV3_RIEM_GL && g.nz <= FV3_KREG_LEVELS;
+  return !off && !FV3_RIEM_GL && g.nz <= (int)FV3_KREG_LEVELS;
 }
 
 #ifndef PG_KC

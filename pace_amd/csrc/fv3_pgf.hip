@@ -13,6 +13,7 @@
 // frame-first passes of the sequencer, the frame of every sub-domain -- are evaluated per point with a2b_point.
 // Same expressions in the same order as the staged form: bitwise equal (FV3_NH_PGF=staged is the A/B switch).
 #include "fv3_a2b.h"
+#include "fv3_math.h"
 
 namespace {
 
@@ -272,12 +273,12 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
           const unsigned p = pcol[l] + (unsigned)(jw * sj32);
           const Real wkp = pc.k1 - pc.k0;
           if (i <= nx) {
-            const Real du = a.dt / (wkp + (pe_.k1 - pe_.k0)) * ((pc.g1 - pe_.g0) * (pe_.k1 - pc.k0) + (pc.g0 - pe_.g1) * (pc.k1 - pe_.k0));
-            FV3_EL(a.u + b, p) = (o_u[l] + du + a.dt / (pc.w + pe_.w) * ((pc.g1 - pe_.g0) * (pe_.q1 - pc.q0) + (pc.g0 - pe_.g1) * (pc.q1 - pe_.q0))) * o_rx[l];
+            const Real du = fv3_div(a.dt, wkp + (pe_.k1 - pe_.k0)) * ((pc.g1 - pe_.g0) * (pe_.k1 - pc.k0) + (pc.g0 - pe_.g1) * (pc.k1 - pe_.k0));
+            FV3_EL(a.u + b, p) = (o_u[l] + du + fv3_div(a.dt, pc.w + pe_.w) * ((pc.g1 - pe_.g0) * (pe_.q1 - pc.q0) + (pc.g0 - pe_.g1) * (pc.q1 - pe_.q0))) * o_rx[l];
           }
           if (jw <= ny) {
-            const Real dv = a.dt / (wkp + (pn.k1 - pn.k0)) * ((pc.g1 - pn.g0) * (pn.k1 - pc.k0) + (pc.g0 - pn.g1) * (pc.k1 - pn.k0));
-            FV3_EL(a.v + b, p) = (o_v[l] + dv + a.dt / (pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
+            const Real dv = fv3_div(a.dt, wkp + (pn.k1 - pn.k0)) * ((pc.g1 - pn.g0) * (pn.k1 - pc.k0) + (pc.g0 - pn.g1) * (pc.k1 - pn.k0));
+            FV3_EL(a.v + b, p) = (o_v[l] + dv + fv3_div(a.dt, pc.w + pn.w) * ((pc.g1 - pn.g0) * (pn.q1 - pc.q0) + (pc.g0 - pn.g1) * (pc.q1 - pn.q0))) * o_ry[l];
           }
         }
         if (next_ok) {  // (the winds of row r-1 and their metric terms: consumed in phase C of the next step)
