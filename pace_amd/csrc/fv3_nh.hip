@@ -137,10 +137,12 @@ struct Sim1 {
 // (every tridiagonal temporary is a context scratch field); here a lane owns one column, the
 // PP -> W2 -> PE chain of temporaries lives in ONE LDS line per lane (slot k of a column's line
 // holds PP(k+1), then W2(k), then PE(k+1): each value dies exactly where its successor is born),
-// only the two gam arrays and PM still go through memory, and the old thickness is recomputed from
-// the interface heights instead of being stored.  nz * 512 B of LDS per wave = 4 waves / CU at L79,
-// so memory-level parallelism comes from explicit register prefetch: k_walk() keeps U levels of
-// every input in flight while the U levels loaded before are being computed.
+// the two gam arrays live in the lane's ACCUMULATION registers (RA form, fv3_agpr.h: a wave at one wave per SIMD owns 512
+// registers per lane and the solver uses a third of them), only PM still goes through memory, and the old thickness is
+// recomputed from the interface heights instead of being stored.  nz * 512 B of LDS per wave = 4 waves / CU at L79, so
+// memory-level parallelism comes from explicit register prefetch: KWALK keeps U levels of every input in flight while the U
+// levels loaded before are being computed.  At one wave per SIMD nothing hides a wave's own VALU time: fields are addressed as
+// scalar base + 32-bit byte offset (KW_), divisions use the unscaled sequence (fv3_div), log / exp are range-specific (fv3_math.h).
 // Operation order per value is the one of Sim1::run (bitwise the same results).
 // ---------------------------------------------------------------------------------------------
 template <int N>
