@@ -15,6 +15,10 @@
 #include "fv3_a2b.h"
 #include "fv3_math.h"
 
+#ifndef PG_WPE
+#define PG_WPE (sizeof(Real) == 4 ? 3 : 2)  // waves per SIMD the fused march is sized for (fp32: three)
+#endif
+
 namespace {
 
 #define PG_OUT 60  // corners owned by a wave: 64 columns of the inputs, 2 + 1 of them halo, one more for the east neighbour's corner
@@ -142,7 +146,7 @@ void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, c
   // next tile -- the lower interface of level k is the upper one of level k+1, and adjacent levels resident together on an XCD read
   // it from its L2 (plane-major, consecutive levels land on different XCDs and every interface comes from HBM twice).
   const int nblk = (nz + PG_KB - 1) / PG_KB;
-  launch_waves<2>(c, s, PG_KB, nstrip * nseg, g.nsub * nblk, 0, [=] FV3_HD(const Blk &blk_, char *) {
+  launch_waves<PG_WPE>(c, s, PG_KB, nstrip * nseg, g.nsub * nblk, 0, [=] FV3_HD(const Blk &blk_, char *) {
     const int t = blk_.bz / nblk, k = (blk_.bz - t * nblk) * PG_KB + blk_.bx;
     if (k >= nz) return;
     Blk blk = blk_;

@@ -498,7 +498,9 @@ static void tp2d_staged(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
 #define TS_SEG 64
 #define TS_LINE (FV3_WAVE + 6)
 #ifndef TS_WPE
-#define TS_WPE 2  // waves per SIMD the register allocation is sized for
+// waves per SIMD the register allocation is sized for.  fp64: two (250 registers); the fp32 build needs 170 and runs three -- the marches are
+// bound by the length of a wave's row step, not by a throughput resource, so a third wave is worth 8 - 12 % there
+#define TS_WPE (sizeof(Real) == 4 ? 3 : 2)
 #endif
 #ifndef TS_LDS_ONLY
 #define TS_LDS_ONLY 0

@@ -91,7 +91,11 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
   constexpr bool TR = PART == Q4_EDGE;      // transposed march
-  constexpr int WPE = (ROLE == Q4_QUAD || PART == Q4_EDGE) ? 1 : 2;
+#ifndef FV3_Q4_WPE
+// waves per SIMD the register allocation of the two-tracer interior marches is sized for: two in fp64 (250 registers), four in the fp32 build (128)
+#define FV3_Q4_WPE (sizeof(Real) == 4 ? 4 : 2)
+#endif
+  constexpr int WPE = (ROLE == Q4_QUAD || PART == Q4_EDGE) ? 1 : FV3_Q4_WPE;
   // interior strips: every neighbour read of the step is a wavefront shuffle (DPP), the kernel uses no LDS at all
 #ifdef Q4_NO_DPP
   constexpr bool DPP = false;
