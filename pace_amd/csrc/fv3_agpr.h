@@ -57,6 +57,34 @@ __device__ __attribute__((always_inline)) inline double fv3_agpr_get(int k) {
   return __hiloint2double(hi, lo);
 }
 
+// four consecutive levels at once (one access site for the U = 4 levels a forward sweep produces per loop iteration): 20 cases of
+// 8 writes + branch = 68 bytes; slot s of the column is a[2s], a[2s+1] as above, group g = slots 4g .. 4g+3
+// clang-format off
+#define FV3_AG_GROUPS(X) \
+  X(0, 1, 2, 3, 4, 5, 6, 7) X(8, 9, 10, 11, 12, 13, 14, 15) \
+  X(16, 17, 18, 19, 20, 21, 22, 23) X(24, 25, 26, 27, 28, 29, 30, 31) \
+  X(32, 33, 34, 35, 36, 37, 38, 39) X(40, 41, 42, 43, 44, 45, 46, 47) \
+  X(48, 49, 50, 51, 52, 53, 54, 55) X(56, 57, 58, 59, 60, 61, 62, 63) \
+  X(64, 65, 66, 67, 68, 69, 70, 71) X(72, 73, 74, 75, 76, 77, 78, 79) \
+  X(80, 81, 82, 83, 84, 85, 86, 87) X(88, 89, 90, 91, 92, 93, 94, 95) \
+  X(96, 97, 98, 99, 100, 101, 102, 103) X(104, 105, 106, 107, 108, 109, 110, 111) \
+  X(112, 113, 114, 115, 116, 117, 118, 119) X(120, 121, 122, 123, 124, 125, 126, 127) \
+  X(128, 129, 130, 131, 132, 133, 134, 135) X(136, 137, 138, 139, 140, 141, 142, 143) \
+  X(144, 145, 146, 147, 148, 149, 150, 151) X(152, 153, 154, 155, 156, 157, 158, 159)
+// clang-format on
+#define FV3_AG_W4(r0, r1, r2, r3, r4, r5, r6, r7)                                                                                       \
+  "v_accvgpr_write_b32 a" #r0 ", %[l0]\n v_accvgpr_write_b32 a" #r1 ", %[h0]\n v_accvgpr_write_b32 a" #r2 ", %[l1]\n v_accvgpr_write_b32 a" #r3 ", %[h1]\n" \
+  "v_accvgpr_write_b32 a" #r4 ", %[l2]\n v_accvgpr_write_b32 a" #r5 ", %[h2]\n v_accvgpr_write_b32 a" #r6 ", %[l3]\n v_accvgpr_write_b32 a" #r7 ", %[h3]\n s_branch .LFV3AG%=\n"
+__device__ __attribute__((always_inline)) inline void fv3_agpr_set4(int g, double v0, double v1, double v2, double v3) {
+  const int l0 = __double2loint(v0), h0 = __double2hiint(v0), l1 = __double2loint(v1), h1 = __double2hiint(v1);
+  const int l2 = __double2loint(v2), h2 = __double2hiint(v2), l3 = __double2loint(v3), h3 = __double2hiint(v3);
+  const int t = g * 68 + 12;
+  asm volatile(FV3_AG_JUMP FV3_AG_GROUPS(FV3_AG_W4) ".LFV3AG%=:\n"
+               :
+               : [t] "s"(t), [l0] "v"(l0), [h0] "v"(h0), [l1] "v"(l1), [h1] "v"(h1), [l2] "v"(l2), [h2] "v"(h2), [l3] "v"(l3), [h3] "v"(h3)
+               : "vcc", "scc", FV3_AG_CLOBBERS);
+}
+
 // fp32 build: one register per level, 128 levels (the L127 configurations), 12-byte cases
 // clang-format off
 #define FV3_AG_CASES1(X) \
@@ -90,5 +118,24 @@ __device__ __attribute__((always_inline)) inline float fv3_agpr_get_f32(int k) {
   const int t = k * 12 + 12;
   asm volatile(FV3_AG_JUMP FV3_AG_CASES1(FV3_AG_R1) ".LFV3AG%=:\n" : [lo] "=&v"(lo) : [t] "s"(t) : "vcc", "scc");
   return __int_as_float(lo);
+}
+
+// clang-format off
+#define FV3_AG_GROUPS1(X) \
+  X(0, 1, 2, 3) X(4, 5, 6, 7) X(8, 9, 10, 11) X(12, 13, 14, 15) \
+  X(16, 17, 18, 19) X(20, 21, 22, 23) X(24, 25, 26, 27) X(28, 29, 30, 31) \
+  X(32, 33, 34, 35) X(36, 37, 38, 39) X(40, 41, 42, 43) X(44, 45, 46, 47) \
+  X(48, 49, 50, 51) X(52, 53, 54, 55) X(56, 57, 58, 59) X(60, 61, 62, 63) \
+  X(64, 65, 66, 67) X(68, 69, 70, 71) X(72, 73, 74, 75) X(76, 77, 78, 79) \
+  X(80, 81, 82, 83) X(84, 85, 86, 87) X(88, 89, 90, 91) X(92, 93, 94, 95) \
+  X(96, 97, 98, 99) X(100, 101, 102, 103) X(104, 105, 106, 107) X(108, 109, 110, 111) \
+  X(112, 113, 114, 115) X(116, 117, 118, 119) X(120, 121, 122, 123) X(124, 125, 126, 127)
+// clang-format on
+#define FV3_AG_W41(r0, r1, r2, r3) \
+  "v_accvgpr_write_b32 a" #r0 ", %[l0]\n v_accvgpr_write_b32 a" #r1 ", %[l1]\n v_accvgpr_write_b32 a" #r2 ", %[l2]\n v_accvgpr_write_b32 a" #r3 ", %[l3]\n s_branch .LFV3AG%=\n"
+__device__ __attribute__((always_inline)) inline void fv3_agpr_set4(int g, float v0, float v1, float v2, float v3) {
+  const int l0 = __float_as_int(v0), l1 = __float_as_int(v1), l2 = __float_as_int(v2), l3 = __float_as_int(v3);
+  const int t = g * 36 + 12;
+  asm volatile(FV3_AG_JUMP FV3_AG_GROUPS1(FV3_AG_W41) ".LFV3AG%=:\n" : : [t] "s"(t), [l0] "v"(l0), [l1] "v"(l1), [l2] "v"(l2), [l3] "v"(l3) : "vcc", "scc", FV3_AG_CLOBBERS1);
 }
 #endif

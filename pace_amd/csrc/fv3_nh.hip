@@ -178,7 +178,9 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
 // that owns the register arrays -- a lambda that captures them by reference sends them to scratch memory (the element store turns into a
 // scalar store through a pointer before the closure is dissolved, and nothing promotes the array afterwards).  `load` may be a lambda:
 // it touches no register array.
-#define KWALK(N, U, UP, load, ...)                                           \
+#define KWALK(N, U, UP, load, ...) KWALK_E(N, U, UP, load, , __VA_ARGS__)
+// ... with a statement EPI that runs after the U bodies of a loop iteration (sees c_: the first level index of the group)
+#define KWALK_E(N, U, UP, load, EPI, ...)                                    \
   {                                                                          \
     KRec<N> buf_[U];                                                         \
     _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                       \
@@ -197,6 +199,7 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
         const KRec<N> &r = buf_[u_];                                         \
         __VA_ARGS__                                                          \
       }                                                                      \
+      EPI;                                                                   \
       _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) buf_[u_] = nxt_[u_];  \
     }                                                                        \
   }
@@ -222,15 +225,19 @@ FV3_HD inline void k_walk(int nz, Load load, Body body) {
 // through the scratch field GAM -- four field passes less per call.  80 levels at most, fp64 build; deeper columns keep the scratch field.
 #define FV3_KREG_LEVELS (sizeof(Real) == 8 ? FV3_AGPR_LEVELS : FV3_AGPR_LEVELS_F32)
 #if defined(__HIP_DEVICE_COMPILE__)
+// (level k of the column sits in slot k + 1: the forward sweeps produce gam(m - 1) while they walk level m, so the four values of a
+//  U = 4 loop iteration are the slots c_ .. c_ + 3 = ONE aligned group, stored by one access site per sweep: KREG_SET4)
 #define KREG_DECL(n)
-#define KREG_SET(n, k, v) fv3_agpr_set(k, (Real)(v))
-#define KREG_GET(n, k) fv3_kreg_get((Real)0, k)
+#define KREG_SET(n, k, v) fv3_agpr_set((k) + 1, (Real)(v))
+#define KREG_GET(n, k) fv3_kreg_get((Real)0, (k) + 1)
+#define KREG_SET4(n, c, q) fv3_agpr_set4((c) >> 2, (q)[0], (q)[1], (q)[2], (q)[3])
 __device__ __attribute__((always_inline)) inline double fv3_kreg_get(double, int k) { return fv3_agpr_get(k); }
 __device__ __attribute__((always_inline)) inline float fv3_kreg_get(float, int k) { return fv3_agpr_get_f32(k); }
 #else
-#define KREG_DECL(n) Real n[FV3_AGPR_LEVELS_F32]
-#define KREG_SET(n, k, v) n[k] = (v)
-#define KREG_GET(n, k) n[k]
+#define KREG_DECL(n) Real n[FV3_AGPR_LEVELS_F32 + 4]
+#define KREG_SET(n, k, v) n[(k) + 1] = (v)
+#define KREG_GET(n, k) n[(k) + 1]
+#define KREG_SET4(n, c, q) n[c] = (q)[0], n[(c) + 1] = (q)[1], n[(c) + 2] = (q)[2], n[(c) + 3] = (q)[3]
 #endif
 
 struct Sim1W {
@@ -252,11 +259,31 @@ struct Sim1W {
     constexpr int UB = RA ? 1 : U1;  // the back substitutions: nothing to prefetch when gam is in registers (one access site)
     Real pp_nz;
     KREG_DECL(rg);  // gam
+#ifdef FV3_RIEM_NO_G4  // (A/B: one access site per level of the unrolled body)
+    constexpr bool G4 = false;
+#else
+    constexpr bool G4 = RA && U == 4;  // the forward sweeps store the four gam of a loop iteration through one access site
+#endif
+    Real gq[4] = {(Real)0, (Real)0, (Real)0, (Real)0};
+    (void)gq;
 #define GAM_PUT(k, v)                       \
   do {                                      \
     if constexpr (RA) KREG_SET(rg, k, v);   \
     else if (GL) B[(k)*FV3_WAVE] = (v);     \
     else KW_(GAM, k) = (v);                 \
+  } while (0)
+// (inside a KWALK body: u_ is the body's static position in its group)
+#define GAM_PUT_U(k, v)                     \
+  do {                                      \
+    if constexpr (G4) gq[u_ & 3] = (v);     \
+    else GAM_PUT(k, v);                     \
+  } while (0)
+#define GAM_FLUSH4()                        \
+  do {                                      \
+    if constexpr (G4) {                     \
+      KREG_SET4(rg, c_, gq);                \
+      gq[0] = gq[1] = gq[2] = gq[3] = (Real)0; \
+    }                                       \
   } while (0)
     // ---- sweep 1 (up): layer pressures, forward elimination for pp.  PP(k+1) -> slot k
     {
@@ -271,7 +298,7 @@ struct Sim1W {
         q.v[4] = KW_(zint, k + 1);
         return q;
       };
-      KWALK(5, U, true, ld, {
+      KWALK_E(5, U, true, ld, GAM_FLUSH4(), {
         const int m = K;
         const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
         KW_(PM, m) = pm_n;
@@ -289,7 +316,7 @@ struct Sim1W {
             pp_k = fv3_div(dd, bet);
           } else {
             const Real gam = fv3_div(g_prev, bet);
-            GAM_PUT(k, gam);
+            GAM_PUT_U(k, gam);
             bet = bb - gam;
             pp_k = fv3_div(dd - pp_k, bet);
           }
@@ -341,7 +368,7 @@ struct Sim1W {
         q.v[3] = KW_(w1, k);
         return q;
       };
-      KWALK(4, U, true, ld, {
+      KWALK_E(4, U, true, ld, GAM_FLUSH4(), {
         const int m = K;
         const Real gm_n = fv3_div((Real)1.0, (Real)1.0 - r.v[1]);
         const Real dz_n = r.v[2] - z_top;
@@ -355,7 +382,7 @@ struct Sim1W {
             w2_prev = fv3_div(dmp * w1p + dt * pp_lo, bet);
           } else {
             const Real gam = fv3_div(aa_k, bet);
-            GAM_PUT(k, gam);
+            GAM_PUT_U(k, gam);
             bet = dmp - (aa_k + aa_n + aa_k * gam);
             w2_prev = fv3_div(dmp * w1p + dt * (pp_lo - pp_lo2) - aa_k * w2_prev, bet);
           }
@@ -437,6 +464,8 @@ struct Sim1W {
       })
     }
 #undef GAM_PUT
+#undef GAM_PUT_U
+#undef GAM_FLUSH4
   }
 };
 
@@ -459,7 +488,7 @@ inline bool riem_gam_lds(const Geo &) { return FV3_RIEM_GL != 0; }
 // (A first attempt let the COMPILER index a register-tuple array: riem_solver_c 9.64 -> 13.84 ms -- DESIGN §7.)
 inline bool riem_reg_arrays(const Geo &g) {
   static const bool off = getenv("FV3_RIEM_REGS") && getenv("FV3_RIEM_REGS")[0] == '0';
-  return !off && !FV3_RIEM_GL && g.nz <= (int)FV3_KREG_LEVELS;
+  return !off && !FV3_RIEM_GL && g.nz < (int)FV3_KREG_LEVELS;  // (level k sits in slot k + 1)
 }
 
 #ifndef PG_KC
