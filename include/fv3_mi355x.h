@@ -371,6 +371,11 @@ const char *fv3_op_name(int op);
 /* accumulated milliseconds and call counts per fv3_op (arrays of FV3_OP_COUNT); waits for the events */
 int fv3_profile_read(fv3_ctx *, double *ms_sum, int64_t *calls, int reset);
 
+/* Device self-test of the hand-written fp64 arithmetic of the Riemann solvers (no reference counterpart; tests/test_device_math.py).
+ * x, y, out: device pointers to n doubles.  which 0: out = x / y by the solvers' division sequence; 1: their log; 2: their exp;
+ * 3: round trip through the 80 accumulation-register slots of one wave (n = 80 * 64).  fp64 values in both builds. */
+int fv3_selftest_math(fv3_ctx *, int which, const double *x, const double *y, double *out, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1579,6 +1579,58 @@ extern "C" int fv3_apply_diffusive_heating(fv3_ctx *c, const fv3_field *delp_, c
   return fv3_post(c, (fv3_stream_t)stream, "apply_diffusive_heating");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self-test of the hand-written arithmetic / register tables of this file ON THE DEVICE (tests/test_device_math.py): the claims "fv3_div
+// is bit for bit `/`", "log / exp are the host emulation's" and "every slot of the accumulation-register column holds what was put
+// there" are checked directly, not only through the solvers.  x, y, out: device pointers to n doubles.
+//   which 0: out = fv3_div(x, y)    1: out = fv3_log(x)    2: out = fv3_exp(x)
+//   which 3: n = 80 * 64: one wave puts x[k * 64 + lane] into slot k (k = 0 .. 79; slots 4g .. 4g+3 through the group table when
+//            g is odd, one by one when even), then reads the slots back in descending order into out[k * 64 + lane]
+// ---------------------------------------------------------------------------------------------
+#ifndef FV3_HOST_EMU
+__global__ void __launch_bounds__(256) fv3_selftest_math_kernel(int which, const double *x, const double *y, double *out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = which == 0 ? fv3_div(x[i], y[i]) : which == 1 ? fv3_log(x[i]) : fv3_exp(x[i]);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) fv3_selftest_agpr_kernel(const double *x, double *out) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass parses kernel bodies too; the register tables exist in the device pass only)
+  const int lane = threadIdx.x;
+  for (int g = 0; g < FV3_AGPR_LEVELS / 4; ++g) {
+    const double v0 = x[(4 * g + 0) * 64 + lane], v1 = x[(4 * g + 1) * 64 + lane], v2 = x[(4 * g + 2) * 64 + lane], v3 = x[(4 * g + 3) * 64 + lane];
+    if (g & 1) {
+      fv3_agpr_set4(g, v0, v1, v2, v3);
+    } else {
+      fv3_agpr_set(4 * g + 0, v0);
+      fv3_agpr_set(4 * g + 1, v1);
+      fv3_agpr_set(4 * g + 2, v2);
+      fv3_agpr_set(4 * g + 3, v3);
+    }
+  }
+  for (int k = FV3_AGPR_LEVELS - 1; k >= 0; --k) out[k * 64 + lane] = fv3_agpr_get(k);
+#else
+  (void)x;
+  (void)out;
+#endif
+}
+#endif
+extern "C" int fv3_selftest_math(fv3_ctx *c, int which, const double *x, const double *y, double *out, int64_t n, void *stream) {
+  if (!c || !x || !out || n < 0 || which < 0 || which > 3 || (which == 0 && !y)) return FV3_ERR_ARG;
+  if (which == 3 && n != (int64_t)FV3_AGPR_LEVELS * 64) return fv3_fail(c, FV3_ERR_ARG, "fv3_selftest_math(3): n must be 80 * 64");
+  if (n == 0) return FV3_OK;
+#ifdef FV3_HOST_EMU
+  (void)stream;
+  for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? fv3_div(x[i], y[i]) : which == 1 ? fv3_log(x[i]) : which == 2 ? fv3_exp(x[i]) : x[i];
+  return FV3_OK;
+#else
+  if (which == 3)
+    hipLaunchKernelGGL(fv3_selftest_agpr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, out);
+  else
+    hipLaunchKernelGGL(fv3_selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, x, y, out, n);
+  return fv3_post(c, (fv3_stream_t)stream, "selftest_math");
+#endif
+}
+
 #ifdef FV3_HOST_EMU
 // test hook of the host-emulation library only (tests/test_fast_math.py): the solvers' log on an array
 extern "C" void fv3_hostemu_log(const double *x, double *y, long n) {

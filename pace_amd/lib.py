@@ -144,6 +144,7 @@ _PROTOS = {
     "fv3_ctx_set_profiling": (C.c_int, [C.c_void_p, _I]),
     "fv3_op_name": (C.c_char_p, [_I]),
     "fv3_profile_read": (C.c_int, [C.c_void_p, P(C.c_double), P(C.c_int64), _I]),
+    "fv3_selftest_math": (C.c_int, [C.c_void_p, _I, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _S]),
     "fv3_gather_plan_create": (C.c_int, [C.c_void_p, P(C.c_void_p), C.c_int64, P(C.c_int64), P(C.c_int64), P(C.c_int8)]),
     "fv3_gather_plan_destroy": (C.c_int, [C.c_void_p]),
     "fv3_gather_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _I, _S]),
