@@ -324,8 +324,10 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
 // (the outputs are written once and not read again by this kernel: non-temporal stores, 6 % faster at C768)
 #if !defined(CSWF_NO_NT) && !defined(FV3_HOST_EMU)
 #define CSWF_ST(ptr, val) __builtin_nontemporal_store((Real)(val), (ptr))
+#define CSWF_STE(base, idx, val) __builtin_nontemporal_store((Real)(val), &FV3_EL(base, idx))
 #else
 #define CSWF_ST(ptr, val) (*(ptr) = (val))
+#define CSWF_STE(base, idx, val) (FV3_EL(base, idx) = (val))
 #endif
 static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *delp, const Real *pt, const Real *w, Real *ua, Real *va, Real *uc,
                              Real *vc, Real *ut, Real *vt, Real *divgd, Real *delpc, Real *ptc, Real *omga, Real *ke, Real *vort, Real dt2, bool do_div) {
@@ -391,7 +393,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
 #define CSW_ROWS(R_)                                                                                                                          \
   const unsigned pa = pcol[l] + (unsigned)(((R_) - 2 < Msd ? Msd : (R_) - 2) * sj32), pb = pcol[l] + (unsigned)(((R_) - 1 < Msd ? Msd : (R_) - 1) * sj32), \
                  pc = pcol[l] + (unsigned)(((R_) - 3 < Msd ? Msd : (R_) - 3) * sj32);
-#define CSW_LD1(i, n, ptr, pp) mn_##n[l] = (ptr + m2)[pp];
+#define CSW_LD1(i, n, ptr, pp) mn_##n[l] = FV3_EL(ptr + m2, pp);
 #define CSW_LOAD_MET(R_) \
   {                      \
     CSW_ROWS(R_)         \
@@ -411,7 +413,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
     Real *lds = (Real *)smem_;
     Real sh[(CSWF_NMET + CSWF_NW - 1) / CSWF_NW][FV3_LPT];
 #define CSW_LDSH(i, n, ptr, pp) \
-  if ((i % CSWF_NW) == wv) sh[i / CSWF_NW][l] = (ptr + m2)[pp];
+  if ((i % CSWF_NW) == wv) sh[i / CSWF_NW][l] = FV3_EL(ptr + m2, pp);
 #define CSW_WRSH(i, n, ptr, pp) \
   if ((i % CSWF_NW) == wv) lds[(slot_ * CSWF_NMET + i) * FV3_WAVE + lane] = sh[i / CSWF_NW][l];
 #define CSW_RDSH(i, n, ptr, pp) mn_##n[l] = lds[(slot_ * CSWF_NMET + i) * FV3_WAVE + lane];
@@ -439,16 +441,16 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
       d0[l] = d1[l] = d2[l] = (Real)1;
       const int R0_ = ja - 3;
       auto row = [&](int r) { return (unsigned)((r < Msd ? Msd : r > r_end ? r_end : r) * sj32); };
-      nu1[l] = ub[pcol[l] + row(R0_)];
-      nv1[l] = vb[pcol[l] + row(R0_)];
-      nu2[l] = ub[pcol[l] + row(R0_ + 1)];
-      nv2[l] = vb[pcol[l] + row(R0_ + 1)];
-      nd1[l] = db[pcol[l] + row(R0_ - 1)];
-      np1[l] = pb_[pcol[l] + row(R0_ - 1)];
-      nw1[l] = wb[pcol[l] + row(R0_ - 1)];
-      nd2[l] = db[pcol[l] + row(R0_)];
-      np2[l] = pb_[pcol[l] + row(R0_)];
-      nw2[l] = wb[pcol[l] + row(R0_)];
+      nu1[l] = FV3_EL(ub, pcol[l] + row(R0_));
+      nv1[l] = FV3_EL(vb, pcol[l] + row(R0_));
+      nu2[l] = FV3_EL(ub, pcol[l] + row(R0_ + 1));
+      nv2[l] = FV3_EL(vb, pcol[l] + row(R0_ + 1));
+      nd1[l] = FV3_EL(db, pcol[l] + row(R0_ - 1));
+      np1[l] = FV3_EL(pb_, pcol[l] + row(R0_ - 1));
+      nw1[l] = FV3_EL(wb, pcol[l] + row(R0_ - 1));
+      nd2[l] = FV3_EL(db, pcol[l] + row(R0_));
+      np2[l] = FV3_EL(pb_, pcol[l] + row(R0_));
+      nw2[l] = FV3_EL(wb, pcol[l] + row(R0_));
       CSW_LOAD_MET(R0_)
       if constexpr (SHARE) {
         CSW_ROWS(R0_ + 1)
@@ -486,11 +488,11 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         nd1[l] = nd2[l];
         np1[l] = np2[l];
         nw1[l] = nw2[l];
-        nu2[l] = ub[pcol[l] + rn2];
-        nv2[l] = vb[pcol[l] + rn2];
-        nd2[l] = db[pcol[l] + rn1];
-        np2[l] = pb_[pcol[l] + rn1];
-        nw2[l] = wb[pcol[l] + rn1];
+        nu2[l] = FV3_EL(ub, pcol[l] + rn2);
+        nv2[l] = FV3_EL(vb, pcol[l] + rn2);
+        nd2[l] = FV3_EL(db, pcol[l] + rn1);
+        np2[l] = FV3_EL(pb_, pcol[l] + rn1);
+        nw2[l] = FV3_EL(wb, pcol[l] + rn1);
 #define CSW_ROT(i, n, ptr, pp) mc_##n[l] = mn_##n[l];
         CSW_METT(CSW_ROT)
 #undef CSW_ROT
@@ -532,14 +534,14 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real vt_o = vtv > (Real)0 ? dt2 * vtv * mc_dx[l] * mc_s4[l] : dt2 * vtv * mc_dx[l] * mc_s2[l];
         const unsigned pd = pcol[l] + (unsigned)(jd * sj32), pv = pcol[l] + (unsigned)(jv * sj32);
         if (c_r0[l] && seg_d) {
-          CSWF_ST((ua + b) + (pd), ua_);
-          CSWF_ST((va + b) + (pd), va_);
-          CSWF_ST((ut + b) + (pd), ut_o);
-          if (!(c_re[l] && r_re_d)) CSWF_ST((uc + b) + (pd), ucv);  // the rim of the rectangle: the stage E kernel finishes it
+          CSWF_STE(ua + b, pd, ua_);
+          CSWF_STE(va + b, pd, va_);
+          CSWF_STE(ut + b, pd, ut_o);
+          if (!(c_re[l] && r_re_d)) CSWF_STE(uc + b, pd, ucv);  // the rim of the rectangle: the stage E kernel finishes it
         }
         if (c_r0[l] && seg_v) {
-          CSWF_ST((vt + b) + (pv), vt_o);
-          if (!(c_re[l] && r_re_v)) CSWF_ST((vc + b) + (pv), vcv);
+          CSWF_STE(vt + b, pv, vt_o);
+          if (!(c_re[l] && r_re_v)) CSWF_STE(vc + b, pv, vcv);
         }
         // west-face fluxes of the cell (lc, R-2): upwind cell lc-1 or lc
         {
@@ -575,7 +577,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real s3w = FV3_LANE_SHR(1, s_s3, l, lane), c3w = FV3_LANE_SHR(1, s_c3, l, lane);
           const Real vf = (v1[l] - (Real)0.25 * (FV3_LANE_SHR(1, s_ua, l, lane) + uav[l]) * (c3w + mc_c1[l])) * mc_dxc[l] * (Real)0.5 * (s3w + mc_s1[l]);
           const Real dv = vf_prev[l] - vf + FV3_LANE_SHR(1, s_uf, l, lane) - ufv[l];
-          if (c_div[l] && r_div) CSWF_ST((divgd + b) + (pd), mc_rac[l] * dv);
+          if (c_div[l] && r_div) CSWF_STE(divgd + b, pd, mc_rac[l] * dv);
           vf_prev[l] = vf;
         }
         // transport: x fluxes at the faces lc (own) and lc + 1 (the neighbouring lane's), y fluxes at the faces R-2 (carried) and R-1
@@ -587,9 +589,9 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real g2_hi = g1_hi * (upn ? w1[l] : w2[l]);
         const Real dpc = d1[l] + (s_f1[l] - fx1e + g1_lo[l] - g1_hi) * mc_ra[l];
         if (c_rd[l] && r_rd) {
-          CSWF_ST((delpc + b) + (pd), dpc);
-          CSWF_ST((ptc + b) + (pd), (p1[l] * d1[l] + (s_f[l] - fxe + g_lo[l] - g_hi) * mc_ra[l]) / dpc);
-          CSWF_ST((omga + b) + (pd), (w1[l] * d1[l] + (s_f2[l] - fx2e + g2_lo[l] - g2_hi) * mc_ra[l]) / dpc);
+          CSWF_STE(delpc + b, pd, dpc);
+          CSWF_STE(ptc + b, pd, (p1[l] * d1[l] + (s_f[l] - fxe + g_lo[l] - g_hi) * mc_ra[l]) / dpc);
+          CSWF_STE(omga + b, pd, (w1[l] * d1[l] + (s_f2[l] - fx2e + g2_lo[l] - g2_hi) * mc_ra[l]) / dpc);
         }
         g1_lo[l] = g1_hi;
         g_lo[l] = g_hi;
@@ -601,8 +603,8 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real kv = (Real)0.5 * dt2 * (uav[l] * kev + vav[l] * vov);
         const Real vo = uc_prev[l] * dxc_prev[l] - ucv_[l] * mc_dxc[l] - FV3_LANE_SHR(1, s_pvd, l, lane) + vc_prev[l] * mc_dyc[l];
         const Real vr = mc_fc[l] + mc_rac[l] * vo;
-        if (c_rd[l] && r_rd && (c_kb[l] || kb_row)) CSWF_ST((ke + b) + (pd), kv);
-        if (c_vr[l] && r_vr && (c_vb[l] || vb_row)) CSWF_ST((vort + b) + (pd), vr);
+        if (c_rd[l] && r_rd && (c_kb[l] || kb_row)) CSWF_STE(ke + b, pd, kv);
+        if (c_vr[l] && r_vr && (c_vb[l] || vb_row)) CSWF_STE(vort + b, pd, vr);
         kev_[l] = kv;
         vov_[l] = vr;
         s_vo[l] = vr;
@@ -615,7 +617,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real fy1 = dt2 * (v0[l] - ucp * cu_prev[l]) / mc_su[l];
           const Real fyv = fy1 > (Real)0 ? vo_prev[l] : vr;
           const Real un = ucp + fy1 * fyv + mc_rdx[l] * (ke_w[l] - ke_prev[l]);
-          if (c_re[l] && r_re_e) CSWF_ST((uc + b) + (pcol[l] + (unsigned)(je * sj32)), un);
+          if (c_re[l] && r_re_e) CSWF_STE(uc + b, pcol[l] + (unsigned)(je * sj32), un);
         }
         {
           const Real vcp = vc_prev[l];
@@ -623,7 +625,7 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
           const Real vre = FV3_LANE_SHL(1, s_vo, l, lane);
           const Real fxv = fx1 > (Real)0 ? vr : vre;
           const Real vn = vcp - fx1 * fxv + mc_rdy[l] * (ke_prev[l] - kv);
-          if (c_re[l] && r_re_d) CSWF_ST((vc + b) + (pcol[l] + (unsigned)(jd * sj32)), vn);
+          if (c_re[l] && r_re_d) CSWF_STE(vc + b, pcol[l] + (unsigned)(jd * sj32), vn);
         }
         s_ke[l] = kv;
         ke_prev[l] = kv;
