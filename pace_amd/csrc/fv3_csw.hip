@@ -366,8 +366,10 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
     Real u0[FV3_LPT], u1[FV3_LPT], u2[FV3_LPT], u3[FV3_LPT], v0[FV3_LPT], v1[FV3_LPT], v2[FV3_LPT], v3[FV3_LPT];
     Real t0[FV3_LPT], t1[FV3_LPT], t2[FV3_LPT], t3[FV3_LPT];
     Real d0[FV3_LPT], d1[FV3_LPT], d2[FV3_LPT], p0[FV3_LPT], p1[FV3_LPT], p2[FV3_LPT], w0[FV3_LPT], w1[FV3_LPT], w2[FV3_LPT];  // delp / pt / w rows R-3 .. R-1
-    Real nu1[FV3_LPT], nv1[FV3_LPT], nu2[FV3_LPT], nv2[FV3_LPT];                                                              // rows R+1, R+2 of u / v
-    Real nd1[FV3_LPT], np1[FV3_LPT], nw1[FV3_LPT], nd2[FV3_LPT], np2[FV3_LPT], nw2[FV3_LPT];                                  // rows R, R+1 of delp / pt / w
+    // Rows in flight: u / v of rows R+1, R+2 and delp / pt / w of rows R, R+1, in TWO register sets that alternate by the step's STATIC parity
+    // (the march is unrolled by two).  A rolled rotation (next = next2 at the top of every step) is a register copy of a load still in flight:
+    // it waits for the row requested ONE step ago, i.e. the prefetch distance of two rows was really one (-DCSWF_ROLLED: that form, A/B).
+    Real nfu[2][FV3_LPT], nfv[2][FV3_LPT], nfd[2][FV3_LPT], nfp[2][FV3_LPT], nfw[2][FV3_LPT];
     // values the neighbouring lanes read
     Real s_ut[FV3_LPT], s_v[FV3_LPT], s_ua[FV3_LPT], s_uf[FV3_LPT], s_uc[FV3_LPT], s_d[FV3_LPT], s_p[FV3_LPT], s_w[FV3_LPT];
     Real s_f1[FV3_LPT], s_f[FV3_LPT], s_f2[FV3_LPT], s_pvd[FV3_LPT], s_ke[FV3_LPT], s_vo[FV3_LPT], s_s3[FV3_LPT], s_c3[FV3_LPT];
@@ -441,23 +443,32 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
       d0[l] = d1[l] = d2[l] = (Real)1;
       const int R0_ = ja - 3;
       auto row = [&](int r) { return (unsigned)((r < Msd ? Msd : r > r_end ? r_end : r) * sj32); };
-      nu1[l] = FV3_EL(ub, pcol[l] + row(R0_));
-      nv1[l] = FV3_EL(vb, pcol[l] + row(R0_));
-      nu2[l] = FV3_EL(ub, pcol[l] + row(R0_ + 1));
-      nv2[l] = FV3_EL(vb, pcol[l] + row(R0_ + 1));
-      nd1[l] = FV3_EL(db, pcol[l] + row(R0_ - 1));
-      np1[l] = FV3_EL(pb_, pcol[l] + row(R0_ - 1));
-      nw1[l] = FV3_EL(wb, pcol[l] + row(R0_ - 1));
-      nd2[l] = FV3_EL(db, pcol[l] + row(R0_));
-      np2[l] = FV3_EL(pb_, pcol[l] + row(R0_));
-      nw2[l] = FV3_EL(wb, pcol[l] + row(R0_));
+      nfu[0][l] = FV3_EL(ub, pcol[l] + row(R0_));
+      nfv[0][l] = FV3_EL(vb, pcol[l] + row(R0_));
+      nfu[1][l] = FV3_EL(ub, pcol[l] + row(R0_ + 1));
+      nfv[1][l] = FV3_EL(vb, pcol[l] + row(R0_ + 1));
+      nfd[0][l] = FV3_EL(db, pcol[l] + row(R0_ - 1));
+      nfp[0][l] = FV3_EL(pb_, pcol[l] + row(R0_ - 1));
+      nfw[0][l] = FV3_EL(wb, pcol[l] + row(R0_ - 1));
+      nfd[1][l] = FV3_EL(db, pcol[l] + row(R0_));
+      nfp[1][l] = FV3_EL(pb_, pcol[l] + row(R0_));
+      nfw[1][l] = FV3_EL(wb, pcol[l] + row(R0_));
       CSW_LOAD_MET(R0_)
       if constexpr (SHARE) {
         CSW_ROWS(R0_ + 1)
         CSW_METT(CSW_LDSH)
       }
     }
+#ifdef CSWF_ROLLED
     for (int R = ja - 3; R <= r_end; ++R) {
+      const int h_ = 0;
+#else
+    for (int R2_ = ja - 3; R2_ <= r_end; R2_ += 2) {
+#pragma unroll
+    for (int h_ = 0; h_ < 2; ++h_) {
+      const int R = R2_ + h_;
+      if (R > r_end) break;
+#endif
       const unsigned rn2 = (unsigned)((R + 2 < r_end ? R + 2 : r_end) * sj32), rn1 = (unsigned)((R + 1 < r_end ? R + 1 : r_end) * sj32);
       const int jd = R - 2, jv = R - 1, je = R - 3;
       const bool seg_d = jd >= ja && jd <= jb, seg_v = jv >= ja && jv <= jb, seg_e = je >= ja && je <= jb;
@@ -469,30 +480,38 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         u0[l] = u1[l];
         u1[l] = u2[l];
         u2[l] = u3[l];
-        u3[l] = nu1[l];
+        u3[l] = nfu[h_][l];
         v0[l] = v1[l];
         v1[l] = v2[l];
         v2[l] = v3[l];
-        v3[l] = nv1[l];
+        v3[l] = nfv[h_][l];
         d0[l] = d1[l];
         d1[l] = d2[l];
-        d2[l] = nd1[l];
+        d2[l] = nfd[h_][l];
         p0[l] = p1[l];
         p1[l] = p2[l];
-        p2[l] = np1[l];
+        p2[l] = nfp[h_][l];
         w0[l] = w1[l];
         w1[l] = w2[l];
-        w2[l] = nw1[l];
-        nu1[l] = nu2[l];
-        nv1[l] = nv2[l];
-        nd1[l] = nd2[l];
-        np1[l] = np2[l];
-        nw1[l] = nw2[l];
-        nu2[l] = FV3_EL(ub, pcol[l] + rn2);
-        nv2[l] = FV3_EL(vb, pcol[l] + rn2);
-        nd2[l] = FV3_EL(db, pcol[l] + rn1);
-        np2[l] = FV3_EL(pb_, pcol[l] + rn1);
-        nw2[l] = FV3_EL(wb, pcol[l] + rn1);
+        w2[l] = nfw[h_][l];
+#ifdef CSWF_ROLLED
+        nfu[0][l] = nfu[1][l];
+        nfv[0][l] = nfv[1][l];
+        nfd[0][l] = nfd[1][l];
+        nfp[0][l] = nfp[1][l];
+        nfw[0][l] = nfw[1][l];
+        nfu[1][l] = FV3_EL(ub, pcol[l] + rn2);
+        nfv[1][l] = FV3_EL(vb, pcol[l] + rn2);
+        nfd[1][l] = FV3_EL(db, pcol[l] + rn1);
+        nfp[1][l] = FV3_EL(pb_, pcol[l] + rn1);
+        nfw[1][l] = FV3_EL(wb, pcol[l] + rn1);
+#else
+        nfu[h_][l] = FV3_EL(ub, pcol[l] + rn2);
+        nfv[h_][l] = FV3_EL(vb, pcol[l] + rn2);
+        nfd[h_][l] = FV3_EL(db, pcol[l] + rn1);
+        nfp[h_][l] = FV3_EL(pb_, pcol[l] + rn1);
+        nfw[h_][l] = FV3_EL(wb, pcol[l] + rn1);
+#endif
 #define CSW_ROT(i, n, ptr, pp) mc_##n[l] = mn_##n[l];
         CSW_METT(CSW_ROT)
 #undef CSW_ROT
@@ -637,6 +656,9 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         cv_prev[l] = mc_cv[l];
       }
     }
+#ifndef CSWF_ROLLED
+    }
+#endif
 #undef CSW_LOAD_MET
 #undef CSW_ROWS
 #undef CSW_LD1
