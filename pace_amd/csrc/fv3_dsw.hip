@@ -217,13 +217,13 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
           Real cr;
           if (x > (Real)0) {
             cr = x * rdxa_m;
-            (xfx + b)[p] = dy_ * x * s3;
+            FV3_ST_NT((xfx + b)[p], dy_ * x * s3);
           } else {
             cr = x * rdxa_0;
-            (xfx + b)[p] = dy_ * x * s1;
+            FV3_ST_NT((xfx + b)[p], dy_ * x * s1);
           }
-          (crx + b)[p] = cr;
-          if (cx) (cx + b)[p] += cr;
+          FV3_ST_NT((crx + b)[p], cr);
+          if (cx) FV3_ST_NT((cx + b)[p], (cx + b)[p] + cr);
         }
       }
       if (int_v) {
@@ -234,13 +234,13 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
           Real cr;
           if (y > (Real)0) {
             cr = y * rdya_m;
-            (yfx + b)[p] = dx_ * y * s4;
+            FV3_ST_NT((yfx + b)[p], dx_ * y * s4);
           } else {
             cr = y * rdya_0;
-            (yfx + b)[p] = dx_ * y * s2;
+            FV3_ST_NT((yfx + b)[p], dx_ * y * s2);
           }
-          (cry + b)[p] = cr;
-          if (cy) (cy + b)[p] += cr;
+          FV3_ST_NT((cry + b)[p], cr);
+          if (cy) FV3_ST_NT((cy + b)[p], (cy + b)[p] + cr);
         }
       }
     }
@@ -1272,7 +1272,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         hs = (o_delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
                                      ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2)));
       }
-      if (heat_on) (heat_source + b)[p] += hs;
+      if (heat_on) FV3_ST_NT((heat_source + b)[p], (heat_source + b)[p] + hs);
     }
   });
   return fv3_post(c, s, "d_sw");

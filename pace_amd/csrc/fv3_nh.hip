@@ -430,7 +430,7 @@ struct Sim1W {
         const Real w2k = A[K * FV3_WAVE];
         pe_run = pe_run + r.v[0] * rgrav * (w2k - r.v[1]) * rdt;
         A[K * FV3_WAVE] = pe_run;
-        if (wout) KW_(wout, K) = w2k;
+        if (wout) FV3_ST_NT(KW_(wout, K), w2k);
         cl.out_pe(K + 1, pe_run, r.v[0]);
       })
     }
@@ -691,11 +691,11 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt2d, const fv3_field *cappa
           }
           FV3_HD void out_pe(int k1, Real pe, Real dm) {
             pem = pem + dm;
-            KW_(pef, k1) = pe + pem;
+            FV3_ST_NT(KW_(pef, k1), pe + pem);
           }
           FV3_HD void finish(int k, Real dz) {
             z = z - dz * grav;
-            KW_(gz, k) = z;
+            FV3_ST_NT(KW_(gz, k), z);
           }
         };
         const Real z_bot = phis[t * st2 + pix];
@@ -801,22 +801,22 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
             const Real peg_n = peg + dm * ((Real)1.0 - qc);
             const Real peln_n = fv3_log(pem), pelng_n = fv3_log(peg_n);
             const Real pk3v = fv3_exp(akap * peln_n);
-            KW_(pk3, k + 1) = pk3v;
+            FV3_ST_NT(KW_(pk3, k + 1), pk3v);
             if constexpr (LAST) {
-              KW_(peln, k + 1) = peln_n;
-              KW_(pk, k + 1) = pk3v;
-              KW_(pe, k + 1) = pem;
+              FV3_ST_NT(KW_(peln, k + 1), peln_n);
+              FV3_ST_NT(KW_(pk, k + 1), pk3v);
+              FV3_ST_NT(KW_(pe, k + 1), pem);
             }
             const Real v = fv3_div(peg_n - peg, pelng_n - pelng_k);
             peg = peg_n;
             pelng_k = pelng_n;
             return v;
           }
-          FV3_HD void out_pe(int k1, Real pev, Real) { KW_(ppe, k1) = pev; }
+          FV3_HD void out_pe(int k1, Real pev, Real) { FV3_ST_NT(KW_(ppe, k1), pev); }
           FV3_HD void finish(int k, Real dz) {
             z = z - dz;
-            KW_(zh, k) = z;
-            KW_(delz, k) = dz;
+            FV3_ST_NT(KW_(zh, k), z);
+            FV3_ST_NT(KW_(delz, k), dz);
           }
         };
         const Real z_bot = zs[t * st2 + pix];

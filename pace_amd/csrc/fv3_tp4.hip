@@ -46,6 +46,7 @@
 // and are read from the flux fields there.  Levels whose chains are not all of order 2 (the sponge layers) take the form
 // without FD.  Same expressions in the same order as del6_stream: bitwise equal (FV3_DSW_DELN=arrays is the A/B switch).
 #include "fv3_ops.h"
+#define FV3_MARCH_ST(lhs, val) FV3_ST_NT(lhs, val)  // (the marches' outputs are streamed: fv3_common.h)
 #include "fv3_ppm.h"
 
 #include <type_traits>
@@ -682,8 +683,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                 if constexpr (ROLE == Q4_AIR) fv3_store_sel((a.fx + b) + p, sink0 + lane, ok, v);
               } else if (fx_row && own_x[l]) {
                 const unsigned p = pcol[l] + (unsigned)(jr * MS);
-                (a.mfx + b)[p] = o_ax[l] + v;
-                if constexpr (ROLE == Q4_AIR) (a.fx + b)[p] = v;
+                FV3_MARCH_ST((a.mfx + b)[p], o_ax[l] + v);
+                if constexpr (ROLE == Q4_AIR) FV3_MARCH_ST((a.fx + b)[p], v);
               }
               vm = v;
               vx[n] = v;
@@ -797,8 +798,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
                 if constexpr (ROLE == Q4_AIR) fv3_store_sel((a.fy + b) + p, sink0 + lane, ok, v);
               } else if (fy_row && own_y[l]) {
                 const unsigned p = pcol[l] + (unsigned)(jf * MS);
-                (a.mfy + b)[p] = o_ay[l] + v;
-                if constexpr (ROLE == Q4_AIR) (a.fy + b)[p] = v;
+                FV3_MARCH_ST((a.mfy + b)[p], o_ay[l] + v);
+                if constexpr (ROLE == Q4_AIR) FV3_MARCH_ST((a.fy + b)[p], v);
               }
               vm = v;
               vy[n] = v;
