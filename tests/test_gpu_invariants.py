@@ -94,6 +94,31 @@ def test_fp32_build_tracks_fp64(gpu_backend):
         assert err < tol, (n, err)
 
 
+def _run(cmd, **kw):
+    """subprocess.run(check=True) that SHOWS what the child printed when it fails or times out (a bare CalledProcessError says nothing)."""
+    import subprocess
+
+    kw.pop("check", None)
+    want_out = kw.pop("capture_output", False)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **{k: v for k, v in kw.items() if k != "text"})
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"")[-3000:] if isinstance(e.stdout, (bytes, bytearray)) else (e.stdout or "")[-3000:]
+        err = (e.stderr or b"")[-3000:] if isinstance(e.stderr, (bytes, bytearray)) else (e.stderr or "")[-3000:]
+        raise AssertionError(f"timed out after {e.timeout} s: {cmd}\n--- stdout\n{out}\n--- stderr\n{err}")
+    assert r.returncode == 0, f"exit code {r.returncode}: {cmd}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-3000:]}"
+    return r if want_out else r
+
+
+def _free_port():
+    """A rendezvous port nobody holds right now (a fixed port fails when an earlier run's socket is still in TIME_WAIT)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4), (48, 1, 6)])
 def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, world):
@@ -110,13 +135,13 @@ def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, wo
     env = dict(os.environ, FV3_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     w1, w2 = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
     size = ["--nx", str(nx), "--layout", str(layout)]
-    subprocess.run([sys.executable, tool, "--out", w1] + size, check=True, env=env, timeout=600)
-    subprocess.run(
+    _run([sys.executable, tool, "--out", w1] + size, check=True, env=env, timeout=1200)
+    _run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
-         str(29533 + world), tool, "--backend", "gloo", "--out", w2] + size,
-        check=True, env=env, timeout=600,
+         _free_port(), tool, "--backend", "gloo", "--out", w2] + size,
+        check=True, env=env, timeout=1200,
     )
-    subprocess.run([sys.executable, tool, "--compare", w1, w2], check=True, timeout=60)
+    _run([sys.executable, tool, "--compare", w1, w2], check=True, timeout=60)
 
 
 @pytest.mark.gpu
@@ -139,10 +164,10 @@ def test_alternative_kernel_forms_agree(tmp_path, toggle):
     base, alt = str(tmp_path / "base.json"), str(tmp_path / "alt.json")
     size = ["--nx", "48", "--nz", "79"]
     env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
-    subprocess.run([sys.executable, tool, "--out", base] + size, check=True, env=env, timeout=600)
+    _run([sys.executable, tool, "--out", base] + size, check=True, env=env, timeout=1200)
     name, val = toggle.split("=")
-    subprocess.run([sys.executable, tool, "--out", alt] + size, check=True, env=dict(env, **{name: val}), timeout=600)
-    subprocess.run([sys.executable, tool, "--compare", base, alt, "--rtol", "1e-11"], check=True, timeout=60)
+    _run([sys.executable, tool, "--out", alt] + size, check=True, env=dict(env, **{name: val}), timeout=1200)
+    _run([sys.executable, tool, "--compare", base, alt, "--rtol", "1e-11"], check=True, timeout=60)
 
 
 @pytest.mark.gpu
@@ -159,11 +184,11 @@ def test_bench_two_ranks_reproduce_the_single_process_state(tmp_path):
     args = ["--config", "c48", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-op-timing"]
     env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, check=True, env=env, timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
-    two = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+    one = _run([sys.executable, os.path.join(root, "bench.py")] + args, check=True, env=env, timeout=1200, capture_output=True, text=True, cwd=str(tmp_path))
+    two = _run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", _free_port(),
          os.path.join(root, "bench.py"), "--gpus", "2"] + args,
-        check=True, env=dict(env, FV3_FORCE_DEVICE="0", FV3_DIST_BACKEND="gloo"), timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
+        check=True, env=dict(env, FV3_FORCE_DEVICE="0", FV3_DIST_BACKEND="gloo"), timeout=1200, capture_output=True, text=True, cwd=str(tmp_path))
     l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["finite"] and l2["scaling"] == "strong"
@@ -210,10 +235,10 @@ def test_bench_init_and_teardown_order_with_both_rccl_users(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("FV3_")}
-    env.update(FV3_BENCH_FORCE_PG="1", FV3_LOOPBACK_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", RANK="0", WORLD_SIZE="1",
+    env.update(FV3_BENCH_FORCE_PG="1", FV3_LOOPBACK_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c48", "--emulate-share", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       env=env, timeout=600, capture_output=True, text=True, cwd=str(tmp_path))
+    r = _run([sys.executable, os.path.join(root, "bench.py"), "--config", "c48", "--emulate-share", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, timeout=1200, capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["finite"] and line["halo_transport"].startswith("loopback-rccl"), line["halo_transport"]

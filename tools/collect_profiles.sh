@@ -11,7 +11,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
 cd "$R"
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$out/pytest_gpu.log"
+python -m pytest tests -q -m gpu > "$out/pytest_gpu_full.log" 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed" "$out/pytest_gpu_full.log" | tail -5 > "$out/pytest_gpu.log"
 python bench.py "$@" > "$out/bench.log" 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o s -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/stats.log" 2>&1
