@@ -359,6 +359,10 @@ def main():
             for k, p_ in passes.items() if k in op_ms and op_ms[k] > 0
         }
         line["operators_ms_per_substep"] = op_ms
+        # (measurement inside the measurement, stated: the per-operator numbers come from one HIP-event pair per operator recorded INSIDE the
+        #  timed region -- 13 pairs per sub-step on the compute stream; `--no-op-timing` runs without them: 108.46 / 108.75 ms per sub-step with,
+        #  108.70 / 108.44 without, at C768 on one box -- no difference above the run-to-run spread)
+        line["operator_timing"] = "HIP event pair around every operator inside the timed region" if not a.no_op_timing else "off"
         if not a.no_cpu_baseline:
             per_cell, sample, cores = cpu_baseline()
             t_step_cpu = per_cell * h.cells_global * n_sub_steps
