@@ -51,6 +51,8 @@ FV3_HD inline int deln_nord(const Deln &d, int k) { return d.nord_k ? d.nord_k[k
 FV3_HD inline Real deln_damp(const Deln &d, int k) { return d.damp_k ? d.damp_k[k] : d.damp_u; }
 FV3_HD inline bool deln_on(const Deln &d, int k) { return d.on_k ? d.on_k[k] > d.on_thr : d.on_u; }
 
+#define FV3_D6_PATCH 8  // the faces within this distance of a cube corner come from the staged del-n chain (corner patches)
+
 // Optional epilogue of fv_tp_2d: the flux-form update the callers apply right after the transport,
 //   out = (mult ? mult * q : q) + (fx - fx[i+1] + fy - fy[j+1]) * rarea       on the compute cells,
 // formed in the transport kernel itself (the fluxes of the neighbouring faces are already in the
@@ -116,6 +118,22 @@ struct DswScalars {
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
 
+// Does the (strip, segment) tile of a scalar march touch a cube corner of its sub-domain (flags fl)?  Such tiles have the rare paths of the
+// marches in them -- the corner-halo remaps of the rows outside 1..nM, the del-n fluxes read from the FV3_D6_PATCH^2 corner patches -- and
+// stay with the round-4 kernel (dsw_scalars_t, tile_sel = 1); every other tile of the interior launches runs the round-5 march
+// (fv3_tp4x.hip).  l0: first owned L face of the strip (lanes cover l0-3 .. l0+60); ca: first owned row; r_end: last row the tile's march
+// consumes.  Conservative: a tile near a corner without rare work in it may count as a corner tile.
+FV3_HD inline bool q4_corner_tile(int fl, int l0, int ca, int r_end, int nL, int nM) {
+  const bool lo_strip = l0 - 3 <= FV3_D6_PATCH, hi_strip = l0 + FV3_WAVE - 4 >= nL + 2 - FV3_D6_PATCH;
+  const bool lo_seg = ca - 3 <= FV3_D6_PATCH + 3, hi_seg = r_end >= nM + 2 - FV3_D6_PATCH;
+  const bool c_ll = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_hl = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
+  const bool c_hh = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_lh = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
+  return (c_ll && lo_strip && lo_seg) || (c_hl && hi_strip && lo_seg) || (c_hh && hi_strip && hi_seg) || (c_lh && lo_strip && hi_seg);
+}
+// the round-5 two-tracer march on the tiles without a cube corner (fv3_tp4x.hip); role 1 = delp + w, 2 = q_con + pt; levels k_lo .. k_hi must
+// all run their del-n chains inside the march (>= fd_k0), PPM order 6
+void dsw_pair_march(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int role, int k_lo, int k_hi);
+
 // two tracers riding on given mass fluxes (the TRC march alone: tracer_2d_1l): a.q_con / a.pt = the two tracers, a.delp = the
 // old air mass, a.o_delp = the new one, a.fx / a.fy = the mass fluxes, outputs a.o_q_con / a.o_pt; no damping (dn_* off)
 void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
@@ -123,7 +141,6 @@ void tracer_pair_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a);
 // del6_vt_flux: fx2, fy2 (work d2) of q.  q_raw: d2 starts as q instead of damp*q.
 // del6_vt_flux_patches: only the faces on the FV3_D6_PATCH^2 patches at the cube corners (staged chain; orders > 0) -- for callers that
 // run the chain themselves everywhere else (the fused scalar marches of d_sw)
-#define FV3_D6_PATCH 8
 #ifndef FV3_Q4_KB_DEFAULT
 #define FV3_Q4_KB_DEFAULT 16  // levels of one tile an XCD walks back to back in the transport marches (0: plane-major launches)
 #endif

@@ -87,7 +87,9 @@ FV3_HD inline void q4_for(F &&f) {
 // HC: 0 = the PPM orders are run-time values (hord_dp / hord_vt / hord_tm of the call); 5 / 6 = all three equal that constant (the
 // reference configs: 6 everywhere): the limiter test of ppm_cell folds to one comparison and the order occupies no register.
 template <int ROLE, int PART, bool M8 = false, bool FD = false, int HC = 0>
-static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi) {
+static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi, int tile_sel = 0) {
+  // tile_sel = 1 (interior launches only): run only the (strip, segment) tiles that touch a cube corner of their sub-domain; the others are the
+  // round-5 march's (fv3_tp4x.hip, q4_corner_tile in fv3_ops.h)
   static_assert(!FD || (ROLE != Q4_QUAD && PART != Q4_ALL && !M8), "the fused del-n chains exist for the two-tracer interior / edge marches");
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
@@ -186,6 +188,10 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       cb = fb < nM ? fb : nM;
     }
     const int Led = nL + nh, Msd = 1 - nh, Med = nM + nh;
+    if (PART == Q4_INTERIOR && tile_sel == 1) {
+      const int r_end_ = fb + 3 < Med ? fb + 3 : Med;
+      if (!q4_corner_tile(fl, l0, ca, r_end_, nL, nM)) return;
+    }
     Real *lq[Q4_NT], *lqi[Q4_NT], *exp_[Q4_NT], *exf[Q4_NT];
     {
       Real *p = (Real *)smem_;
@@ -948,10 +954,16 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
       dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
       if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
     } else {
+      // Round 5: the tiles without a cube corner run the branch-free march of fv3_tp4x.hip (PPM order 6 only), the corner tiles the round-4
+      // kernel (tile_sel = 1).  FV3_DSW_MARCH=old: the round-4 kernel on every tile (A/B; read per call: the parity test flips it).
+      const char *me = getenv("FV3_DSW_MARCH");
+      const bool px_on = !(me && !strcmp(me, "old")) && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6;
       // (measured and dropped: the transposed tile-edge marches on the auxiliary stream beside the interior ones -- d_sw 51.5 ms either way)
-      dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+      if (px_on) dsw_pair_march(c, s, a, 1, kf, nz1);
+      dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1, px_on ? 1 : 0);
       if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
-      dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+      if (px_on) dsw_pair_march(c, s, a, 2, kf, nz1);
+      dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1, px_on ? 1 : 0);
       if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
     }
     if (s2 != s) fv3_wait(c, s, 3);

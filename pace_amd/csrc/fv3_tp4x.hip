@@ -1,0 +1,576 @@
+// fv3_tp4x.hip -- d_sw's two-tracer scalar marches (delp + w, q_con + pt), round-5 form.  Same operator, same expressions in the same
+// order as dsw_scalars_t<ROLE, Q4_INTERIOR, false, true> of fv3_tp4.hip (bitwise equal: FV3_DSW_MARCH=old is the A/B switch, and
+// tests/test_parity.py::test_pair_march_is_bitwise_the_round4_march compares them); CPU twin: oracle/fv3_oracle/d_sw.py (the four fv_tp_2d
+// calls and the divisions by the new air mass of d_sw_levels).  [SURVEY A.3.2 - A.3.4, A.4]
+//
+// Why a second form.  Round 4 measured the round-4 march from inside: 57 800 VALU instructions per wave of which 33 500 were
+// fp64 arithmetic -- the rest were loop-carried register copies of the rolled march (~6 000), 64-bit address arithmetic (~4 000), reloads
+// of spilled SGPRs (~4 000: 106 live scalars, most of them the state of rare paths) and DPP moves (7 300).  This file is the march
+// with those removed by construction:
+//   * NO RARE PATH IN THE ROW STEP.  The (strip, segment) tiles that touch a cube corner of their sub-domain (corner-halo remaps, 8 x 8
+//     del-n patches: 1 tile of 28 at C768 layout 2 x 2) are left to the round-4 kernel (tile_sel, fv3_tp4.hip), the W / E tile-edge columns
+//     were a launch of their own already (Q4_EDGE).  What is left of "rare" -- the one-sided PPM formulas on the three rows either side
+//     of a S / N tile edge, the rows a segment does not own while its windows fill and drain -- lives in a GENERAL form of the step
+//     (template argument GEN) that runs the first six and the last few rows of a segment; the rows between run the form without a
+//     single branch, ownership test or clamp.
+//   * STATIC ROTATION.  The march is unrolled by three: the three register sets of the rows in flight, the optional inputs and the
+//     del-n metric rows fetched one step ahead rotate by the step's static index Q instead of being copied, and the own-lane LDS ring
+//     of the delay lines has three slots addressed by Q too (immediate offsets: no address arithmetic).
+//   * SCALAR-BASE ADDRESSING.  Every access is (uniform field base) + (32-bit byte offset of the lane's column and row); the six row
+//     offsets of a step are one vector add each.
+//   * ONE RECIPROCAL PER DENOMINATOR.  The two tracers of a wave divide by the same cross-direction areas (and q_con / pt by the same
+//     new air mass): the refined reciprocal (rcp + two Newton steps, the part of the fp64 division sequence that depends on the
+//     denominator only) is formed once and each quotient takes three more instructions -- operation for operation what fv3_div does per
+//     quotient, hence the same bits (fv3_math.h).
+//   * the PPM order is the constant 6 (the reference configurations; any other order takes the round-4 kernel).
+#include <type_traits>
+
+#include "fv3_ops.h"
+#include "fv3_math.h"
+#define FV3_MARCH_ST(lhs, val) FV3_ST_NT(lhs, val)
+#include "fv3_ppm.h"
+
+namespace {
+
+#ifndef PX_NO_FENCE
+#define PX_FENCE() FV3_SCHED_FENCE()  // the scheduler may not move code across the phases of a step (unfenced, the unrolled march overlaps them until the registers spill)
+#else
+#define PX_FENCE() ((void)0)
+#endif
+// Ablation builds (diagnostic, never the product library; profiles/r05_ablation.md): -DPX_ABL=1 keeps every load and store of a step and
+// replaces the arithmetic by one sum of what was loaded (the floor the memory system sets for this access pattern); -DPX_ABL=2 keeps the
+// arithmetic and the stores and replaces the loads inside the march by the registers of the first rows, passed through an empty asm so
+// that nothing becomes loop-invariant (the floor instruction issue sets).
+#ifndef PX_ABL
+#define PX_ABL 0
+#endif
+#if PX_ABL == 2 && !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define PX_KEEP(x) asm volatile("" : "+v"(x))
+#else
+#define PX_KEEP(x) ((void)0)
+#endif
+#define PX_OUT 58
+#define PX_ORD 6
+enum { PX_AIR = 1, PX_TRC = 2 };
+#ifndef PX_WPE
+#define PX_WPE (sizeof(Real) == 4 ? 4 : 2)
+#endif
+
+// x / y with the denominator's refined reciprocal formed once: r = px_rcp(y); q = px_quot(x, y, r) -- the instruction sequence of
+// fv3_div split at the point where the numerator enters (bit for bit `/` for normal operands; the host emulation and fp32 divide)
+FV3_HD inline Real px_rcp(Real y) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FV3_DIV_PLAIN)
+  if constexpr (sizeof(Real) == 8) {
+    const double r0 = __builtin_amdgcn_rcp((double)y);
+    const double e0 = __builtin_fma(-(double)y, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-(double)y, r1, 1.0);
+    return (Real)__builtin_fma(r1, e1, r1);
+  }
+#endif
+  return y;
+}
+FV3_HD inline Real px_quot(Real x, Real y, Real r) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FV3_DIV_PLAIN)
+  if constexpr (sizeof(Real) == 8) {
+    const double q = (double)x * (double)r;
+    const double e2 = __builtin_fma(-(double)y, q, (double)x);
+    return (Real)__builtin_fma(e2, (double)r, q);
+  }
+#endif
+  (void)r;
+  return x / y;
+}
+
+// element at (uniform base) + (32-bit byte offset)
+FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff); }
+
+template <int ROLE>
+void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int k_hi) {
+  constexpr bool AIR = ROLE == PX_AIR;
+  const Geo g = c->g;
+  const int nk = k_hi - k_lo + 1;
+  if (nk <= 0) return;
+  const int nL = g.nx, nM = g.ny, nh = g.nh, go = g.o, sj32 = g.sj32;
+  // (launch geometry of dsw_scalars_t<ROLE, Q4_INTERIOR>: the two kernels split the same tiles between them)
+  const int nstrip = (nL + 1 + PX_OUT - 1) / PX_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((nM + 63) / 64) * g.nsub * nk, PX_WPE);
+  const int nseg = (nM + seg - 1) / seg;
+  static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : FV3_Q4_KB_DEFAULT;
+  const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const unsigned char *gflags = c->g_dev->flags;
+  const MPtr garea = g.area, grarea = g.rarea, gd6L = g.del6_v, gd6M = g.del6_u, gdya = g.dya;
+  // what a wave reads / writes (ROLE folds the unused ones away)
+  const Real *const q0f = AIR ? a.delp : a.q_con, *const q1f = AIR ? a.w : a.pt;
+  const Real *const crL = a.crx, *const crM = a.cry, *const afL = a.xfx, *const afM = a.yfx;
+  Real *const accL = a.mfx, *const accM = a.mfy;          // AIR: accumulated air-mass fluxes (read + written)
+  Real *const flL = a.fx, *const flM = a.fy;              // air-mass fluxes of the sub-step: AIR writes, TRC reads
+  const Real *const oldm = a.delp;                        // TRC: the old air mass
+  Real *const out0 = AIR ? a.o_delp : a.o_q_con, *const out1 = AIR ? a.o_w : a.o_pt, *const heat = a.heat;
+  // per-level coefficients: d2 of iteration 0 = c0 * q (delp, w); the mass-weighted damping of q_con / pt
+  const Deln dn_vt = a.dn_vt, dn_t = a.dn_t, dn_w = a.dn_w;
+  const Real *ke_bg_k = g.ke_bg;
+  const Real adt = fabs(a.dt);
+  constexpr int NRING = 8;  // ring variables: del-n metric rows (M faces, L faces, 1 / area), Courant number, area flux, area, inner L flux x 2
+  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };
+  const size_t smem = sizeof(Real) * (size_t)NRING * 3 * FV3_WAVE;
+  launch_waves<PX_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    int t, k, bx, by;
+    if (KB) {
+      t = blk_.bz / nblk;
+      const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k = k_lo + kk;
+      by = blk_.by / nstrip;
+      bx = blk_.by - by * nstrip;
+    } else {
+      t = blk_.bz / nk;
+      k = k_lo + (blk_.bz - t * nk);
+      bx = blk_.bx;
+      by = blk_.by;
+    }
+    const int fl = gflags[t];
+    const int l0 = 1 + bx * PX_OUT;
+    const int ca = 1 + by * seg, fa = ca;
+    const int fb = by == nseg - 1 ? nM + 1 : fa + seg - 1;
+    const int cb = fb < nM ? fb : nM;
+    const int Led = nL + nh, Msd = 1 - nh, Med = nM + nh, npM = nM + 1;
+    const int r_end = fb + 3 < Med ? fb + 3 : Med;
+    if (q4_corner_tile(fl, l0, ca, r_end, nL, nM)) return;  // the round-4 kernel's (tile_sel = 1)
+    const bool Mlo = fl & FV3_S, Mhi = fl & FV3_N;
+    const long b = t * st + k * sk, m2 = t * st2;
+    // uniform bases
+    const Real *const q0b = q0f + b, *const q1b = q1f + b, *const crLb = crL + b, *const crMb = crM + b, *const afLb = afL + b, *const afMb = afM + b;
+    const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6Lb = (const Real *)gd6L + m2, *const d6Mb = (const Real *)gd6M + m2;
+    Real *const accLb = accL + b, *const accMb = accM + b, *const flLb = flL + b, *const flMb = flM + b;
+    const Real *const oldmb = oldm + b;
+    Real *const out0b = out0 + b, *const out1b = out1 + b, *const heatb = heat + b;
+    const Real damp_vt = deln_damp(dn_vt, k), damp_t = deln_damp(dn_t, k);
+    const Real c0 = AIR ? deln_damp(dn_vt, k) : (Real)1, c1 = AIR ? deln_damp(dn_w, k) : (Real)1;
+    const Real dd8 = ke_bg_k[k] * adt;
+    const unsigned rowB = (unsigned)sj32 * (unsigned)sizeof(Real);
+    Real *const ring = (Real *)smem_;
+    auto RG = [&](int var, int slot) -> Real * { return ring + (var * 3 + slot) * FV3_WAVE; };
+
+    // ---- per-lane state
+    struct Row {
+      Real q0, q1, cx, xv, ar, cy, yv;
+    };
+    struct Met {  // del-n metric terms of a row, requested one step ahead
+      Real du, dv, ra;
+    };
+    Row R[3][FV3_LPT];
+    // inputs a step consumes late, requested one step ahead.  AIR: accumulated L / M fluxes;  TRC: air-mass L / M fluxes, old air mass of (lc, r-2)
+    Real Ox[3][FV3_LPT], Oy[3][FV3_LPT], Om[3][FV3_LPT];
+    Met MN[3][FV3_LPT];
+    unsigned pcolB[FV3_LPT];  // byte offset of (lc, M coordinate 0) inside a plane
+    bool own_x[FV3_LPT], own_y[FV3_LPT];
+    // PPM windows / cells of q (rows r-3 .. r) and of the L-advected q (likewise), per tracer
+    Real w2[2][FV3_LPT], w3[2][FV3_LPT], w4[2][FV3_LPT], al_q[2][FV3_LPT];
+    Real v2[2][FV3_LPT], v3[2][FV3_LPT], v4[2][FV3_LPT], al_v[2][FV3_LPT];
+    PpmCell cq[2][FV3_LPT], cv[2][FV3_LPT];
+    Real p_prev[2][FV3_LPT], y_prev[FV3_LPT];
+    Real fyin[2][FV3_LPT], px[2][FV3_LPT], fxk[2][FV3_LPT], fyp[2][FV3_LPT];
+    Real sqx[2][FV3_LPT], sqi[2][FV3_LPT], smb[FV3_LPT], sxv[FV3_LPT];
+    Real mbk[FV3_LPT], fyp_air[FV3_LPT];
+    // del-n chains (see dsw_scalars_t)
+    Real sd0[2][FV3_LPT], sd1[2][FV3_LPT], sd2[2][FV3_LPT], gx0[2][FV3_LPT], gx1[2][FV3_LPT], gy0[2][FV3_LPT], gy1[2][FV3_LPT];
+    Real dxd[2][FV3_LPT], dyf[2][FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
+    // values handed from phase to phase inside a step
+    Real h_dv0[FV3_LPT], h_era[FV3_LPT], h_ody[2][FV3_LPT], h_q5[2][FV3_LPT], h_mc[FV3_LPT];
+    Real h_zx0[FV3_LPT], h_zy0[FV3_LPT], h_zy1[FV3_LPT];
+
+    // loads.  GEN: rows clamped like the round-4 kernel clamps them while the windows fill / past the last row
+    auto load_row = [&](int r, int l, auto gen_tag) -> Row {
+      constexpr bool GEN = decltype(gen_tag)::value;
+      const int rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
+      const unsigned p0 = pcolB[l] + (unsigned)r * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
+      Row w;
+      w.q0 = px_ld(q0b, p0);
+      w.q1 = px_ld(q1b, p0);
+      w.cx = px_ld(crLb, p0);
+      w.xv = px_ld(afLb, p0);
+      w.ar = px_ld(areab, p0);
+      w.cy = px_ld(crMb, pf);
+      w.yv = px_ld(afMb, pf);
+      return w;
+    };
+    auto load_opt = [&](int q, int r, int l, auto gen_tag) {  // what step r consumes: row r-3, face r-2 (into set q)
+      constexpr bool GEN = decltype(gen_tag)::value;
+      const int r3 = GEN ? (r - 3 < Msd ? Msd : r - 3) : r - 3, rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
+      const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
+      if constexpr (AIR) {
+        Ox[q][l] = px_ld(accLb, p3);
+        Oy[q][l] = px_ld(accMb, pf);
+      } else {
+        Ox[q][l] = px_ld(flLb, p3);
+        Oy[q][l] = px_ld(flMb, pf);
+        Om[q][l] = px_ld(oldmb, pf);
+      }
+    };
+    auto load_met = [&](int r, int l) -> Met {
+      const unsigned pm = pcolB[l] + (unsigned)r * rowB;
+      Met m;
+      m.du = px_ld(d6Mb, pm);
+      m.dv = px_ld(d6Lb, pm);
+      m.ra = px_ld(rab, pm);
+      return m;
+    };
+
+    const int r0 = ca - 3;
+    FV3_LANES(blk_, lane, l) {
+      const int lc = l0 - 3 + lane, lcc = lc < Led ? lc : Led;
+      pcolB[l] = (unsigned)(go * sj32 + go + lcc) * (unsigned)sizeof(Real);
+      own_x[l] = lc >= l0 && lc < l0 + PX_OUT && lc <= nL + 1;
+      own_y[l] = lc >= l0 && lc < l0 + PX_OUT && lc <= nL;
+      if (fl & FV3_W) {  // the columns the W / E one-sided formulas reach belong to the EDGE launch
+        own_x[l] = own_x[l] && lc > 3;
+        own_y[l] = own_y[l] && lc > 3;
+      }
+      if (fl & FV3_E) {
+        own_x[l] = own_x[l] && lc < nL - 3 + 2;
+        own_y[l] = own_y[l] && lc < nL - 3 + 1;
+      }
+      y_prev[l] = smb[l] = sxv[l] = mbk[l] = fyp_air[l] = zyp[l] = zxo[l] = (Real)0;
+      h_dv0[l] = h_era[l] = h_mc[l] = h_zx0[l] = h_zy0[l] = h_zy1[l] = (Real)0;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        w2[n][l] = w3[n][l] = w4[n][l] = al_q[n][l] = v2[n][l] = v3[n][l] = v4[n][l] = al_v[n][l] = (Real)0;
+        cq[n][l] = cv[n][l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+        p_prev[n][l] = fyin[n][l] = px[n][l] = fxk[n][l] = fyp[n][l] = sqx[n][l] = sqi[n][l] = (Real)0;
+        sd0[n][l] = sd1[n][l] = sd2[n][l] = gx0[n][l] = gx1[n][l] = gy0[n][l] = gy1[n][l] = dxd[n][l] = dyf[n][l] = (Real)0;
+        h_ody[n][l] = h_q5[n][l] = (Real)0;
+      }
+      for (int v = 0; v < NRING; ++v)
+        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
+      // step r0 (Q = 0) consumes R[0] = row r0, O[0], MN[0]; row r0 + 1 is in flight in R[1]
+      MN[0][l] = load_met(r0, l);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Ox[q][l] = Oy[q][l] = Om[q][l] = (Real)0;
+      load_opt(0, r0, l, std::true_type{});
+      R[0][l] = load_row(r0, l, std::true_type{});
+      R[1][l] = load_row(r0 + 1 < r_end ? r0 + 1 : r_end, l, std::true_type{});
+      MN[1][l] = MN[2][l] = MN[0][l];
+      R[2][l] = R[0][l];
+#if PX_ABL == 2
+      R[2][l] = load_row(r0 + 2 < r_end ? r0 + 2 : r_end, l, std::true_type{});
+      load_opt(1, r0 + 1 < r_end ? r0 + 1 : r_end, l, std::true_type{});
+      load_opt(2, r0 + 2 < r_end ? r0 + 2 : r_end, l, std::true_type{});
+      MN[1][l] = load_met(r0 + 1 < r_end ? r0 + 1 : r_end, l);
+      MN[2][l] = load_met(r0 + 2 < r_end ? r0 + 2 : r_end, l);
+#endif
+    }
+
+    // ---- step r, Q = (r - r0) mod 3.  GEN: with the row-ownership tests, the load clamps and the S / N tile-edge formulas
+    auto step = [&](const int r, auto q_tag, auto gen_tag) {
+      constexpr int Q = decltype(q_tag)::value, Q1 = (Q + 1) % 3, Q2 = (Q + 2) % 3;
+      constexpr bool GEN = decltype(gen_tag)::value;
+      // ring slots: rows r and r-3 share slot Q (r-3 is read before r is written), r-1 -> Q2, r-2 -> Q1
+      const int sy = r - 1;  // cell whose low edge value the M windows complete at this step
+      const bool m_edge = GEN && ((Mlo && sy >= 0 && sy <= 2) || (Mhi && sy >= npM - 1 && sy <= npM + 1));
+      const int jr = r - 3, jf = r - 2;
+      const bool fx_row = !GEN || (jr >= ca && jr <= cb), fy_row = !GEN || (jf >= fa && jf <= fb);
+#if PX_ABL == 1
+      FV3_LANES(blk_, lane, l) {
+        const Met mc_ = MN[Q][l];
+        const Row cu = R[Q][l];
+        const Real ox = Ox[Q][l], oy = Oy[Q][l], om = AIR ? (Real)0 : Om[Q][l];
+        {
+          const int r1 = GEN ? (r + 1 < r_end ? r + 1 : r_end) : r + 1, rn = GEN ? (r + 2 < r_end ? r + 2 : r_end) : r + 2;
+          load_opt(Q1, r1, l, gen_tag);
+          MN[Q1][l] = load_met(r1, l);
+          R[Q2][l] = load_row(rn, l, gen_tag);
+        }
+        const Real sum = ((cu.q0 + cu.q1) + (cu.cx + cu.xv)) + ((cu.ar + cu.cy) + (cu.yv + ox)) + ((oy + om) + (mc_.du + mc_.dv)) + mc_.ra;
+        if (fx_row && own_x[l] && AIR) {
+          const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+          FV3_MARCH_ST(*fv3_at(accLb, p), sum);
+          FV3_MARCH_ST(*fv3_at(flLb, p), sum);
+        }
+        if (fy_row && own_y[l] && AIR) {
+          const unsigned p = pcolB[l] + (unsigned)jf * rowB;
+          FV3_MARCH_ST(*fv3_at(accMb, p), sum);
+          FV3_MARCH_ST(*fv3_at(flMb, p), sum);
+        }
+        if (fx_row && own_y[l]) {
+          const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+          FV3_MARCH_ST(*fv3_at(out0b, p), sum);
+          FV3_MARCH_ST(*fv3_at(out1b, p), sum);
+          if constexpr (AIR) FV3_MARCH_ST(*fv3_at(heatb, p), sum);
+        }
+      }
+      if (PX_ABL == 1) return;
+#endif
+      // ---- phase 1: requests of the next steps; inner M fluxes at face r-2, the M-advected q at row r-3; del-n chains, own-lane part
+      FV3_LANES(blk_, lane, l) {
+        const Met mc_ = MN[Q][l];
+        {
+          const int r1 = GEN ? (r + 1 < r_end ? r + 1 : r_end) : r + 1, rn = GEN ? (r + 2 < r_end ? r + 2 : r_end) : r + 2;
+#if PX_ABL == 2
+          (void)r1;
+          (void)rn;
+          PX_KEEP(Ox[Q1][l]); PX_KEEP(Oy[Q1][l]); PX_KEEP(Om[Q1][l]);
+          PX_KEEP(MN[Q1][l].du); PX_KEEP(MN[Q1][l].dv); PX_KEEP(MN[Q1][l].ra);
+          PX_KEEP(R[Q2][l].q0); PX_KEEP(R[Q2][l].q1); PX_KEEP(R[Q2][l].cx); PX_KEEP(R[Q2][l].xv); PX_KEEP(R[Q2][l].ar); PX_KEEP(R[Q2][l].cy); PX_KEEP(R[Q2][l].yv);
+#else
+          load_opt(Q1, r1, l, gen_tag);
+          MN[Q1][l] = load_met(r1, l);
+          R[Q2][l] = load_row(rn, l, gen_tag);
+#endif
+        }
+        const Row cu = R[Q][l];
+        const Real era = RG(RG_RA, Q)[lane];
+        const Real ar3 = RG(RG_AR, Q)[lane];
+        const Real du1 = RG(RG_DU, Q2)[lane], du2 = RG(RG_DU, Q1)[lane], ra1 = RG(RG_RA, Q2)[lane], ra2 = RG(RG_RA, Q1)[lane];
+        RG(RG_DU, Q)[lane] = mc_.du;
+        RG(RG_DV, Q)[lane] = mc_.dv;
+        RG(RG_RA, Q)[lane] = mc_.ra;
+        const Real du0 = mc_.du;
+        h_dv0[l] = mc_.dv;
+        h_era[l] = era;
+        const Real yv = cu.yv;
+        const Real den_y = ar3 + y_prev[l] - yv;
+        const Real rden_y = px_rcp(den_y);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const Real qraw = n == 0 ? cu.q0 : cu.q1;
+          {  // del-n chain: d2 of iteration s on row r-s, its M flux at face r-s
+            const Real cf = n == 0 ? c0 : c1;
+            const Real d0c = AIR ? cf * qraw : qraw;
+            const Real fyc0 = du0 * (sd0[n][l] - d0c);
+            const Real gxe0 = FV3_LANE_SHL(1, gx0[n], l, lane), gxe1 = FV3_LANE_SHL(1, gx1[n], l, lane);
+            const Real d2c1 = (gx0[n][l] - gxe0 + gy0[n][l] - fyc0) * ra1;
+            const Real fyc1 = du1 * (d2c1 - sd1[n][l]);
+            const Real d2c2 = (gx1[n][l] - gxe1 + gy1[n][l] - fyc1) * ra2;
+            dyf[n][l] = du2 * (d2c2 - sd2[n][l]);
+            gy0[n][l] = fyc0;
+            gy1[n][l] = fyc1;
+            sd0[n][l] = d0c;
+            sd1[n][l] = d2c1;
+            sd2[n][l] = d2c2;
+          }
+          const Real a_ = w2[n][l], b_ = w3[n][l], c_ = w4[n][l], d_ = qraw;  // q of rows r-3 .. r
+          Real al_new;
+          if (m_edge) {
+            const Real *mmb = (const Real *)gdya + m2;
+            auto My = [&](int s_) { return px_ld(mmb, pcolB[l] + (unsigned)s_ * rowB); };
+            al_new = ppm_al_win(a_, b_, c_, d_, My, sy, Mlo, Mhi, npM);
+            FV3_LANDED(al_new);
+          } else {
+            al_new = PPM_P1 * (b_ + c_) + PPM_P2 * (a_ + d_);
+          }
+          const PpmCell co = ppm_cell(al_q[n][l], al_new, b_, PX_ORD);
+          al_q[n][l] = al_new;
+          const Real fyi = ppm_face(cq[n][l], co, cu.cy);
+          fyin[n][l] = fyi;
+          cq[n][l] = co;
+          const Real pn = yv * fyi;
+          const Real qi = px_quot(a_ * ar3 + p_prev[n][l] - pn, den_y, rden_y);
+          p_prev[n][l] = pn;
+          sqx[n][l] = qraw;
+          sqi[n][l] = qi;
+          h_q5[n][l] = qraw;
+        }
+        y_prev[l] = yv;
+        if constexpr (AIR) {
+          smb[l] = w2[0][l];
+        } else {
+          smb[l] = mbk[l];
+          h_mc[l] = Om[Q][l];
+        }
+      }
+      PX_FENCE();
+      // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3; del-n chains, L fluxes
+      FV3_LANES(blk_, lane, l) {
+        const Row cu = R[Q][l];
+        const Real cx = cu.cx, xv = cu.xv;
+        const Real cx3 = RG(RG_CX, Q)[lane], xv3 = RG(RG_XV, Q)[lane];
+        const Real dv0 = h_dv0[l], dv1 = RG(RG_DV, Q2)[lane], dv2 = RG(RG_DV, Q1)[lane];
+        Real o_dx[2], o_dy[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const Real e0 = FV3_LANE_SHR(1, sd0[n], l, lane), e1 = FV3_LANE_SHR(1, sd1[n], l, lane), e2 = FV3_LANE_SHR(1, sd2[n], l, lane);
+          gx0[n][l] = dv0 * (e0 - sd0[n][l]);
+          gx1[n][l] = dv1 * (sd1[n][l] - e1);
+          o_dx[n] = dxd[n][l];  // final L flux of row r-3 (formed at the previous step)
+          o_dy[n] = dyf[n][l];
+          dxd[n][l] = dv2 * (sd2[n][l] - e2);  // ... of row r-2
+          h_ody[n][l] = o_dy[n];
+        }
+        if constexpr (AIR) {
+          h_zx0[l] = o_dx[1];
+          h_zy0[l] = zyp[l];
+          h_zy1[l] = o_dy[1];
+          zxo[l] = o_dx[1];
+        }
+        const Real mb = AIR ? w2[0][l] : mbk[l];  // old air mass of (lc, r-3)
+        const Real mw = FV3_LANE_SHR(1, smb, l, lane) + mb;
+        Real vm = Ox[Q][l];  // TRC: the stored air-mass flux of the face
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const Real fi3 = RG(RG_FI + n, Q)[lane];
+          const Real a0 = FV3_LANE_SHR(3, sqx[n], l, lane), a1 = FV3_LANE_SHR(2, sqx[n], l, lane), a2 = FV3_LANE_SHR(1, sqx[n], l, lane), a3 = sqx[n][l],
+                     a4 = FV3_LANE_SHL(1, sqx[n], l, lane), a5 = FV3_LANE_SHL(2, sqx[n], l, lane);
+          const Real b0 = FV3_LANE_SHR(3, sqi[n], l, lane), b1 = FV3_LANE_SHR(2, sqi[n], l, lane), b2 = FV3_LANE_SHR(1, sqi[n], l, lane), b3 = sqi[n][l],
+                     b4 = FV3_LANE_SHL(1, sqi[n], l, lane), b5 = FV3_LANE_SHL(2, sqi[n], l, lane);
+          const Real fxin = ppm_flux_int(a0, a1, a2, a3, a4, a5, cx, PX_ORD);
+          const Real fxout = ppm_flux_int(b0, b1, b2, b3, b4, b5, cx3, PX_ORD);
+          Real v;
+          if (AIR && n == 0) {  // air mass: area-flux weighted, plain damping flux
+            v = (Real)0.5 * (fxout + fi3) * xv3;
+            v = v + o_dx[n];
+            if (fx_row && own_x[l]) {
+              const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+              FV3_MARCH_ST(*fv3_at(accLb, p), Ox[Q][l] + v);
+              FV3_MARCH_ST(*fv3_at(flLb, p), v);
+            }
+            vm = v;
+          } else {  // riding on the air-mass flux; q_con / pt with the mass-weighted damping flux
+            v = (Real)0.5 * (fxout + fi3) * vm;
+            if constexpr (!AIR) v = v + (Real)0.5 * (n == 0 ? damp_t : damp_vt) * mw * o_dx[n];
+          }
+          fxk[n][l] = v;
+          RG(RG_FI + n, Q)[lane] = fxin;
+          px[n][l] = xv * fxin;
+        }
+        RG(RG_CX, Q)[lane] = cx;
+        RG(RG_XV, Q)[lane] = xv;
+        sxv[l] = xv;
+      }
+      PX_FENCE();
+      // ---- phase 3: the L-advected q on row r, outer M fluxes at face r-2, final M fluxes, the cell update of (lc, r-3)
+      FV3_LANES(blk_, lane, l) {
+        const Row cu = R[Q][l];
+        const Real x1 = FV3_LANE_SHL(1, sxv, l, lane);
+        const Real ar = cu.ar;
+        const Real den_x = ar + cu.xv - x1;
+        const Real rden_x = px_rcp(den_x);
+        const Real era = h_era[l];
+        const Real mb = AIR ? w2[0][l] : mbk[l], mc = AIR ? w3[0][l] : h_mc[l];  // old air mass of (lc, r-3), (lc, r-2)
+        Real vy[2];
+        Real vm = Oy[Q][l];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const Real p1 = FV3_LANE_SHL(1, px[n], l, lane);
+          const Real qj = px_quot(h_q5[n][l] * ar + px[n][l] - p1, den_x, rden_x);
+          const Real a_ = v2[n][l], b_ = v3[n][l], c_ = v4[n][l], d_ = qj;
+          Real al_new;
+          if (m_edge) {
+            const Real *mmb = (const Real *)gdya + m2;
+            auto My = [&](int s_) { return px_ld(mmb, pcolB[l] + (unsigned)s_ * rowB); };
+            al_new = ppm_al_win(a_, b_, c_, d_, My, sy, Mlo, Mhi, npM);
+            FV3_LANDED(al_new);
+          } else {
+            al_new = PPM_P1 * (b_ + c_) + PPM_P2 * (a_ + d_);
+          }
+          const PpmCell co = ppm_cell(al_v[n][l], al_new, b_, PX_ORD);
+          al_v[n][l] = al_new;
+          const Real fyout = ppm_face(cv[n][l], co, cu.cy);
+          cv[n][l] = co;
+          v2[n][l] = b_;
+          v3[n][l] = c_;
+          v4[n][l] = d_;
+          Real v;
+          if (AIR && n == 0) {
+            v = (Real)0.5 * (fyout + fyin[n][l]) * cu.yv;
+            v = v + h_ody[n][l];
+            if (fy_row && own_y[l]) {
+              const unsigned p = pcolB[l] + (unsigned)jf * rowB;
+              FV3_MARCH_ST(*fv3_at(accMb, p), Oy[Q][l] + v);
+              FV3_MARCH_ST(*fv3_at(flMb, p), v);
+            }
+            vm = v;
+          } else {
+            v = (Real)0.5 * (fyout + fyin[n][l]) * vm;
+            if constexpr (!AIR) v = v + (Real)0.5 * (n == 0 ? damp_t : damp_vt) * (mb + mc) * h_ody[n][l];
+          }
+          vy[n] = v;
+        }
+        Real fxe[2];  // (read outside the branch below: a shuffle needs the source lane active)
+        fxe[0] = FV3_LANE_SHL(1, fxk[0], l, lane);
+        fxe[1] = FV3_LANE_SHL(1, fxk[1], l, lane);
+        Real fe_air = (Real)0, zx1 = (Real)0;
+        if constexpr (AIR)
+          zx1 = FV3_LANE_SHL(1, zxo, l, lane);
+        else
+          fe_air = FV3_LANE_SHL(1, Ox[Q], l, lane);  // the air-mass flux through the high L face of the cell: the neighbouring lane's
+        if (fx_row && own_y[l]) {
+          const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+          Real up[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const Real dv_ = (fxk[n][l] - fxe[n] + fyp[n][l] - vy[n]) * era;
+            up[n] = (AIR && n == 0) ? w2[n][l] + dv_ : mb * w2[n][l] + dv_;
+          }
+          if constexpr (AIR) {
+            const Real dpn = up[0];
+            FV3_MARCH_ST(*fv3_at(out0b, p), dpn);
+            Real wn = px_quot(up[1], dpn, px_rcp(dpn));
+            const Real dwv = (h_zx0[l] - zx1 + h_zy0[l] - h_zy1[l]) * era;  // (x terms first)
+            const Real hs = dd8 - dwv * (w2[1][l] + (Real)0.5 * dwv);
+            wn = wn + dwv;
+            FV3_MARCH_ST(*fv3_at(out1b, p), wn);
+            FV3_MARCH_ST(*fv3_at(heatb, p), hs);
+          } else {
+            const Real dpn = mb + (Ox[Q][l] - fe_air + fyp_air[l] - Oy[Q][l]) * era;  // the new air mass, as the delp + w march formed it
+            const Real rdpn = px_rcp(dpn);
+            FV3_MARCH_ST(*fv3_at(out0b, p), px_quot(up[0], dpn, rdpn));
+            FV3_MARCH_ST(*fv3_at(out1b, p), px_quot(up[1], dpn, rdpn));
+          }
+        }
+        if constexpr (!AIR) {
+          mbk[l] = h_mc[l];
+          fyp_air[l] = Oy[Q][l];
+        } else {
+          zyp[l] = h_zy1[l];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          fyp[n][l] = vy[n];
+          w2[n][l] = w3[n][l];
+          w3[n][l] = w4[n][l];
+          w4[n][l] = h_q5[n][l];
+        }
+        RG(RG_AR, Q)[lane] = ar;
+      }
+      PX_FENCE();
+    };
+
+    // ---- the march: 6 general steps (windows fill; S tile edge), branch-free triples, general triples to the end (rows past r_end are
+    //      clamped loads and masked stores)
+    int r_hi = cb + 3 < fb + 2 ? cb + 3 : fb + 2;  // last row whose step owns both its cell row and its M face ...
+    if (r_hi > r_end - 2) r_hi = r_end - 2;        // ... and requests no row past the segment's last
+    if (Mhi && r_hi > nM) r_hi = nM;               // ... and meets no N tile-edge formula
+    int r = r0;
+#pragma clang loop unroll(disable)
+    for (int part = 0; part < 2; ++part) {  // (one copy of the general triple in the code: head and tail are two trips of this loop)
+      const int stop = part == 0 ? r0 + 5 : r_end;
+#pragma clang loop unroll(disable)
+      for (; r <= stop; r += 3) {
+        step(r, std::integral_constant<int, 0>{}, std::true_type{});
+        step(r + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        step(r + 2, std::integral_constant<int, 2>{}, std::true_type{});
+      }
+      if (part == 0) {
+#pragma clang loop unroll(disable)
+        for (; r + 2 <= r_hi; r += 3) {
+          step(r, std::integral_constant<int, 0>{}, std::false_type{});
+          step(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
+          step(r + 2, std::integral_constant<int, 2>{}, std::false_type{});
+        }
+      }
+    }
+  });
+}
+
+}  // namespace
+
+void dsw_pair_march(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int role, int k_lo, int k_hi) {
+  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] round-5 pair march, role %d, levels %d..%d\n", role, k_lo, k_hi);
+  if (role == PX_AIR)
+    pair_march_t<PX_AIR>(c, s, a, k_lo, k_hi);
+  else
+    pair_march_t<PX_TRC>(c, s, a, k_lo, k_hi);
+}

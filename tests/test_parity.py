@@ -404,6 +404,27 @@ def test_del_n_chains_inside_the_marches_are_bitwise_the_del6_launches(backend, 
             assert np.array_equal(res["fused"][r][name], res["arrays"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (65, (1, 1), "0"), (200, (1, 1), "96"), (200, (1, 1), "32")])
+def test_pair_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout, seg):
+    """d_sw's two-tracer marches in their round-5 form (fv3_tp4x.hip: branch-free row step unrolled by three, general steps at the ends
+    of a segment, cube-corner tiles left to the round-4 kernel) against the round-4 kernel on every tile (FV3_DSW_MARCH=old): the same
+    expressions in the same order, so every field is bitwise equal -- on sub-domains with interior strips between tile-edge strips,
+    with S / N tile edges in the first / last segment, with several segments (whole triples, and segment lengths that leave one or
+    two rows to the general steps) and on 2 x 2 ranks (one cube corner per sub-domain)."""
+    nz = 6  # (levels 0..2 are the sponge layers: the round-4 kernel without the chains; 3..5 run the round-5 march)
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("new", "old"):
+        monkeypatch.setenv("FV3_DSW_MARCH", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["new"][r][name], res["old"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
 def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
     """update_dz_d: the del-n chain of the interface heights run inside the transport march (tp2d_stream_t TF_FD, strips away from

@@ -110,9 +110,42 @@ def waits(lib, keys):
                 print(f"  {i:5d}  s_waitcnt {args:24s} -> {n[1]} {n[2][:48]}" + ("   <-- in front of hot-path arithmetic" if hot else ""))
 
 
+def all_loops(lines):
+    """every backward branch of the kernel: (first instruction index, last instruction index), innermost loops included"""
+    ins, _ = main_loop(lines)
+    addr = {a: i for i, (a, _, _) in enumerate(ins)}
+    out = []
+    for i, (a, op, args) in enumerate(ins):
+        if op.startswith("s_cbranch") or op == "s_branch":
+            off = int(args.split()[0])
+            if off > 32767:
+                off -= 65536
+            tgt = a + 4 + off * 4
+            if tgt < a and tgt in addr:
+                out.append((addr[tgt], i))
+    return ins, out
+
+
+def loops(lib, keys, dump=None):
+    for name, lines in kernel_asm(lib, keys):
+        ins, lp = all_loops(lines)
+        print(f"{name[:120]}\n  kernel {len(ins)} instructions, {len(lp)} loops")
+        for a, b in sorted(lp):
+            c = Counter(classify(op) for _, op, _ in ins[a : b + 1])
+            print(f"  [{a:5d} .. {b:5d}] {b - a + 1:5d}: " + ", ".join(f"{k} {v}" for k, v in sorted(c.items(), key=lambda kv: -kv[1])))
+        if dump:
+            with open(dump, "w") as f:
+                for i, (a, op, args) in enumerate(ins):
+                    f.write(f"{i:6d}  {op} {args}\n")
+
+
 def main():
     if sys.argv[1] == "--waits":
         return waits(sys.argv[2], sys.argv[3:])
+    if sys.argv[1] == "--loops":  # every loop of the kernel with its mix; --dump=<file> also writes the numbered listing
+        args = [x for x in sys.argv[2:] if not x.startswith("--dump=")]
+        dump = next((x[7:] for x in sys.argv[2:] if x.startswith("--dump=")), None)
+        return loops(args[0], args[1:], dump)
     lib, keys = sys.argv[1], sys.argv[2:]
     for name, lines in kernel_asm(lib, keys):
         ins, body = main_loop(lines)
