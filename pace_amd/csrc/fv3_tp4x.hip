@@ -49,6 +49,40 @@ namespace {
 #else
 #define PX_KEEP(x) ((void)0)
 #endif
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define PX_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#else
+#define PX_OPAQUE_S(x) ((void)0)
+#endif
+#ifdef PX_TRACER_FENCE
+#define PX_FENCE_T() FV3_SCHED_FENCE()  // ... nor across the tracers inside a phase
+#else
+#define PX_FENCE_T() ((void)0)
+#endif
+// the limiter flag of the previous lane: the lane mask shifted by one (a scalar instruction); false for lane 0
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define FV3_LANE_SHR1_FLAG(arr, l, lane) __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64((arr)[l]) << 1)
+#else
+#define FV3_LANE_SHR1_FLAG(arr, l, lane) ((lane) >= 1 ? (arr)[(l) - 1] : false)
+#endif
+// A value that outlives the step which consumes its load (q -> the PPM windows, the M area flux, the old air mass) is MOVED out of the load's
+// destination register at the point of consumption.  Left to the compiler, the register the load was issued into stays the value's home for
+// up to four more steps, i.e. across the back edge of the unrolled march, where it is copied while a younger load into the same name is still in
+// flight -- and that copy waits for it with vmcnt(0): the whole prefetch, once per three steps (seen in the ISA of the first build).
+#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+FV3_DEV inline double px_move(double x) {
+  double y;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+FV3_DEV inline float px_move(float x) {
+  float y;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+#else
+inline Real px_move(Real x) { return x; }
+#endif
 #define PX_OUT 58
 #define PX_ORD 6
 enum { PX_AIR = 1, PX_TRC = 2 };
@@ -179,7 +213,9 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     Real sd0[2][FV3_LPT], sd1[2][FV3_LPT], sd2[2][FV3_LPT], gx0[2][FV3_LPT], gx1[2][FV3_LPT], gy0[2][FV3_LPT], gy1[2][FV3_LPT];
     Real dxd[2][FV3_LPT], dyf[2][FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
     // values handed from phase to phase inside a step
-    Real h_dv0[FV3_LPT], h_era[FV3_LPT], h_ody[2][FV3_LPT], h_q5[2][FV3_LPT], h_mc[FV3_LPT];
+    Real s_al[2][2][FV3_LPT], s_bl[2][2][FV3_LPT], s_br[2][2][FV3_LPT];  // L sweeps (inner, outer) x tracers: edge value at the low face of the lane's cell, the cell's bl / br ...
+    bool s_sm[2][2][FV3_LPT];                                              // ... and limiter flag
+    Real h_era[FV3_LPT], h_ody[2][FV3_LPT], h_q5[2][FV3_LPT], h_mc[FV3_LPT];
     Real h_zx0[FV3_LPT], h_zy0[FV3_LPT], h_zy1[FV3_LPT];
 
     // loads.  GEN: rows clamped like the round-4 kernel clamps them while the windows fill / past the last row
@@ -234,7 +270,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         own_y[l] = own_y[l] && lc < nL - 3 + 1;
       }
       y_prev[l] = smb[l] = sxv[l] = mbk[l] = fyp_air[l] = zyp[l] = zxo[l] = (Real)0;
-      h_dv0[l] = h_era[l] = h_mc[l] = h_zx0[l] = h_zy0[l] = h_zy1[l] = (Real)0;
+      h_era[l] = h_mc[l] = h_zx0[l] = h_zy0[l] = h_zy1[l] = (Real)0;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         w2[n][l] = w3[n][l] = w4[n][l] = al_q[n][l] = v2[n][l] = v3[n][l] = v4[n][l] = al_v[n][l] = (Real)0;
@@ -242,6 +278,10 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         p_prev[n][l] = fyin[n][l] = px[n][l] = fxk[n][l] = fyp[n][l] = sqx[n][l] = sqi[n][l] = (Real)0;
         sd0[n][l] = sd1[n][l] = sd2[n][l] = gx0[n][l] = gx1[n][l] = gy0[n][l] = gy1[n][l] = dxd[n][l] = dyf[n][l] = (Real)0;
         h_ody[n][l] = h_q5[n][l] = (Real)0;
+        for (int w = 0; w < 2; ++w) {
+          s_al[w][n][l] = s_bl[w][n][l] = s_br[w][n][l] = (Real)0;
+          s_sm[w][n][l] = false;
+        }
       }
       for (int v = 0; v < NRING; ++v)
         for (int q = 0; q < 3; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
@@ -264,9 +304,13 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     }
 
     // ---- step r, Q = (r - r0) mod 3.  GEN: with the row-ownership tests, the load clamps and the S / N tile-edge formulas
-    auto step = [&](const int r, auto q_tag, auto gen_tag) {
+    auto step = [&](const int r_, auto q_tag, auto gen_tag) {
       constexpr int Q = decltype(q_tag)::value, Q1 = (Q + 1) % 3, Q2 = (Q + 2) % 3;
       constexpr bool GEN = decltype(gen_tag)::value;
+      // (the row index is made opaque: seen as an induction variable, every access stream gets a 64-bit vector pointer of its own that is
+      //  bumped per step -- 2 registers and a 64-bit add per stream -- instead of (uniform base) + (32-bit offset))
+      int r = r_;
+      PX_OPAQUE_S(r);
       // ring slots: rows r and r-3 share slot Q (r-3 is read before r is written), r-1 -> Q2, r-2 -> Q1
       const int sy = r - 1;  // cell whose low edge value the M windows complete at this step
       const bool m_edge = GEN && ((Mlo && sy >= 0 && sy <= 2) || (Mhi && sy >= npM - 1 && sy <= npM + 1));
@@ -328,14 +372,13 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         RG(RG_DV, Q)[lane] = mc_.dv;
         RG(RG_RA, Q)[lane] = mc_.ra;
         const Real du0 = mc_.du;
-        h_dv0[l] = mc_.dv;
         h_era[l] = era;
-        const Real yv = cu.yv;
+        const Real yv = px_move(cu.yv);
         const Real den_y = ar3 + y_prev[l] - yv;
         const Real rden_y = px_rcp(den_y);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          const Real qraw = n == 0 ? cu.q0 : cu.q1;
+          const Real qraw = px_move(n == 0 ? cu.q0 : cu.q1);
           {  // del-n chain: d2 of iteration s on row r-s, its M flux at face r-s
             const Real cf = n == 0 ? c0 : c1;
             const Real d0c = AIR ? cf * qraw : qraw;
@@ -372,22 +415,49 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
           sqx[n][l] = qraw;
           sqi[n][l] = qi;
           h_q5[n][l] = qraw;
+          PX_FENCE_T();
         }
         y_prev[l] = yv;
         if constexpr (AIR) {
           smb[l] = w2[0][l];
         } else {
           smb[l] = mbk[l];
-          h_mc[l] = Om[Q][l];
+          h_mc[l] = px_move(Om[Q][l]);
         }
       }
       PX_FENCE();
-      // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3; del-n chains, L fluxes
-      FV3_LANES(blk_, lane, l) {
+      // ---- phase 2: inner L fluxes on row r, outer L fluxes on row r-3, final L fluxes of row r-3; del-n chains, L fluxes.
+      //      The L sweeps share their reconstruction between neighbouring lanes: a lane forms the edge value at the low face of ITS cell
+      //      and that cell's limited profile once (ppm_flux_int forms three edge values and two cells per face, two of the edge values
+      //      and one cell being the neighbouring lane's too); the high edge value is the next lane's low one, the upwind-side cell of
+      //      the lane's face the previous lane's -- wavefront shuffles of results instead of operands, the limiter flag as a shifted
+      //      lane mask (a scalar instruction).  Same expressions on the same operands: the same bits.
+      //      (2a, 2b, 2c are one stretch of code on the device; the host emulation needs the neighbour's value complete before it is read)
+      FV3_LANES(blk_, lane, l) {  // 2a: edge value at the low face of the lane's cell, both sweeps
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          s_al[0][n][l] = PPM_P1 * (FV3_LANE_SHR(1, sqx[n], l, lane) + sqx[n][l]) + PPM_P2 * (FV3_LANE_SHR(2, sqx[n], l, lane) + FV3_LANE_SHL(1, sqx[n], l, lane));
+          s_al[1][n][l] = PPM_P1 * (FV3_LANE_SHR(1, sqi[n], l, lane) + sqi[n][l]) + PPM_P2 * (FV3_LANE_SHR(2, sqi[n], l, lane) + FV3_LANE_SHL(1, sqi[n], l, lane));
+        }
+      }
+      FV3_LANES(blk_, lane, l) {  // 2b: the lane's cell
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const PpmCell ci = ppm_cell(s_al[0][n][l], FV3_LANE_SHL(1, s_al[0][n], l, lane), sqx[n][l], PX_ORD);
+          const PpmCell co = ppm_cell(s_al[1][n][l], FV3_LANE_SHL(1, s_al[1][n], l, lane), sqi[n][l], PX_ORD);
+          s_bl[0][n][l] = ci.bl;
+          s_br[0][n][l] = ci.br;
+          s_sm[0][n][l] = ci.sm;
+          s_bl[1][n][l] = co.bl;
+          s_br[1][n][l] = co.br;
+          s_sm[1][n][l] = co.sm;
+        }
+      }
+      FV3_LANES(blk_, lane, l) {  // 2c: the faces
         const Row cu = R[Q][l];
         const Real cx = cu.cx, xv = cu.xv;
         const Real cx3 = RG(RG_CX, Q)[lane], xv3 = RG(RG_XV, Q)[lane];
-        const Real dv0 = h_dv0[l], dv1 = RG(RG_DV, Q2)[lane], dv2 = RG(RG_DV, Q1)[lane];
+        const Real dv0 = RG(RG_DV, Q)[lane], dv1 = RG(RG_DV, Q2)[lane], dv2 = RG(RG_DV, Q1)[lane];
         Real o_dx[2], o_dy[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -411,12 +481,16 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const Real fi3 = RG(RG_FI + n, Q)[lane];
-          const Real a0 = FV3_LANE_SHR(3, sqx[n], l, lane), a1 = FV3_LANE_SHR(2, sqx[n], l, lane), a2 = FV3_LANE_SHR(1, sqx[n], l, lane), a3 = sqx[n][l],
-                     a4 = FV3_LANE_SHL(1, sqx[n], l, lane), a5 = FV3_LANE_SHL(2, sqx[n], l, lane);
-          const Real b0 = FV3_LANE_SHR(3, sqi[n], l, lane), b1 = FV3_LANE_SHR(2, sqi[n], l, lane), b2 = FV3_LANE_SHR(1, sqi[n], l, lane), b3 = sqi[n][l],
-                     b4 = FV3_LANE_SHL(1, sqi[n], l, lane), b5 = FV3_LANE_SHL(2, sqi[n], l, lane);
-          const Real fxin = ppm_flux_int(a0, a1, a2, a3, a4, a5, cx, PX_ORD);
-          const Real fxout = ppm_flux_int(b0, b1, b2, b3, b4, b5, cx3, PX_ORD);
+          Real ff[2];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {  // w = 0: inner flux (q on row r), 1: outer flux (the M-advected q on row r-3)
+            const Real qv = w == 0 ? sqx[n][l] : sqi[n][l];
+            const PpmCell cm{FV3_LANE_SHR(1, s_bl[w][n], l, lane), FV3_LANE_SHR(1, s_br[w][n], l, lane), w == 0 ? FV3_LANE_SHR(1, sqx[n], l, lane) : FV3_LANE_SHR(1, sqi[n], l, lane),
+                             FV3_LANE_SHR1_FLAG(s_sm[w][n], l, lane)};
+            const PpmCell c0{s_bl[w][n][l], s_br[w][n][l], qv, s_sm[w][n][l]};
+            ff[w] = ppm_face(cm, c0, w == 0 ? cx : cx3);
+          }
+          const Real fxin = ff[0], fxout = ff[1];
           Real v;
           if (AIR && n == 0) {  // air mass: area-flux weighted, plain damping flux
             v = (Real)0.5 * (fxout + fi3) * xv3;
@@ -434,6 +508,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
           fxk[n][l] = v;
           RG(RG_FI + n, Q)[lane] = fxin;
           px[n][l] = xv * fxin;
+          PX_FENCE_T();
         }
         RG(RG_CX, Q)[lane] = cx;
         RG(RG_XV, Q)[lane] = xv;
@@ -487,6 +562,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
             if constexpr (!AIR) v = v + (Real)0.5 * (n == 0 ? damp_t : damp_vt) * (mb + mc) * h_ody[n][l];
           }
           vy[n] = v;
+          PX_FENCE_T();
         }
         Real fxe[2];  // (read outside the branch below: a shuffle needs the source lane active)
         fxe[0] = FV3_LANE_SHL(1, fxk[0], l, lane);
