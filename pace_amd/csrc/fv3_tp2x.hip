@@ -1,0 +1,464 @@
+// fv3_tp2x.hip -- the single-tracer transport marches with their del-n chain inside, round-5 form: d_sw's vorticity transport with the wind
+// update (SX_WIND) and update_dz_d's interface-height transport with the advective-form height update (SX_AREA).  Same operator, same
+// expressions in the same order as tp2d_stream_t<TF_WIND | TF_FD, 6, true> / <TF_EPI | TF_AREA | TF_FD, 6, true> of fv3_tp2d.hip on the strips
+// away from the W / E tile edges (bitwise equal: FV3_TP2D_MARCH=old is the A/B switch; tests/test_parity.py::
+// test_single_march_is_bitwise_the_round4_march); CPU twin: oracle/fv3_oracle/fvtp2d.py, d_sw.py, nh.py.  [SURVEY A.3.7, A.4, A.8]
+//
+// The construction is that of fv3_tp4x.hip (see there for the reasons): no rare path in the row step -- the strips that touch a W / E tile
+// edge (per-lane one-sided formulas) and the tiles at a cube corner stay with the round-4 kernel, launched compactly on exactly those tiles
+// (tile_sel); the rows either side of a S / N tile edge and the rows a segment does not own run a general form of the step --, the march
+// unrolled by three with static rotation of the sets in flight, scalar-base addressing, the L sweeps' reconstruction shared between
+// neighbouring lanes, one refined reciprocal per denominator pair.
+#include <type_traits>
+
+#include "fv3_ops.h"
+#include "fv3_math.h"
+#define FV3_MARCH_ST(lhs, val) FV3_ST_NT(lhs, val)
+#include "fv3_ppm.h"
+#include "fv3_march.h"
+
+namespace {
+
+#define SX_OUT 58
+#define SX_ORD 6
+enum { SX_WIND = 1, SX_AREA = 2 };
+#ifndef SX_WPE
+#define SX_WPE (sizeof(Real) == 4 ? 3 : 2)
+#endif
+
+struct SxArgs {
+  const Real *q, *crx, *cry, *xfx, *yfx;
+  const Real *coef;  // d2 of iteration 0 = coef[k] * q
+  // SX_WIND
+  Real *u, *v, *u_pre, *v_pre, *du, *dv;
+  const Real *ke, *add;  // add: 2-D term added to q where the transport loads it (f0)
+  // SX_AREA
+  Real *out;
+};
+
+template <int KIND>
+void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k_hi) {
+  constexpr bool WIND = KIND == SX_WIND, AREA = KIND == SX_AREA;
+  const Geo g = c->g;
+  const int nk = k_hi - k_lo + 1;
+  if (nk <= 0) return;
+  const int nx = g.nx, ny = g.ny, nh = g.nh, go = g.o, sj32 = g.sj32;
+  // (launch geometry of tp2d_stream_t: the two kernels split the same tiles between them)
+  const int nstrip = (nx + 1 + SX_OUT - 1) / SX_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((ny + 63) / 64) * g.nsub * nk, 2);
+  const int nseg = (ny + seg - 1) / seg;
+  static const int kb_env = getenv("FV3_Q4_KB") ? atoi(getenv("FV3_Q4_KB")) : FV3_Q4_KB_DEFAULT;
+  const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
+  const int nblk = KB ? (nk + KB - 1) / KB : 0;
+  const long st = g.st, sk = g.sk, st2 = g.st2;
+  const unsigned char *gflags = c->g_dev->flags;
+  const MPtr garea = g.area, grarea = g.rarea, gd6v = g.del6_v, gd6u = g.del6_u, gdya = g.dya, gdx = g.dx, gdy = g.dy;
+  const SxArgs A = a;
+  constexpr int NRING = 7;
+  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };
+  const size_t smem = sizeof(Real) * (size_t)NRING * 3 * FV3_WAVE;
+  launch_waves<SX_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+    int t, k, bx, by;
+    if (KB) {
+      t = blk_.bz / nblk;
+      const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
+      if (kk >= nk) return;
+      k = k_lo + kk;
+      by = blk_.by / nstrip;
+      bx = blk_.by - by * nstrip;
+    } else {
+      t = blk_.bz / nk;
+      k = k_lo + (blk_.bz - t * nk);
+      bx = blk_.bx;
+      by = blk_.by;
+    }
+    const int fl = gflags[t];
+    const int i0 = 1 + bx * SX_OUT;
+    const int ja = 1 + by * seg;
+    const int jb = by == nseg - 1 ? ny + 1 : ja + seg - 1;
+    const int cb = jb < ny ? jb : ny;
+    const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh, npy = ny + 1;
+    const int r_end = jb + 3 < jed ? jb + 3 : jed;
+    if (tp2d_old_tile(fl, i0, ja, r_end, nx, ny)) return;  // the round-4 kernel's (tile_sel = 1)
+    const bool S = fl & FV3_S, N = fl & FV3_N;
+    const long b = t * st + k * sk, m2 = t * st2;
+    const Real *const qb = A.q + b, *const crxb = A.crx + b, *const cryb = A.cry + b, *const xfxb = A.xfx + b, *const yfxb = A.yfx + b;
+    const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6vb = (const Real *)gd6v + m2, *const d6ub = (const Real *)gd6u + m2;
+    const Real *const addb = WIND ? A.add + m2 : nullptr, *const dxb = (const Real *)gdx + m2, *const dyb = (const Real *)gdy + m2;
+    const Real *const keb = WIND ? A.ke + b : nullptr;
+    Real *const ub = WIND ? A.u + b : nullptr, *const vb = WIND ? A.v + b : nullptr, *const upb = WIND ? A.u_pre + b : nullptr, *const vpb = WIND ? A.v_pre + b : nullptr;
+    Real *const dub = WIND ? A.du + b : nullptr, *const dvb = WIND ? A.dv + b : nullptr;
+    Real *const outb = AREA ? A.out + b : nullptr;
+    const Real dcoef = A.coef[k];
+    const unsigned rowB = (unsigned)sj32 * (unsigned)sizeof(Real);
+    Real *const ring = (Real *)smem_;
+    auto RG = [&](int var, int slot) -> Real * { return ring + (var * 3 + slot) * FV3_WAVE; };
+
+    struct Row {
+      Real qy, cx, xv, ar, cy, yv;
+    };
+    struct Met {
+      Real du, dv, ra, qa;  // qa (WIND): the 2-D term added to q
+    };
+    Row R[3][FV3_LPT];
+    Met MN[3][FV3_LPT];
+    // WIND: the winds / kinetic energy / grid spacings the epilogue of a step needs, requested one step ahead
+    Real Ou[3][FV3_LPT], Odx[3][FV3_LPT], Okf[3][FV3_LPT], Ov[3][FV3_LPT], Ody[3][FV3_LPT];
+    unsigned pcolB[FV3_LPT];
+    bool own_x[FV3_LPT], own_y[FV3_LPT];
+    Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], al_q[FV3_LPT], v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], al_v[FV3_LPT];
+    PpmCell cq[FV3_LPT], cv[FV3_LPT];
+    Real p_prev[FV3_LPT], y_prev[FV3_LPT], fyin[FV3_LPT], px[FV3_LPT], fxk[FV3_LPT], fyp[FV3_LPT], sqx[FV3_LPT], sqi[FV3_LPT], sxv[FV3_LPT];
+    Real sd0[FV3_LPT], sd1[FV3_LPT], sd2[FV3_LPT], gx0[FV3_LPT], gx1[FV3_LPT], gy0[FV3_LPT], gy1[FV3_LPT], dxd[FV3_LPT], dyf[FV3_LPT], zyp[FV3_LPT], zxo[FV3_LPT];
+    Real wkr[FV3_LPT], xjr[FV3_LPT];
+    Real s_al[2][FV3_LPT], s_bl[2][FV3_LPT], s_br[2][FV3_LPT];
+    bool s_sm[2][FV3_LPT];
+    Real h_era[FV3_LPT], h_q5[FV3_LPT], h_ypp[FV3_LPT], h_ox[FV3_LPT], h_oy[FV3_LPT], h_zy0[FV3_LPT];
+
+    auto load_row = [&](int r, int l, auto gen_tag) -> Row {
+      constexpr bool GEN = decltype(gen_tag)::value;
+      const int rf = GEN ? (r - 2 < jsd ? jsd : r - 2) : r - 2;
+      const unsigned p0 = pcolB[l] + (unsigned)r * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
+      Row w;
+      w.qy = px_ld(qb, p0);
+      w.cx = px_ld(crxb, p0);
+      w.xv = px_ld(xfxb, p0);
+      w.ar = px_ld(areab, p0);
+      w.cy = px_ld(cryb, pf);
+      w.yv = px_ld(yfxb, pf);
+      return w;
+    };
+    auto load_opt = [&](int q, int r, int l, auto gen_tag) {  // what step r consumes: face r-2, row r-3 (into set q)
+      if constexpr (WIND) {
+        constexpr bool GEN = decltype(gen_tag)::value;
+        const int r3 = GEN ? (r - 3 < jsd ? jsd : r - 3) : r - 3, rf = GEN ? (r - 2 < jsd ? jsd : r - 2) : r - 2;
+        const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
+        Ou[q][l] = px_ld(ub, pf);
+        Odx[q][l] = px_ld(dxb, pf);
+        Okf[q][l] = px_ld(keb, pf);
+        Ov[q][l] = px_ld(vb, p3);
+        Ody[q][l] = px_ld(dyb, p3);
+      }
+    };
+    auto load_met = [&](int r, int l) -> Met {
+      const unsigned pm = pcolB[l] + (unsigned)r * rowB;
+      Met m;
+      m.du = px_ld(d6ub, pm);
+      m.dv = px_ld(d6vb, pm);
+      m.ra = px_ld(rab, pm);
+      m.qa = WIND ? px_ld(addb, pm) : (Real)0;
+      return m;
+    };
+
+    const int r0 = ja - 3;
+    FV3_LANES(blk_, lane, l) {
+      const int i = i0 - 3 + lane, ic = i < ied ? i : ied;
+      pcolB[l] = (unsigned)(go * sj32 + go + ic) * (unsigned)sizeof(Real);
+      own_x[l] = i >= i0 && i < i0 + SX_OUT && i <= nx + 1;
+      own_y[l] = i >= i0 && i < i0 + SX_OUT && i <= nx;
+      w2[l] = w3[l] = w4[l] = al_q[l] = v2[l] = v3[l] = v4[l] = al_v[l] = (Real)0;
+      cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
+      p_prev[l] = y_prev[l] = fyin[l] = px[l] = fxk[l] = fyp[l] = sqx[l] = sqi[l] = sxv[l] = (Real)0;
+      sd0[l] = sd1[l] = sd2[l] = gx0[l] = gx1[l] = gy0[l] = gy1[l] = dxd[l] = dyf[l] = zyp[l] = zxo[l] = wkr[l] = xjr[l] = (Real)0;
+      h_era[l] = h_q5[l] = h_ypp[l] = h_ox[l] = h_oy[l] = h_zy0[l] = (Real)0;
+      for (int w = 0; w < 2; ++w) {
+        s_al[w][l] = s_bl[w][l] = s_br[w][l] = (Real)0;
+        s_sm[w][l] = false;
+      }
+      for (int v = 0; v < NRING; ++v)
+        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
+      for (int q = 0; q < 3; ++q) Ou[q][l] = Odx[q][l] = Okf[q][l] = Ov[q][l] = Ody[q][l] = (Real)0;
+      MN[0][l] = load_met(r0, l);
+      load_opt(0, r0, l, std::true_type{});
+      R[0][l] = load_row(r0, l, std::true_type{});
+      R[1][l] = load_row(r0 + 1 < r_end ? r0 + 1 : r_end, l, std::true_type{});
+      MN[1][l] = MN[2][l] = MN[0][l];
+      R[2][l] = R[0][l];
+#if PX_ABL == 2
+      R[2][l] = load_row(r0 + 2 < r_end ? r0 + 2 : r_end, l, std::true_type{});
+      load_opt(1, r0 + 1 < r_end ? r0 + 1 : r_end, l, std::true_type{});
+      load_opt(2, r0 + 2 < r_end ? r0 + 2 : r_end, l, std::true_type{});
+      MN[1][l] = load_met(r0 + 1 < r_end ? r0 + 1 : r_end, l);
+      MN[2][l] = load_met(r0 + 2 < r_end ? r0 + 2 : r_end, l);
+#endif
+    }
+
+    auto step = [&](const int r_, auto q_tag, auto gen_tag) {
+      constexpr int Q = decltype(q_tag)::value, Q1 = (Q + 1) % 3, Q2 = (Q + 2) % 3;
+      constexpr bool GEN = decltype(gen_tag)::value;
+      int r = r_;
+      PX_OPAQUE_S(r);
+      const int sy = r - 1;
+      const bool y_edge = GEN && ((S && sy >= 0 && sy <= 2) || (N && sy >= npy - 1 && sy <= npy + 1));
+      const int jr = r - 3, jf = r - 2;
+      const bool fx_row = !GEN || (jr >= ja && jr <= cb), fy_row = !GEN || (jf >= ja && jf <= jb);
+#if PX_ABL == 1
+      FV3_LANES(blk_, lane, l) {
+        const Met mc_ = MN[Q][l];
+        const Row cu = R[Q][l];
+        Real sum = ((cu.qy + cu.cx) + (cu.xv + cu.ar)) + ((cu.cy + cu.yv) + (mc_.du + mc_.dv)) + (mc_.ra + mc_.qa);
+        if constexpr (WIND) sum = sum + ((Ou[Q][l] + Odx[Q][l]) + (Okf[Q][l] + Ov[Q][l]) + Ody[Q][l]);
+        {
+          const int r1 = GEN ? (r + 1 < r_end ? r + 1 : r_end) : r + 1, rn = GEN ? (r + 2 < r_end ? r + 2 : r_end) : r + 2;
+          load_opt(Q1, r1, l, gen_tag);
+          MN[Q1][l] = load_met(r1, l);
+          R[Q2][l] = load_row(rn, l, gen_tag);
+        }
+        if constexpr (WIND) {
+          if (fx_row && own_x[l]) {
+            const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+            FV3_MARCH_ST(*fv3_at(dvb, p), sum);
+            FV3_MARCH_ST(*fv3_at(vpb, p), sum);
+            FV3_MARCH_ST(*fv3_at(vb, p), sum);
+          }
+          if (fy_row && own_y[l]) {
+            const unsigned p = pcolB[l] + (unsigned)jf * rowB;
+            FV3_MARCH_ST(*fv3_at(dub, p), sum);
+            FV3_MARCH_ST(*fv3_at(upb, p), sum);
+            FV3_MARCH_ST(*fv3_at(ub, p), sum);
+          }
+        } else {
+          if (fx_row && own_y[l]) FV3_MARCH_ST(*fv3_at(outb, pcolB[l] + (unsigned)jr * rowB), sum);
+        }
+      }
+      if (PX_ABL == 1) return;
+#endif
+      // ---- phase 1: requests of the next steps; inner y flux at face r-2, q_i at row r-3; del-n chain, own-lane part
+      FV3_LANES(blk_, lane, l) {
+        const Met mc_ = MN[Q][l];
+        {
+#if PX_ABL == 2
+          PX_KEEP(Ou[Q1][l]); PX_KEEP(Odx[Q1][l]); PX_KEEP(Okf[Q1][l]); PX_KEEP(Ov[Q1][l]); PX_KEEP(Ody[Q1][l]);
+          PX_KEEP(MN[Q1][l].du); PX_KEEP(MN[Q1][l].dv); PX_KEEP(MN[Q1][l].ra); PX_KEEP(MN[Q1][l].qa);
+          PX_KEEP(R[Q2][l].qy); PX_KEEP(R[Q2][l].cx); PX_KEEP(R[Q2][l].xv); PX_KEEP(R[Q2][l].ar); PX_KEEP(R[Q2][l].cy); PX_KEEP(R[Q2][l].yv);
+#else
+          const int r1 = GEN ? (r + 1 < r_end ? r + 1 : r_end) : r + 1, rn = GEN ? (r + 2 < r_end ? r + 2 : r_end) : r + 2;
+          load_opt(Q1, r1, l, gen_tag);
+          MN[Q1][l] = load_met(r1, l);
+          R[Q2][l] = load_row(rn, l, gen_tag);
+#endif
+        }
+        const Row cu = R[Q][l];
+        const Real era = RG(RG_RA, Q)[lane];
+        const Real ar3 = RG(RG_AR, Q)[lane];
+        const Real du1 = RG(RG_DU, Q2)[lane], du2 = RG(RG_DU, Q1)[lane], ra1 = RG(RG_RA, Q2)[lane], ra2 = RG(RG_RA, Q1)[lane];
+        RG(RG_DU, Q)[lane] = mc_.du;
+        RG(RG_DV, Q)[lane] = mc_.dv;
+        RG(RG_RA, Q)[lane] = mc_.ra;
+        const Real du0 = mc_.du;
+        h_era[l] = era;
+        const Real yv = px_move(cu.yv);
+        const Real qraw = px_move(cu.qy);  // (the del-n chain runs on the field itself: no added term)
+        const Real qy = WIND ? qraw + mc_.qa : qraw;
+        {
+          const Real d0c = dcoef * qraw;
+          const Real fyc0 = du0 * (sd0[l] - d0c);
+          const Real gxe0 = FV3_LANE_SHL(1, gx0, l, lane), gxe1 = FV3_LANE_SHL(1, gx1, l, lane);
+          const Real d2c1 = (gx0[l] - gxe0 + gy0[l] - fyc0) * ra1;
+          const Real fyc1 = du1 * (d2c1 - sd1[l]);
+          const Real d2c2 = (gx1[l] - gxe1 + gy1[l] - fyc1) * ra2;
+          dyf[l] = du2 * (d2c2 - sd2[l]);
+          gy0[l] = fyc0;
+          gy1[l] = fyc1;
+          sd0[l] = d0c;
+          sd1[l] = d2c1;
+          sd2[l] = d2c2;
+        }
+        const Real a_ = w2[l], b_ = w3[l], c_ = w4[l], d_ = qy;  // q of rows r-3 .. r
+        Real al_new;
+        if (y_edge) {
+          const Real *mmb = (const Real *)gdya + m2;
+          auto My = [&](int s_) { return px_ld(mmb, pcolB[l] + (unsigned)s_ * rowB); };
+          al_new = ppm_al_win(a_, b_, c_, d_, My, sy, S, N, npy);
+          FV3_LANDED(al_new);
+        } else {
+          al_new = PPM_P1 * (b_ + c_) + PPM_P2 * (a_ + d_);
+        }
+        const PpmCell co = ppm_cell(al_q[l], al_new, b_, SX_ORD);
+        al_q[l] = al_new;
+        const Real fyi = ppm_face(cq[l], co, cu.cy);
+        fyin[l] = fyi;
+        cq[l] = co;
+        const Real pn = yv * fyi;
+        const Real den_y = ar3 + y_prev[l] - yv;
+        const Real qi = px_quot(a_ * ar3 + p_prev[l] - pn, den_y, px_rcp(den_y));
+        p_prev[l] = pn;
+        h_ypp[l] = y_prev[l];
+        y_prev[l] = yv;
+        sqx[l] = qy;
+        sqi[l] = qi;
+        h_q5[l] = qy;
+      }
+      PX_FENCE();
+      // ---- phase 2: inner x flux on row r, outer x flux on row r-3, fx of row r-3; del-n chain, x fluxes (2a / 2b / 2c: see fv3_tp4x.hip)
+      FV3_LANES(blk_, lane, l) {
+        s_al[0][l] = PPM_P1 * (FV3_LANE_SHR(1, sqx, l, lane) + sqx[l]) + PPM_P2 * (FV3_LANE_SHR(2, sqx, l, lane) + FV3_LANE_SHL(1, sqx, l, lane));
+        s_al[1][l] = PPM_P1 * (FV3_LANE_SHR(1, sqi, l, lane) + sqi[l]) + PPM_P2 * (FV3_LANE_SHR(2, sqi, l, lane) + FV3_LANE_SHL(1, sqi, l, lane));
+      }
+      FV3_LANES(blk_, lane, l) {
+        const PpmCell ci = ppm_cell(s_al[0][l], FV3_LANE_SHL(1, s_al[0], l, lane), sqx[l], SX_ORD);
+        const PpmCell co = ppm_cell(s_al[1][l], FV3_LANE_SHL(1, s_al[1], l, lane), sqi[l], SX_ORD);
+        s_bl[0][l] = ci.bl;
+        s_br[0][l] = ci.br;
+        s_sm[0][l] = ci.sm;
+        s_bl[1][l] = co.bl;
+        s_br[1][l] = co.br;
+        s_sm[1][l] = co.sm;
+      }
+      FV3_LANES(blk_, lane, l) {
+        const Row cu = R[Q][l];
+        const Real cx = cu.cx, xv = cu.xv;
+        const Real cx3 = RG(RG_CX, Q)[lane], xv3 = RG(RG_XV, Q)[lane], fi3 = RG(RG_FI, Q)[lane];
+        const Real dv0 = RG(RG_DV, Q)[lane], dv1 = RG(RG_DV, Q2)[lane], dv2 = RG(RG_DV, Q1)[lane];
+        const Real e0 = FV3_LANE_SHR(1, sd0, l, lane), e1 = FV3_LANE_SHR(1, sd1, l, lane), e2 = FV3_LANE_SHR(1, sd2, l, lane);
+        gx0[l] = dv0 * (e0 - sd0[l]);
+        gx1[l] = dv1 * (sd1[l] - e1);
+        const Real ox = dxd[l], oy = dyf[l];  // x flux of (i, r-3), y flux of face (i, r-2)
+        dxd[l] = dv2 * (sd2[l] - e2);
+        h_ox[l] = ox;
+        h_oy[l] = oy;
+        if constexpr (AREA) {
+          zxo[l] = ox;
+          h_zy0[l] = zyp[l];
+        }
+        if constexpr (WIND) {  // the vorticity-damping increments of v (row r-3) / u (face r-2); the damping-heat kernel reads them again: stored
+          if (fx_row && own_x[l]) FV3_MARCH_ST(*fv3_at(dvb, pcolB[l] + (unsigned)jr * rowB), ox);
+          if (fy_row && own_y[l]) FV3_MARCH_ST(*fv3_at(dub, pcolB[l] + (unsigned)jf * rowB), oy);
+        }
+        Real ff[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const Real qv = w == 0 ? sqx[l] : sqi[l];
+          const PpmCell cm{FV3_LANE_SHR(1, s_bl[w], l, lane), FV3_LANE_SHR(1, s_br[w], l, lane), w == 0 ? FV3_LANE_SHR(1, sqx, l, lane) : FV3_LANE_SHR(1, sqi, l, lane),
+                           FV3_LANE_SHR1_FLAG(s_sm[w], l, lane)};
+          const PpmCell c0{s_bl[w][l], s_br[w][l], qv, s_sm[w][l]};
+          ff[w] = ppm_face(cm, c0, w == 0 ? cx : cx3);
+        }
+        const Real fxin = ff[0], fxout = ff[1];
+        const Real v = (Real)0.5 * (fxout + fi3) * xv3;
+        if constexpr (WIND) {
+          const Real vn = Ov[Q][l] * Ody[Q][l] + wkr[l] - Okf[Q][l] - v;
+          if (fx_row && own_x[l]) {
+            const unsigned p = pcolB[l] + (unsigned)jr * rowB;
+            FV3_MARCH_ST(*fv3_at(vpb, p), vn);
+            FV3_MARCH_ST(*fv3_at(vb, p), vn - ox);
+          }
+        } else {
+          fxk[l] = v;
+          xjr[l] = xv3;
+        }
+        RG(RG_FI, Q)[lane] = fxin;
+        RG(RG_CX, Q)[lane] = cx;
+        RG(RG_XV, Q)[lane] = xv;
+        px[l] = xv * fxin;
+        sxv[l] = xv;
+      }
+      PX_FENCE();
+      // ---- phase 3: q_j on row r, outer y flux at face r-2, fy of face r-2; the epilogue
+      FV3_LANES(blk_, lane, l) {
+        const Row cu = R[Q][l];
+        const Real p1 = FV3_LANE_SHL(1, px, l, lane), x1 = FV3_LANE_SHL(1, sxv, l, lane);
+        const Real ar = cu.ar;
+        const Real den_x = ar + cu.xv - x1;
+        const Real qj = px_quot(h_q5[l] * ar + px[l] - p1, den_x, px_rcp(den_x));
+        const Real a_ = v2[l], b_ = v3[l], c_ = v4[l], d_ = qj;
+        Real al_new;
+        if (y_edge) {
+          const Real *mmb = (const Real *)gdya + m2;
+          auto My = [&](int s_) { return px_ld(mmb, pcolB[l] + (unsigned)s_ * rowB); };
+          al_new = ppm_al_win(a_, b_, c_, d_, My, sy, S, N, npy);
+          FV3_LANDED(al_new);
+        } else {
+          al_new = PPM_P1 * (b_ + c_) + PPM_P2 * (a_ + d_);
+        }
+        const PpmCell co = ppm_cell(al_v[l], al_new, b_, SX_ORD);
+        al_v[l] = al_new;
+        const Real fyout = ppm_face(cv[l], co, cu.cy);
+        cv[l] = co;
+        v2[l] = b_;
+        v3[l] = c_;
+        v4[l] = d_;
+        const Real v = (Real)0.5 * (fyout + fyin[l]) * cu.yv;
+        if constexpr (WIND) {
+          const Real ke_e = FV3_LANE_SHL(1, Okf[Q], l, lane);  // ke(i + 1, jf): the neighbouring lane loaded it as its ke(i, jf)
+          const Real un = Ou[Q][l] * Odx[Q][l] + Okf[Q][l] - ke_e + v;
+          if (fy_row && own_y[l]) {
+            const unsigned p = pcolB[l] + (unsigned)jf * rowB;
+            FV3_MARCH_ST(*fv3_at(upb, p), un);
+            FV3_MARCH_ST(*fv3_at(ub, p), un + h_oy[l]);
+          }
+          wkr[l] = Okf[Q][l];  // ke(i, jr) of the next step = this step's ke(i, jf)
+        } else {
+          const Real fxe = FV3_LANE_SHL(1, fxk, l, lane), xje = FV3_LANE_SHL(1, xjr, l, lane), zx1 = FV3_LANE_SHL(1, zxo, l, lane);
+          const Real qc = w2[l];  // q(i, r-3)
+          const Real ar_ = RG(RG_AR, Q)[lane];
+          const Real ra_x = ar_ + xjr[l] - xje, ra_y = ar_ + h_ypp[l] - cu.yv;
+          const Real den = ra_x + ra_y - ar_;
+          Real z = px_quot(qc * ar_ + fxk[l] - fxe + fyp[l] - v, den, px_rcp(den));
+          z = z + (h_ox[l] - zx1 + h_zy0[l] - h_oy[l]) * h_era[l];
+          if (fx_row && own_y[l]) FV3_MARCH_ST(*fv3_at(outb, pcolB[l] + (unsigned)jr * rowB), z);
+          fyp[l] = v;
+          zyp[l] = h_oy[l];
+        }
+        w2[l] = w3[l];
+        w3[l] = w4[l];
+        w4[l] = h_q5[l];
+        RG(RG_AR, Q)[lane] = ar;
+      }
+      PX_FENCE();
+    };
+
+    int r_hi = cb + 3 < jb + 2 ? cb + 3 : jb + 2;
+    if (r_hi > r_end - 2) r_hi = r_end - 2;
+    if (N && r_hi > ny) r_hi = ny;
+    int r = r0;
+#pragma clang loop unroll(disable)
+    for (int part = 0; part < 2; ++part) {
+      const int stop = part == 0 ? r0 + 5 : r_end;
+#pragma clang loop unroll(disable)
+      for (; r <= stop; r += 3) {
+        step(r, std::integral_constant<int, 0>{}, std::true_type{});
+        step(r + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        step(r + 2, std::integral_constant<int, 2>{}, std::true_type{});
+      }
+      if (part == 0) {
+#pragma clang loop unroll(disable)
+        for (; r + 2 <= r_hi; r += 3) {
+          step(r, std::integral_constant<int, 0>{}, std::false_type{});
+          step(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
+          step(r + 2, std::integral_constant<int, 2>{}, std::false_type{});
+        }
+      }
+    }
+  });
+}
+
+}  // namespace
+
+// kind 1: the vorticity transport of d_sw with the wind update (epi: wind_u / wind_v / wind_ke / wind_du / wind_dv / wind_u_pre / wind_v_pre, fd_coef,
+// fd_add); kind 2: the interface-height transport of update_dz_d (epi: out, fd_coef).  Levels k0 .. k1 all run their del-n chain inside the march.
+void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
+                       const TpEpi *epi) {
+  SxArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = q;
+  a.crx = crx;
+  a.cry = cry;
+  a.xfx = xfx;
+  a.yfx = yfx;
+  a.coef = epi->fd_coef;
+  if (kind == SX_WIND) {
+    a.u = epi->wind_u;
+    a.v = epi->wind_v;
+    a.u_pre = epi->wind_u_pre;
+    a.v_pre = epi->wind_v_pre;
+    a.du = const_cast<Real *>(epi->wind_du);
+    a.dv = const_cast<Real *>(epi->wind_dv);
+    a.ke = epi->wind_ke;
+    a.add = epi->fd_add;
+    single_march_t<SX_WIND>(c, s, a, k0, k1);
+  } else {
+    a.out = epi->out;
+    single_march_t<SX_AREA>(c, s, a, k0, k1);
+  }
+}

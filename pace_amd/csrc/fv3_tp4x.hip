@@ -29,95 +29,16 @@
 #include "fv3_math.h"
 #define FV3_MARCH_ST(lhs, val) FV3_ST_NT(lhs, val)
 #include "fv3_ppm.h"
+#include "fv3_march.h"
 
 namespace {
 
-#ifndef PX_NO_FENCE
-#define PX_FENCE() FV3_SCHED_FENCE()  // the scheduler may not move code across the phases of a step (unfenced, the unrolled march overlaps them until the registers spill)
-#else
-#define PX_FENCE() ((void)0)
-#endif
-// Ablation builds (diagnostic, never the product library; profiles/r05_ablation.md): -DPX_ABL=1 keeps every load and store of a step and
-// replaces the arithmetic by one sum of what was loaded (the floor the memory system sets for this access pattern); -DPX_ABL=2 keeps the
-// arithmetic and the stores and replaces the loads inside the march by the registers of the first rows, passed through an empty asm so
-// that nothing becomes loop-invariant (the floor instruction issue sets).
-#ifndef PX_ABL
-#define PX_ABL 0
-#endif
-#if PX_ABL == 2 && !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-#define PX_KEEP(x) asm volatile("" : "+v"(x))
-#else
-#define PX_KEEP(x) ((void)0)
-#endif
-#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-#define PX_OPAQUE_S(x) asm volatile("" : "+s"(x))
-#else
-#define PX_OPAQUE_S(x) ((void)0)
-#endif
-#ifdef PX_TRACER_FENCE
-#define PX_FENCE_T() FV3_SCHED_FENCE()  // ... nor across the tracers inside a phase
-#else
-#define PX_FENCE_T() ((void)0)
-#endif
-// the limiter flag of the previous lane: the lane mask shifted by one (a scalar instruction); false for lane 0
-#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-#define FV3_LANE_SHR1_FLAG(arr, l, lane) __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64((arr)[l]) << 1)
-#else
-#define FV3_LANE_SHR1_FLAG(arr, l, lane) ((lane) >= 1 ? (arr)[(l) - 1] : false)
-#endif
-// A value that outlives the step which consumes its load (q -> the PPM windows, the M area flux, the old air mass) is MOVED out of the load's
-// destination register at the point of consumption.  Left to the compiler, the register the load was issued into stays the value's home for
-// up to four more steps, i.e. across the back edge of the unrolled march, where it is copied while a younger load into the same name is still in
-// flight -- and that copy waits for it with vmcnt(0): the whole prefetch, once per three steps (seen in the ISA of the first build).
-#if !defined(FV3_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
-FV3_DEV inline double px_move(double x) {
-  double y;
-  asm volatile("v_mov_b64 %0, %1" : "=v"(y) : "v"(x));
-  return y;
-}
-FV3_DEV inline float px_move(float x) {
-  float y;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
-  return y;
-}
-#else
-inline Real px_move(Real x) { return x; }
-#endif
 #define PX_OUT 58
 #define PX_ORD 6
 enum { PX_AIR = 1, PX_TRC = 2 };
 #ifndef PX_WPE
 #define PX_WPE (sizeof(Real) == 4 ? 4 : 2)
 #endif
-
-// x / y with the denominator's refined reciprocal formed once: r = px_rcp(y); q = px_quot(x, y, r) -- the instruction sequence of
-// fv3_div split at the point where the numerator enters (bit for bit `/` for normal operands; the host emulation and fp32 divide)
-FV3_HD inline Real px_rcp(Real y) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FV3_DIV_PLAIN)
-  if constexpr (sizeof(Real) == 8) {
-    const double r0 = __builtin_amdgcn_rcp((double)y);
-    const double e0 = __builtin_fma(-(double)y, r0, 1.0);
-    const double r1 = __builtin_fma(r0, e0, r0);
-    const double e1 = __builtin_fma(-(double)y, r1, 1.0);
-    return (Real)__builtin_fma(r1, e1, r1);
-  }
-#endif
-  return y;
-}
-FV3_HD inline Real px_quot(Real x, Real y, Real r) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FV3_DIV_PLAIN)
-  if constexpr (sizeof(Real) == 8) {
-    const double q = (double)x * (double)r;
-    const double e2 = __builtin_fma(-(double)y, q, (double)x);
-    return (Real)__builtin_fma(e2, (double)r, q);
-  }
-#endif
-  (void)r;
-  return x / y;
-}
-
-// element at (uniform base) + (32-bit byte offset)
-FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff); }
 
 template <int ROLE>
 void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int k_hi) {

@@ -425,6 +425,26 @@ def test_pair_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout,
             assert np.array_equal(res["new"][r][name], res["old"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (200, (1, 1), "96"), (200, (1, 1), "32"), (250, (2, 2), "0")])
+def test_single_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout, seg):
+    """The single-tracer transports with their del-n chain inside -- d_sw's vorticity transport with the wind update, update_dz_d's
+    interface-height transport -- in their round-5 form (fv3_tp2x.hip; the strips at a W / E tile edge and the cube-corner tiles left to
+    the round-4 kernel, launched on exactly those tiles) against the round-4 kernel on every tile (FV3_TP2D_MARCH=old): bitwise equal
+    states, on sub-domains with interior strips between tile-edge strips, several row segments and 2 x 2 ranks."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("new", "old"):
+        monkeypatch.setenv("FV3_TP2D_MARCH", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["new"][r][name], res["old"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
 def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
     """update_dz_d: the del-n chain of the interface heights run inside the transport march (tp2d_stream_t TF_FD, strips away from
