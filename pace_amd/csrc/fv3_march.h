@@ -85,3 +85,15 @@ FV3_HD inline Real px_quot(Real x, Real y, Real r) {
 
 // element at (uniform base) + (32-bit byte offset)
 FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff); }
+
+// The edge value at the low face of cell s next to a W / E tile edge (fv3_ppm.h: ppm_al), for the lane that holds cell s: kind 1 = the face one
+// before the edge (s == 0 / np-1), 2 = the edge face itself (the two-sided, width-weighted mean; s == 1 / np), 3 = the face one behind it
+// (s == 2 / np+1); 0 = an interior face (al_int).  a, b, c_, d = q(s-2 .. s+1); ma .. md = the cell widths of those cells.  Every form is evaluated in
+// every lane of the strip (the lanes execute together anyway) and the lane keeps its own: the expressions are ppm_al's, so are the bits.
+#include "fv3_ppm.h"
+FV3_HD inline Real px_al_edge(Real al_int, int kind, Real a, Real b, Real c_, Real d, Real ma, Real mb, Real mc, Real md) {
+  const Real f1 = PPM_C1 * a + PPM_C2 * b + PPM_C3 * c_;
+  const Real f2 = ppm_edge_mean(a, b, c_, d, ma, mb, mc, md);
+  const Real f3 = PPM_C3 * b + PPM_C2 * c_ + PPM_C1 * d;
+  return kind == 1 ? f1 : kind == 2 ? f2 : kind == 3 ? f3 : al_int;
+}

@@ -130,11 +130,10 @@ FV3_HD inline bool q4_corner_tile(int fl, int l0, int ca, int r_end, int nL, int
   const bool c_hh = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_lh = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
   return (c_ll && lo_strip && lo_seg) || (c_hl && hi_strip && lo_seg) || (c_hh && hi_strip && hi_seg) || (c_lh && lo_strip && hi_seg);
 }
-// the tiles of a single-tracer FD transport (tp2d_stream_t) that stay with the round-4 kernel: the strips with the W / E one-sided formulas among their
-// faces and the cube-corner tiles; every other tile runs the round-5 march (fv3_tp2x.hip)
-FV3_HD inline bool tp2d_old_tile(int fl, int i0, int ja, int r_end, int nx, int ny) {
-  return ((fl & FV3_W) && i0 <= 3) || ((fl & FV3_E) && i0 + 58 + 1 >= nx) || q4_corner_tile(fl, i0, ja, r_end, nx, ny);
-}
+// the tiles of a single-tracer FD transport (tp2d_stream_t) that stay with the round-4 kernel: the cube-corner tiles; every other tile runs the round-5
+// march (fv3_tp2x.hip), which evaluates the W / E one-sided formulas of a tile-edge strip in its lanes
+FV3_HD inline bool tp2d_old_tile(int fl, int i0, int ja, int r_end, int nx, int ny) { return q4_corner_tile(fl, i0, ja, r_end, nx, ny); }
+bool tp2d_fd_lean(int hord);  // (fv3_tp2d.hip) will tp2d's FD forms run the round-5 march?  (then only the corner patches of the chain's fluxes are needed)
 // kind 1: d_sw's vorticity transport + wind update, 2: update_dz_d's interface-height transport (TpEpi as for tp2d with fd = 1); PPM order 6
 struct TpEpi;
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,

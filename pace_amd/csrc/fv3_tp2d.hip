@@ -1200,6 +1200,15 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   });
 }
 
+// Will the FD forms of tp2d (TpEpi::fd != 0, FA contract) run the round-5 march of fv3_tp2x.hip?  It serves every tile of the sub-domains, so the
+// callers then compute the chain's fluxes only on the cube-corner patches (del6_vt_flux_patches) instead of on the whole tile-edge strips.
+bool tp2d_fd_lean(int hord) {
+  static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
+  static const bool fa_off = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
+  const char *me = getenv("FV3_TP2D_MARCH");  // (read per call: the parity test flips it)
+  return hord == 6 && !hc_off && !fa_off && !TS_LDS_ONLY && !(me && !strcmp(me, "old"));
+}
+
 static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
                         const Real *mfx, const Real *mfy, const Real *mass, int hord, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   unsigned m = 0;
@@ -1223,23 +1232,25 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   // (FA: what the two callers of the FD forms guarantee -- fv3_update_dz_d / fv3_d_sw_out pass only levels whose chain is on)
   static const bool fa_off = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
   if (hord == 6 && !hc_off && !TS_LDS_ONLY) {
-    // Round 5: the FA forms run the branch-free march of fv3_tp2x.hip on the tiles away from the W / E tile edges and the cube corners, the
-    // round-4 kernel on the others (tile_sel = 1).  FV3_TP2D_MARCH=old: the round-4 kernel on every tile (A/B; read per call).
-    const char *me = getenv("FV3_TP2D_MARCH");
-    const bool sx_on = !(me && !strcmp(me, "old")) && epi->fd_coef;
+    // Round 5: the FA forms run the march of fv3_tp2x.hip (every tile: it evaluates the W / E one-sided formulas in its lanes and the cube-corner
+    // remaps / patch fluxes in its general steps).  FV3_TP2D_MARCH=old: the round-4 kernel (A/B; read per call).
+    const bool sx_on = tp2d_fd_lean(hord) && epi && epi->fd_coef;
     if (m == (TF_EPI | TF_AREA | TF_FD)) {
       if (!fa_off && epi->area_form && epi->zfx && epi->out) {
-        if (sx_on) tp2d_single_march(c, s, 2, q, crx, cry, xfx, yfx, k0, k1, epi);
-        tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi, sx_on ? 1 : 0);
+        if (sx_on)
+          tp2d_single_march(c, s, 2, q, crx, cry, xfx, yfx, k0, k1, epi);
+        else
+          tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       } else
         tp2d_stream_t<(TF_EPI | TF_AREA | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       return;
     }
     if (m == (TF_WIND | TF_FD)) {
       if (!fa_off && epi->wind_du && epi->wind_u_pre && epi->wind_v_pre) {
-        const bool wx_on = sx_on && epi->fd_add;
-        if (wx_on) tp2d_single_march(c, s, 1, q, crx, cry, xfx, yfx, k0, k1, epi);
-        tp2d_stream_t<(TF_WIND | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi, wx_on ? 1 : 0);
+        if (sx_on && epi->fd_add)
+          tp2d_single_march(c, s, 1, q, crx, cry, xfx, yfx, k0, k1, epi);
+        else
+          tp2d_stream_t<(TF_WIND | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       } else
         tp2d_stream_t<(TF_WIND | TF_FD), 6>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       return;

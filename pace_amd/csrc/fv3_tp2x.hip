@@ -34,6 +34,8 @@ struct SxArgs {
   const Real *ke, *add;  // add: 2-D term added to q where the transport loads it (f0)
   // SX_AREA
   Real *out;
+  // the staged chain's damping fluxes on the cube-corner patches (read where the chain of the march does not reach: corner-halo remaps)
+  const Real *pfx, *pfy;
 };
 
 template <int KIND>
@@ -52,10 +54,11 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const unsigned char *gflags = c->g_dev->flags;
-  const MPtr garea = g.area, grarea = g.rarea, gd6v = g.del6_v, gd6u = g.del6_u, gdya = g.dya, gdx = g.dx, gdy = g.dy;
+  const Geo *gp = c->g_dev;
+  const MPtr garea = g.area, grarea = g.rarea, gd6v = g.del6_v, gd6u = g.del6_u, gdya = g.dya, gdx = g.dx, gdy = g.dy, gdxa = g.dxa;
   const SxArgs A = a;
-  constexpr int NRING = 7;
-  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };
+  constexpr int NRING = 8;
+  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6, RG_MX = 7 };
   const size_t smem = sizeof(Real) * (size_t)NRING * 3 * FV3_WAVE;
   launch_waves<SX_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     int t, k, bx, by;
@@ -79,9 +82,24 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     const int cb = jb < ny ? jb : ny;
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh, npy = ny + 1;
     const int r_end = jb + 3 < jed ? jb + 3 : jed;
-    if (tp2d_old_tile(fl, i0, ja, r_end, nx, ny)) return;  // the round-4 kernel's (tile_sel = 1)
     const bool S = fl & FV3_S, N = fl & FV3_N;
+    // Cube corners (general steps only): the rows outside 1 .. ny of a strip with corner-halo columns see the field through the two
+    // copy_corners remaps (one per sweep direction); the del-n fluxes of the faces on a corner patch come from the staged chain's arrays.
+    const bool halo_cols = i0 - 3 < 1 || i0 + FV3_WAVE - 4 > nx;
+    const bool c_sw_ = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_se = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
+    const bool c_ne = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_nw = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
+    const bool pz = ((c_sw_ || c_nw) && i0 - 3 <= FV3_D6_PATCH) || ((c_se || c_ne) && i0 + FV3_WAVE - 4 >= nx + 2 - FV3_D6_PATCH);
+    auto on_patch = [&](int i, int j) -> bool {
+      const bool wi = i >= 1 && i <= FV3_D6_PATCH, ei = i >= nx + 2 - FV3_D6_PATCH && i >= 1 && i <= nx + 1;
+      const bool sj = j >= 1 && j <= FV3_D6_PATCH, nj = j >= ny + 2 - FV3_D6_PATCH && j >= 1 && j <= ny + 1;
+      return (wi && sj && c_sw_) || (ei && sj && c_se) || (ei && nj && c_ne) || (wi && nj && c_nw);
+    };
+    // XE: this strip has W / E one-sided formulas among its x faces (the three faces either side of the tile edge).  They use the same four cells as the
+    // interior edge value (+ the cell widths dxa of those cells), so a lane evaluates them beside the interior form and keeps what its face calls for.
+    const bool Wst = (fl & FV3_W) && i0 <= 3, Est = (fl & FV3_E) && i0 + SX_OUT + 1 >= nx;
+    const bool xe = Wst || Est;
     const long b = t * st + k * sk, m2 = t * st2;
+    const Real *const dxab = (const Real *)gdxa + m2;
     const Real *const qb = A.q + b, *const crxb = A.crx + b, *const cryb = A.cry + b, *const xfxb = A.xfx + b, *const yfxb = A.yfx + b;
     const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6vb = (const Real *)gd6v + m2, *const d6ub = (const Real *)gd6u + m2;
     const Real *const addb = WIND ? A.add + m2 : nullptr, *const dxb = (const Real *)gdx + m2, *const dyb = (const Real *)gdy + m2;
@@ -99,6 +117,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     };
     struct Met {
       Real du, dv, ra, qa;  // qa (WIND): the 2-D term added to q
+      Real mx;              // XE strips: the cell width dxa of the lane's column
     };
     Row R[3][FV3_LPT];
     Met MN[3][FV3_LPT];
@@ -113,6 +132,8 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     Real wkr[FV3_LPT], xjr[FV3_LPT];
     Real s_al[2][FV3_LPT], s_bl[2][FV3_LPT], s_br[2][FV3_LPT];
     bool s_sm[2][FV3_LPT];
+    int akind[FV3_LPT];                  // XE strips: which edge-value form the lane's cell takes (0 interior; 1, 2, 3: ppm_al's one-sided forms)
+    Real h_mx0[FV3_LPT], h_mx3[FV3_LPT];  // XE strips: dxa of the lane's column on rows r / r-3
     Real h_era[FV3_LPT], h_q5[FV3_LPT], h_ypp[FV3_LPT], h_ox[FV3_LPT], h_oy[FV3_LPT], h_zy0[FV3_LPT];
 
     auto load_row = [&](int r, int l, auto gen_tag) -> Row {
@@ -147,6 +168,8 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       m.dv = px_ld(d6vb, pm);
       m.ra = px_ld(rab, pm);
       m.qa = WIND ? px_ld(addb, pm) : (Real)0;
+      m.mx = (Real)1;
+      if (xe) m.mx = px_ld(dxab, pm);
       return m;
     };
 
@@ -156,6 +179,10 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       pcolB[l] = (unsigned)(go * sj32 + go + ic) * (unsigned)sizeof(Real);
       own_x[l] = i >= i0 && i < i0 + SX_OUT && i <= nx + 1;
       own_y[l] = i >= i0 && i < i0 + SX_OUT && i <= nx;
+      akind[l] = 0;
+      if (Wst && i >= 0 && i <= 2) akind[l] = 1 + i;
+      if (Est && i >= nx && i <= nx + 2) akind[l] = 1 + (i - nx);
+      h_mx0[l] = h_mx3[l] = (Real)1;
       w2[l] = w3[l] = w4[l] = al_q[l] = v2[l] = v3[l] = v4[l] = al_v[l] = (Real)0;
       cq[l] = cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       p_prev[l] = y_prev[l] = fyin[l] = px[l] = fxk[l] = fyp[l] = sqx[l] = sqi[l] = sxv[l] = (Real)0;
@@ -166,7 +193,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         s_sm[w][l] = false;
       }
       for (int v = 0; v < NRING; ++v)
-        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
+        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = (v == RG_AR || v == RG_MX) ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
       for (int q = 0; q < 3; ++q) Ou[q][l] = Odx[q][l] = Okf[q][l] = Ov[q][l] = Ody[q][l] = (Real)0;
       MN[0][l] = load_met(r0, l);
       load_opt(0, r0, l, std::true_type{});
@@ -247,9 +274,29 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         RG(RG_RA, Q)[lane] = mc_.ra;
         const Real du0 = mc_.du;
         h_era[l] = era;
+        if (xe) {
+          h_mx3[l] = RG(RG_MX, Q)[lane];
+          RG(RG_MX, Q)[lane] = mc_.mx;
+          h_mx0[l] = mc_.mx;
+        }
         const Real yv = px_move(cu.yv);
         const Real qraw = px_move(cu.qy);  // (the del-n chain runs on the field itself: no added term)
-        const Real qy = WIND ? qraw + mc_.qa : qraw;
+        Real qy = WIND ? qraw + mc_.qa : qraw, qx = qy;
+        if (GEN && halo_cols && (r < 1 || r > ny)) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
+          int lane_o = lane;
+          FV3_LAUNDER(lane_o);
+          const int i = i0 - 3 + lane_o, ic = i < ied ? i : ied;
+          const int rc = r < jed ? r : jed;  // (trailing steps past the last row)
+          const unsigned iy = cc_index<2>(*gp, fl, ic, rc), ix = cc_index<1>(*gp, fl, ic, rc);
+          qy = qb[iy];
+          qx = qb[ix];
+          if constexpr (WIND) {
+            qy = qy + addb[iy];
+            qx = qx + addb[ix];
+          }
+          FV3_LANDED(qy);
+          FV3_LANDED(qx);
+        }
         {
           const Real d0c = dcoef * qraw;
           const Real fyc0 = du0 * (sd0[l] - d0c);
@@ -285,7 +332,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         p_prev[l] = pn;
         h_ypp[l] = y_prev[l];
         y_prev[l] = yv;
-        sqx[l] = qy;
+        sqx[l] = qx;
         sqi[l] = qi;
         h_q5[l] = qy;
       }
@@ -294,6 +341,12 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       FV3_LANES(blk_, lane, l) {
         s_al[0][l] = PPM_P1 * (FV3_LANE_SHR(1, sqx, l, lane) + sqx[l]) + PPM_P2 * (FV3_LANE_SHR(2, sqx, l, lane) + FV3_LANE_SHL(1, sqx, l, lane));
         s_al[1][l] = PPM_P1 * (FV3_LANE_SHR(1, sqi, l, lane) + sqi[l]) + PPM_P2 * (FV3_LANE_SHR(2, sqi, l, lane) + FV3_LANE_SHL(1, sqi, l, lane));
+        if (xe) {
+          s_al[0][l] = px_al_edge(s_al[0][l], akind[l], FV3_LANE_SHR(2, sqx, l, lane), FV3_LANE_SHR(1, sqx, l, lane), sqx[l], FV3_LANE_SHL(1, sqx, l, lane),
+                                  FV3_LANE_SHR(2, h_mx0, l, lane), FV3_LANE_SHR(1, h_mx0, l, lane), h_mx0[l], FV3_LANE_SHL(1, h_mx0, l, lane));
+          s_al[1][l] = px_al_edge(s_al[1][l], akind[l], FV3_LANE_SHR(2, sqi, l, lane), FV3_LANE_SHR(1, sqi, l, lane), sqi[l], FV3_LANE_SHL(1, sqi, l, lane),
+                                  FV3_LANE_SHR(2, h_mx3, l, lane), FV3_LANE_SHR(1, h_mx3, l, lane), h_mx3[l], FV3_LANE_SHL(1, h_mx3, l, lane));
+        }
       }
       FV3_LANES(blk_, lane, l) {
         const PpmCell ci = ppm_cell(s_al[0][l], FV3_LANE_SHL(1, s_al[0], l, lane), sqx[l], SX_ORD);
@@ -313,8 +366,17 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         const Real e0 = FV3_LANE_SHR(1, sd0, l, lane), e1 = FV3_LANE_SHR(1, sd1, l, lane), e2 = FV3_LANE_SHR(1, sd2, l, lane);
         gx0[l] = dv0 * (e0 - sd0[l]);
         gx1[l] = dv1 * (sd1[l] - e1);
-        const Real ox = dxd[l], oy = dyf[l];  // x flux of (i, r-3), y flux of face (i, r-2)
+        Real ox = dxd[l], oy = dyf[l];  // x flux of (i, r-3), y flux of face (i, r-2)
         dxd[l] = dv2 * (sd2[l] - e2);
+        if (GEN && pz) {
+          int lane_o = lane;
+          FV3_LAUNDER(lane_o);
+          const int i = i0 - 3 + lane_o;
+          if (jr >= 1 && jr <= ny && on_patch(i, jr)) ox = px_ld(A.pfx + b, pcolB[l] + (unsigned)jr * rowB);
+          if (i <= nx && on_patch(i, jf)) oy = px_ld(A.pfy + b, pcolB[l] + (unsigned)jf * rowB);
+          FV3_LANDED(ox);
+          FV3_LANDED(oy);
+        }
         h_ox[l] = ox;
         h_oy[l] = oy;
         if constexpr (AREA) {
@@ -411,10 +473,12 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     int r_hi = cb + 3 < jb + 2 ? cb + 3 : jb + 2;
     if (r_hi > r_end - 2) r_hi = r_end - 2;
     if (N && r_hi > ny) r_hi = ny;
+    if (pz && r_hi > ny - FV3_D6_PATCH + 2) r_hi = ny - FV3_D6_PATCH + 2;  // (the first step that consumes a face of a N corner patch: r - 2 = ny + 2 - PATCH)
+    const int head = pz && r0 <= FV3_D6_PATCH + 3 ? 15 : 6;               // (... of a S corner patch: r - 3 <= PATCH)
     int r = r0;
 #pragma clang loop unroll(disable)
     for (int part = 0; part < 2; ++part) {
-      const int stop = part == 0 ? r0 + 5 : r_end;
+      const int stop = part == 0 ? r0 + head - 1 : r_end;
 #pragma clang loop unroll(disable)
       for (; r <= stop; r += 3) {
         step(r, std::integral_constant<int, 0>{}, std::true_type{});
@@ -456,9 +520,13 @@ void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, cons
     a.dv = const_cast<Real *>(epi->wind_dv);
     a.ke = epi->wind_ke;
     a.add = epi->fd_add;
+    a.pfx = epi->wind_dv;
+    a.pfy = epi->wind_du;
     single_march_t<SX_WIND>(c, s, a, k0, k1);
   } else {
     a.out = epi->out;
+    a.pfx = epi->zfx;
+    a.pfy = epi->zfy;
     single_march_t<SX_AREA>(c, s, a, k0, k1);
   }
 }
