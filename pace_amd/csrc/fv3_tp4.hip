@@ -981,12 +981,15 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
       const char *me = getenv("FV3_DSW_MARCH");
       const bool px_on = !(me && !strcmp(me, "old")) && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6;
       // (measured and dropped: the transposed tile-edge marches on the auxiliary stream beside the interior ones -- d_sw 51.5 ms either way)
-      if (px_on) dsw_pair_march(c, s, a, 1, kf, nz1);
-      dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1, px_on ? 1 : 0);
-      if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
-      if (px_on) dsw_pair_march(c, s, a, 2, kf, nz1);
-      dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1, px_on ? 1 : 0);
-      if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+      if (px_on) {  // (every tile: the W / E one-sided formulas in the lanes, the cube-corner remaps / patch fluxes in the general steps)
+        dsw_pair_march(c, s, a, 1, kf, nz1);
+        dsw_pair_march(c, s, a, 2, kf, nz1);
+      } else {
+        dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+        if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+        dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
+        if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
+      }
     }
     if (s2 != s) fv3_wait(c, s, 3);
   }

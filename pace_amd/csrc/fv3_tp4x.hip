@@ -56,7 +56,10 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const unsigned char *gflags = c->g_dev->flags;
-  const MPtr garea = g.area, grarea = g.rarea, gd6L = g.del6_v, gd6M = g.del6_u, gdya = g.dya;
+  const MPtr garea = g.area, grarea = g.rarea, gd6L = g.del6_v, gd6M = g.del6_u, gdya = g.dya, gdxa = g.dxa;
+  const Geo *gp = c->g_dev;
+  // the staged chain's damping fluxes on the cube-corner patches, per tracer slot (L faces, M faces)
+  const Real *const pL0 = AIR ? a.dpx : a.dqx, *const pL1 = AIR ? a.dwx : a.dtx, *const pM0 = AIR ? a.dpy : a.dqy, *const pM1 = AIR ? a.dwy : a.dty;
   // what a wave reads / writes (ROLE folds the unused ones away)
   const Real *const q0f = AIR ? a.delp : a.q_con, *const q1f = AIR ? a.w : a.pt;
   const Real *const crL = a.crx, *const crM = a.cry, *const afL = a.xfx, *const afM = a.yfx;
@@ -68,8 +71,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
   const Deln dn_vt = a.dn_vt, dn_t = a.dn_t, dn_w = a.dn_w;
   const Real *ke_bg_k = g.ke_bg;
   const Real adt = fabs(a.dt);
-  constexpr int NRING = 8;  // ring variables: del-n metric rows (M faces, L faces, 1 / area), Courant number, area flux, area, inner L flux x 2
-  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6 };
+  constexpr int NRING = 9;  // ring variables: del-n metric rows (M faces, L faces, 1 / area), Courant number, area flux, area, inner L flux x 2, cell width (tile-edge strips)
+  enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6, RG_MX = 8 };
   const size_t smem = sizeof(Real) * (size_t)NRING * 3 * FV3_WAVE;
   launch_waves<PX_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     int t, k, bx, by;
@@ -93,11 +96,24 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     const int cb = fb < nM ? fb : nM;
     const int Led = nL + nh, Msd = 1 - nh, Med = nM + nh, npM = nM + 1;
     const int r_end = fb + 3 < Med ? fb + 3 : Med;
-    if (q4_corner_tile(fl, l0, ca, r_end, nL, nM)) return;  // the round-4 kernel's (tile_sel = 1)
     const bool Mlo = fl & FV3_S, Mhi = fl & FV3_N;
+    // xe: this strip has W / E one-sided formulas among its L faces (evaluated in the lanes: px_al_edge)
+    const bool Llo = (fl & FV3_W) && l0 <= 3, Lhi = (fl & FV3_E) && l0 + PX_OUT + 1 >= nL;
+    const bool xe = Llo || Lhi;
+    // Cube corners (general steps only): corner-halo remaps of the rows outside 1 .. nM, the staged chain's fluxes on the corner patches
+    const bool halo_cols = l0 - 3 < 1 || l0 + FV3_WAVE - 4 > nL;
+    const bool c_ll = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_hl = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
+    const bool c_hh = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_lh = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
+    const bool pz = ((c_ll || c_lh) && l0 - 3 <= FV3_D6_PATCH) || ((c_hl || c_hh) && l0 + FV3_WAVE - 4 >= nL + 2 - FV3_D6_PATCH);
+    auto on_patch = [&](int lc, int m) -> bool {
+      const bool llo = lc >= 1 && lc <= FV3_D6_PATCH, lhi = lc >= nL + 2 - FV3_D6_PATCH && lc >= 1 && lc <= nL + 1;
+      const bool mlo = m >= 1 && m <= FV3_D6_PATCH, mhi = m >= nM + 2 - FV3_D6_PATCH && m >= 1 && m <= nM + 1;
+      return (llo && mlo && c_ll) || (lhi && mlo && c_hl) || (lhi && mhi && c_hh) || (llo && mhi && c_lh);
+    };
     const long b = t * st + k * sk, m2 = t * st2;
     // uniform bases
     const Real *const q0b = q0f + b, *const q1b = q1f + b, *const crLb = crL + b, *const crMb = crM + b, *const afLb = afL + b, *const afMb = afM + b;
+    const Real *const dxab = (const Real *)gdxa + m2;
     const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6Lb = (const Real *)gd6L + m2, *const d6Mb = (const Real *)gd6M + m2;
     Real *const accLb = accL + b, *const accMb = accM + b, *const flLb = flL + b, *const flMb = flM + b;
     const Real *const oldmb = oldm + b;
@@ -115,6 +131,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     };
     struct Met {  // del-n metric terms of a row, requested one step ahead
       Real du, dv, ra;
+      Real mx;  // tile-edge strips: the cell width dxa of the lane's column
     };
     Row R[3][FV3_LPT];
     // inputs a step consumes late, requested one step ahead.  AIR: accumulated L / M fluxes;  TRC: air-mass L / M fluxes, old air mass of (lc, r-2)
@@ -136,6 +153,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     // values handed from phase to phase inside a step
     Real s_al[2][2][FV3_LPT], s_bl[2][2][FV3_LPT], s_br[2][2][FV3_LPT];  // L sweeps (inner, outer) x tracers: edge value at the low face of the lane's cell, the cell's bl / br ...
     bool s_sm[2][2][FV3_LPT];                                              // ... and limiter flag
+    int akind[FV3_LPT];                   // tile-edge strips: the edge-value form of the lane's cell (px_al_edge)
+    Real h_mx0[FV3_LPT], h_mx3[FV3_LPT];  // ... and dxa of the lane's column on rows r / r-3
     Real h_era[FV3_LPT], h_ody[2][FV3_LPT], h_q5[2][FV3_LPT], h_mc[FV3_LPT];
     Real h_zx0[FV3_LPT], h_zy0[FV3_LPT], h_zy1[FV3_LPT];
 
@@ -173,6 +192,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       m.du = px_ld(d6Mb, pm);
       m.dv = px_ld(d6Lb, pm);
       m.ra = px_ld(rab, pm);
+      m.mx = (Real)1;
+      if (xe) m.mx = px_ld(dxab, pm);
       return m;
     };
 
@@ -182,14 +203,10 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       pcolB[l] = (unsigned)(go * sj32 + go + lcc) * (unsigned)sizeof(Real);
       own_x[l] = lc >= l0 && lc < l0 + PX_OUT && lc <= nL + 1;
       own_y[l] = lc >= l0 && lc < l0 + PX_OUT && lc <= nL;
-      if (fl & FV3_W) {  // the columns the W / E one-sided formulas reach belong to the EDGE launch
-        own_x[l] = own_x[l] && lc > 3;
-        own_y[l] = own_y[l] && lc > 3;
-      }
-      if (fl & FV3_E) {
-        own_x[l] = own_x[l] && lc < nL - 3 + 2;
-        own_y[l] = own_y[l] && lc < nL - 3 + 1;
-      }
+      akind[l] = 0;
+      if (Llo && lc >= 0 && lc <= 2) akind[l] = 1 + lc;
+      if (Lhi && lc >= nL && lc <= nL + 2) akind[l] = 1 + (lc - nL);
+      h_mx0[l] = h_mx3[l] = (Real)1;
       y_prev[l] = smb[l] = sxv[l] = mbk[l] = fyp_air[l] = zyp[l] = zxo[l] = (Real)0;
       h_era[l] = h_mc[l] = h_zx0[l] = h_zy0[l] = h_zy1[l] = (Real)0;
 #pragma unroll
@@ -205,7 +222,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         }
       }
       for (int v = 0; v < NRING; ++v)
-        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = v == RG_AR ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
+        for (int q = 0; q < 3; ++q) RG(v, q)[lane] = (v == RG_AR || v == RG_MX) ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
       // step r0 (Q = 0) consumes R[0] = row r0, O[0], MN[0]; row r0 + 1 is in flight in R[1]
       MN[0][l] = load_met(r0, l);
 #pragma unroll
@@ -294,13 +311,30 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         RG(RG_RA, Q)[lane] = mc_.ra;
         const Real du0 = mc_.du;
         h_era[l] = era;
+        if (xe) {
+          h_mx3[l] = RG(RG_MX, Q)[lane];
+          RG(RG_MX, Q)[lane] = mc_.mx;
+          h_mx0[l] = mc_.mx;
+        }
         const Real yv = px_move(cu.yv);
         const Real den_y = ar3 + y_prev[l] - yv;
         const Real rden_y = px_rcp(den_y);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const Real qraw = px_move(n == 0 ? cu.q0 : cu.q1);
-          {  // del-n chain: d2 of iteration s on row r-s, its M flux at face r-s
+          Real qy = qraw, qx = qraw;
+          if (GEN && halo_cols && (r < 1 || r > nM)) {  // the two sweeps see the cube-corner cells through different remaps (rare, not prefetched)
+            int lane_o = lane;
+            FV3_LAUNDER(lane_o);
+            const int lc = l0 - 3 + lane_o, lcc = lc < Led ? lc : Led;
+            const int rc = r < Med ? r : Med;
+            const Real *qf = (n == 0 ? q0f : q1f) + b;
+            qy = cc<2>(qf, *gp, fl, lcc, rc);
+            qx = cc<1>(qf, *gp, fl, lcc, rc);
+            FV3_LANDED(qy);
+            FV3_LANDED(qx);
+          }
+          {  // del-n chain (on the field itself: the corner-halo remaps belong to the patches): d2 of iteration s on row r-s, its M flux at face r-s
             const Real cf = n == 0 ? c0 : c1;
             const Real d0c = AIR ? cf * qraw : qraw;
             const Real fyc0 = du0 * (sd0[n][l] - d0c);
@@ -315,7 +349,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
             sd1[n][l] = d2c1;
             sd2[n][l] = d2c2;
           }
-          const Real a_ = w2[n][l], b_ = w3[n][l], c_ = w4[n][l], d_ = qraw;  // q of rows r-3 .. r
+          const Real a_ = w2[n][l], b_ = w3[n][l], c_ = w4[n][l], d_ = qy;  // q of rows r-3 .. r
           Real al_new;
           if (m_edge) {
             const Real *mmb = (const Real *)gdya + m2;
@@ -333,9 +367,9 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
           const Real pn = yv * fyi;
           const Real qi = px_quot(a_ * ar3 + p_prev[n][l] - pn, den_y, rden_y);
           p_prev[n][l] = pn;
-          sqx[n][l] = qraw;
+          sqx[n][l] = qx;
           sqi[n][l] = qi;
-          h_q5[n][l] = qraw;
+          h_q5[n][l] = qy;
           PX_FENCE_T();
         }
         y_prev[l] = yv;
@@ -359,6 +393,15 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         for (int n = 0; n < 2; ++n) {
           s_al[0][n][l] = PPM_P1 * (FV3_LANE_SHR(1, sqx[n], l, lane) + sqx[n][l]) + PPM_P2 * (FV3_LANE_SHR(2, sqx[n], l, lane) + FV3_LANE_SHL(1, sqx[n], l, lane));
           s_al[1][n][l] = PPM_P1 * (FV3_LANE_SHR(1, sqi[n], l, lane) + sqi[n][l]) + PPM_P2 * (FV3_LANE_SHR(2, sqi[n], l, lane) + FV3_LANE_SHL(1, sqi[n], l, lane));
+        }
+        if (xe) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            s_al[0][n][l] = px_al_edge(s_al[0][n][l], akind[l], FV3_LANE_SHR(2, sqx[n], l, lane), FV3_LANE_SHR(1, sqx[n], l, lane), sqx[n][l], FV3_LANE_SHL(1, sqx[n], l, lane),
+                                       FV3_LANE_SHR(2, h_mx0, l, lane), FV3_LANE_SHR(1, h_mx0, l, lane), h_mx0[l], FV3_LANE_SHL(1, h_mx0, l, lane));
+            s_al[1][n][l] = px_al_edge(s_al[1][n][l], akind[l], FV3_LANE_SHR(2, sqi[n], l, lane), FV3_LANE_SHR(1, sqi[n], l, lane), sqi[n][l], FV3_LANE_SHL(1, sqi[n], l, lane),
+                                       FV3_LANE_SHR(2, h_mx3, l, lane), FV3_LANE_SHR(1, h_mx3, l, lane), h_mx3[l], FV3_LANE_SHL(1, h_mx3, l, lane));
+          }
         }
       }
       FV3_LANES(blk_, lane, l) {  // 2b: the lane's cell
@@ -388,8 +431,27 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
           o_dx[n] = dxd[n][l];  // final L flux of row r-3 (formed at the previous step)
           o_dy[n] = dyf[n][l];
           dxd[n][l] = dv2 * (sd2[n][l] - e2);  // ... of row r-2
-          h_ody[n][l] = o_dy[n];
         }
+        if (GEN && pz) {  // faces on a cube-corner patch: the staged chain's fluxes
+          int lane_o = lane;
+          FV3_LAUNDER(lane_o);
+          const int lc = l0 - 3 + lane_o;
+          const bool px_ = jr >= 1 && jr <= nM && on_patch(lc, jr), py_ = lc <= nL && on_patch(lc, jf);
+          if (px_) {
+            o_dx[0] = px_ld(pL0 + b, pcolB[l] + (unsigned)jr * rowB);
+            o_dx[1] = px_ld(pL1 + b, pcolB[l] + (unsigned)jr * rowB);
+          }
+          if (py_) {
+            o_dy[0] = px_ld(pM0 + b, pcolB[l] + (unsigned)jf * rowB);
+            o_dy[1] = px_ld(pM1 + b, pcolB[l] + (unsigned)jf * rowB);
+          }
+          FV3_LANDED(o_dx[0]);
+          FV3_LANDED(o_dx[1]);
+          FV3_LANDED(o_dy[0]);
+          FV3_LANDED(o_dy[1]);
+        }
+        h_ody[0][l] = o_dy[0];
+        h_ody[1][l] = o_dy[1];
         if constexpr (AIR) {
           h_zx0[l] = o_dx[1];
           h_zy0[l] = zyp[l];
@@ -540,10 +602,12 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     int r_hi = cb + 3 < fb + 2 ? cb + 3 : fb + 2;  // last row whose step owns both its cell row and its M face ...
     if (r_hi > r_end - 2) r_hi = r_end - 2;        // ... and requests no row past the segment's last
     if (Mhi && r_hi > nM) r_hi = nM;               // ... and meets no N tile-edge formula
+    if (pz && r_hi > nM - FV3_D6_PATCH + 2) r_hi = nM - FV3_D6_PATCH + 2;  // ... and consumes no face of a N corner patch (first: r - 2 = nM + 2 - PATCH)
+    const int head = pz && r0 <= FV3_D6_PATCH + 3 ? 15 : 6;                // (S corner patch: faces up to r - 3 = PATCH)
     int r = r0;
 #pragma clang loop unroll(disable)
     for (int part = 0; part < 2; ++part) {  // (one copy of the general triple in the code: head and tail are two trips of this loop)
-      const int stop = part == 0 ? r0 + 5 : r_end;
+      const int stop = part == 0 ? r0 + head - 1 : r_end;
 #pragma clang loop unroll(disable)
       for (; r <= stop; r += 3) {
         step(r, std::integral_constant<int, 0>{}, std::true_type{});
