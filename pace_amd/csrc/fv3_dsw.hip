@@ -1231,6 +1231,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   //      u += vtd, v -= utd on the levels that have it; the winds BEFORE that damping -- what the damping heat is
   //      formed from -- go to scratch beside
   Real *u_pre = c->scratch[SC_N], *v_pre = c->scratch[SC_O];
+  int heat_k1 = nz1;  // last level the damping-heat kernel serves
   {
     TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
     // (the levels without the chain: a small launch, on the auxiliary stream beside the others -- events 2 = fork, 3 = join)
@@ -1244,13 +1245,22 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     e.fd = 1;
     e.fd_coef = tab.d6_vt;
     e.fd_add = (const Real *)g.f0;
+    // Round 5: on these levels the damping heat is the epilogue of the march (fv3_tp2x.hip, HEAT): the pre-damping winds and the two damping
+    // increments are not stored and the damping-heat kernel below only serves the levels under fdw_k0.  FV3_DSW_HEAT=separate: the round-4
+    // sequence (A/B; read per call).
+    const char *he = getenv("FV3_DSW_HEAT");
+    const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source};
+    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && tp2d_fd_lean(cf.hord_vt) && fdw_k0 <= nz1) {
+      e.heat = &th;
+      heat_k1 = fdw_k0 - 1;
+    }
     tp2d(c, s, wk, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, fdw_k0, nz1, &e);
     if (sv != s) fv3_wait(c, s, 3);
   }
 
   const bool heat_on = cf.d_con > 1.0e-5;
   // (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  if (heat_k1 >= 0) launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (heat_k1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j), pne = IX(i + 1, j + 1);
     const Real rdx0 = (g.rdx + m2)[p], rdx1 = (g.rdx + m2)[pn], rdy0 = (g.rdy + m2)[p], rdy1 = (g.rdy + m2)[pe_];
@@ -1258,7 +1268,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
 #pragma unroll 1
     for (int kk = 0; kk < FV3_KC; ++kk) {
       const int k = FV3_KC * kp + kk;
-      if (k > nz1) break;
+      if (k > heat_k1) break;
       const long b = t * g.st + k * g.sk;
       Real hs = (heat_s + b)[p];
       const Real dcon = g.d_con[k];

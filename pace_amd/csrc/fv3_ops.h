@@ -90,6 +90,8 @@ struct TpEpi {
   int fd = 0;
   const Real *fd_coef = nullptr;
   const Real *fd_add = nullptr;
+  // wind form, fd != 0, round-5 march only: the damping heat formed in the march (TpHeat, below); ignored by the other forms
+  const struct TpHeat *heat = nullptr;
 };
 
 // fv_tp_2d on levels k0..k1.  mfx/mfy/mass may be null; dn may be null (no damping).
@@ -136,8 +138,15 @@ FV3_HD inline bool tp2d_old_tile(int fl, int i0, int ja, int r_end, int nx, int 
 bool tp2d_fd_lean(int hord);  // (fv3_tp2d.hip) will tp2d's FD forms run the round-5 march?  (then only the corner patches of the chain's fluxes are needed)
 // kind 1: d_sw's vorticity transport + wind update, 2: update_dz_d's interface-height transport (TpEpi as for tp2d with fd = 1); PPM order 6
 struct TpEpi;
+// d_sw's damping heat as the epilogue of the vorticity march (kind 1): heat_src += ndelp * (heat_s - 0.25 d_con rsin2 (...)) on the levels with d_con > 1e-5,
+// heat_src += heat_s on the others; vdamp = the corner damping field.  Null: the winds before the damping and the increments are stored for the
+// damping-heat kernel instead (TpEpi::wind_u_pre ...).
+struct TpHeat {
+  const Real *vdamp, *ndelp, *heat_s, *dcon;
+  Real *heat_src;
+};
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
-                       const TpEpi *epi);
+                       const TpEpi *epi, const TpHeat *heat = nullptr);
 // the round-5 two-tracer march on the tiles without a cube corner (fv3_tp4x.hip); role 1 = delp + w, 2 = q_con + pt; levels k_lo .. k_hi must
 // all run their del-n chains inside the march (>= fd_k0), PPM order 6
 void dsw_pair_march(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int role, int k_lo, int k_hi);

@@ -1248,7 +1248,7 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
     if (m == (TF_WIND | TF_FD)) {
       if (!fa_off && epi->wind_du && epi->wind_u_pre && epi->wind_v_pre) {
         if (sx_on && epi->fd_add)
-          tp2d_single_march(c, s, 1, q, crx, cry, xfx, yfx, k0, k1, epi);
+          tp2d_single_march(c, s, 1, q, crx, cry, xfx, yfx, k0, k1, epi, epi->heat);
         else
           tp2d_stream_t<(TF_WIND | TF_FD), 6, true>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord, dn, k0, k1, epi);
       } else

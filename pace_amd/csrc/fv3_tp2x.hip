@@ -32,15 +32,26 @@ struct SxArgs {
   // SX_WIND
   Real *u, *v, *u_pre, *v_pre, *du, *dv;
   const Real *ke, *add;  // add: 2-D term added to q where the transport loads it (f0)
+  // SX_WIND with the damping-heat epilogue (HEAT): the corner damping field, the new air mass, the heat of w's damping (AIR march), the accumulated
+  // heat source (read + written), the per-level fraction d_con
+  const Real *vdamp, *ndelp, *heat_s, *dcon;
+  Real *heat_src;
+  // HEAT: copies (made before the march) of the u rows / v columns on the boundaries between segments / strips -- see sx_side_copy
+  const Real *u_side, *v_side;
   // SX_AREA
   Real *out;
   // the staged chain's damping fluxes on the cube-corner patches (read where the chain of the march does not reach: corner-halo remaps)
   const Real *pfx, *pfy;
 };
 
-template <int KIND>
+// HEAT (SX_WIND): d_sw's damping heat as the epilogue of the cell (i, r-3) -- the pre-damping winds and the damping increments of the
+// cell's four faces are in the wave (this step's and the previous step's u face, the lane's and the next lane's v face), so the four fields the
+// round-4 sequence stored for the damping-heat kernel and read back there (u_pre, v_pre, the two increments) never exist.  Expressions and order:
+// the damping-heat kernel's (fv3_dsw.hip, the last launch of fv3_d_sw_out).
+template <int KIND, bool HEAT = false>
 void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k_hi) {
   constexpr bool WIND = KIND == SX_WIND, AREA = KIND == SX_AREA;
+  static_assert(!HEAT || WIND, "the damping heat is the epilogue of the wind form");
   const Geo g = c->g;
   const int nk = k_hi - k_lo + 1;
   if (nk <= 0) return;
@@ -55,7 +66,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const unsigned char *gflags = c->g_dev->flags;
   const Geo *gp = c->g_dev;
-  const MPtr garea = g.area, grarea = g.rarea, gd6v = g.del6_v, gd6u = g.del6_u, gdya = g.dya, gdx = g.dx, gdy = g.dy, gdxa = g.dxa;
+  const MPtr garea = g.area, grarea = g.rarea, gd6v = g.del6_v, gd6u = g.del6_u, gdya = g.dya, gdx = g.dx, gdy = g.dy, gdxa = g.dxa, grdx = g.rdx, grdy = g.rdy, grs2 = g.rsin2, gcs = g.cosa_s;
   const SxArgs A = a;
   constexpr int NRING = 8;
   enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6, RG_MX = 7 };
@@ -107,6 +118,12 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     Real *const ub = WIND ? A.u + b : nullptr, *const vb = WIND ? A.v + b : nullptr, *const upb = WIND ? A.u_pre + b : nullptr, *const vpb = WIND ? A.v_pre + b : nullptr;
     Real *const dub = WIND ? A.du + b : nullptr, *const dvb = WIND ? A.dv + b : nullptr;
     Real *const outb = AREA ? A.out + b : nullptr;
+    const Real *const vdb = HEAT ? A.vdamp + b : nullptr, *const ndpb = HEAT ? A.ndelp + b : nullptr, *const hsb = HEAT ? A.heat_s + b : nullptr;
+    Real *const hob = HEAT ? A.heat_src + b : nullptr;
+    const Real *const rdxb = (const Real *)grdx + m2, *const rdyb = (const Real *)grdy + m2, *const rs2b = (const Real *)grs2 + m2, *const csb = (const Real *)gcs + m2;
+    const Real dcon = HEAT ? A.dcon[k] : (Real)0;
+    const Real *const usideb = HEAT ? A.u_side + b : nullptr, *const vsideb = HEAT ? A.v_side + b : nullptr;
+    const bool side_row = HEAT && by != nseg - 1, side_col = HEAT && bx != nstrip - 1;
     const Real dcoef = A.coef[k];
     const unsigned rowB = (unsigned)sj32 * (unsigned)sizeof(Real);
     Real *const ring = (Real *)smem_;
@@ -123,8 +140,13 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     Met MN[3][FV3_LPT];
     // WIND: the winds / kinetic energy / grid spacings the epilogue of a step needs, requested one step ahead
     Real Ou[3][FV3_LPT], Odx[3][FV3_LPT], Okf[3][FV3_LPT], Ov[3][FV3_LPT], Ody[3][FV3_LPT];
+    // HEAT: corner damping field / 1/dx of face row r-2; 1/dy, 1/sin^2, cos, new air mass, w's damping heat, accumulated heat of cell row r-3
+    Real Hvd[3][FV3_LPT], Hrx[3][FV3_LPT], Hry[3][FV3_LPT], Hrs[3][FV3_LPT], Hcs[3][FV3_LPT], Hdp[3][FV3_LPT], Hhs[3][FV3_LPT], Hho[3][FV3_LPT];
+    Real vdp[FV3_LPT], ubp[FV3_LPT], fyq[FV3_LPT];  // ... the damping field of row r-3, ub / fy of the u face r-3 (the previous step's)
+    Real s_vb[FV3_LPT], s_fx[FV3_LPT];              // ... vb / fx of the lane's v face (row r-3): read by lane - 1
     unsigned pcolB[FV3_LPT];
     bool own_x[FV3_LPT], own_y[FV3_LPT];
+    const Real *vsrc[FV3_LPT];  // HEAT: where the lane reads v (the side copy for the column the next strip owns)
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], al_q[FV3_LPT], v2[FV3_LPT], v3[FV3_LPT], v4[FV3_LPT], al_v[FV3_LPT];
     PpmCell cq[FV3_LPT], cv[FV3_LPT];
     Real p_prev[FV3_LPT], y_prev[FV3_LPT], fyin[FV3_LPT], px[FV3_LPT], fxk[FV3_LPT], fyp[FV3_LPT], sqx[FV3_LPT], sqi[FV3_LPT], sxv[FV3_LPT];
@@ -154,11 +176,30 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         constexpr bool GEN = decltype(gen_tag)::value;
         const int r3 = GEN ? (r - 3 < jsd ? jsd : r - 3) : r - 3, rf = GEN ? (r - 2 < jsd ? jsd : r - 2) : r - 2;
         const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
-        Ou[q][l] = px_ld(ub, pf);
+        // HEAT: the cell epilogue also uses the winds of two faces the wave does not own -- the u row of the next segment's first face, the v column
+        // of the next strip's first face.  Their owners update them IN PLACE at a time of their own, so these two are read from copies made
+        // before the march (sx_side_copy); without the epilogue the values computed on faces a wave does not own are discarded.
+        if (HEAT && GEN && side_row && rf == jb + 1)
+          Ou[q][l] = px_ld(usideb, pf);
+        else
+          Ou[q][l] = px_ld(ub, pf);
         Odx[q][l] = px_ld(dxb, pf);
         Okf[q][l] = px_ld(keb, pf);
-        Ov[q][l] = px_ld(vb, p3);
+        if constexpr (HEAT)
+          Ov[q][l] = *fv3_at(vsrc[l], p3);
+        else
+          Ov[q][l] = px_ld(vb, p3);
         Ody[q][l] = px_ld(dyb, p3);
+        if constexpr (HEAT) {
+          Hvd[q][l] = px_ld(vdb, pf);
+          Hrx[q][l] = px_ld(rdxb, pf);
+          Hry[q][l] = px_ld(rdyb, p3);
+          Hrs[q][l] = px_ld(rs2b, p3);
+          Hcs[q][l] = px_ld(csb, p3);
+          Hdp[q][l] = px_ld(ndpb, p3);
+          Hhs[q][l] = px_ld(hsb, p3);
+          Hho[q][l] = px_ld(hob, p3);
+        }
       }
     };
     auto load_met = [&](int r, int l) -> Met {
@@ -179,6 +220,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       pcolB[l] = (unsigned)(go * sj32 + go + ic) * (unsigned)sizeof(Real);
       own_x[l] = i >= i0 && i < i0 + SX_OUT && i <= nx + 1;
       own_y[l] = i >= i0 && i < i0 + SX_OUT && i <= nx;
+      vsrc[l] = (side_col && i == i0 + SX_OUT) ? vsideb : (const Real *)vb;
       akind[l] = 0;
       if (Wst && i >= 0 && i <= 2) akind[l] = 1 + i;
       if (Est && i >= nx && i <= nx + 2) akind[l] = 1 + (i - nx);
@@ -194,7 +236,11 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       }
       for (int v = 0; v < NRING; ++v)
         for (int q = 0; q < 3; ++q) RG(v, q)[lane] = (v == RG_AR || v == RG_MX) ? (Real)1 : (Real)0;  // (warm-up steps: outputs masked, keep the divisions finite)
-      for (int q = 0; q < 3; ++q) Ou[q][l] = Odx[q][l] = Okf[q][l] = Ov[q][l] = Ody[q][l] = (Real)0;
+      for (int q = 0; q < 3; ++q) {
+        Ou[q][l] = Odx[q][l] = Okf[q][l] = Ov[q][l] = Ody[q][l] = (Real)0;
+        Hvd[q][l] = Hrx[q][l] = Hry[q][l] = Hrs[q][l] = Hcs[q][l] = Hdp[q][l] = Hhs[q][l] = Hho[q][l] = (Real)0;
+      }
+      vdp[l] = ubp[l] = fyq[l] = s_vb[l] = s_fx[l] = (Real)0;
       MN[0][l] = load_met(r0, l);
       load_opt(0, r0, l, std::true_type{});
       R[0][l] = load_row(r0, l, std::true_type{});
@@ -225,6 +271,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         const Row cu = R[Q][l];
         Real sum = ((cu.qy + cu.cx) + (cu.xv + cu.ar)) + ((cu.cy + cu.yv) + (mc_.du + mc_.dv)) + (mc_.ra + mc_.qa);
         if constexpr (WIND) sum = sum + ((Ou[Q][l] + Odx[Q][l]) + (Okf[Q][l] + Ov[Q][l]) + Ody[Q][l]);
+        if constexpr (HEAT) sum = sum + ((Hvd[Q][l] + Hrx[Q][l]) + (Hry[Q][l] + Hrs[Q][l]) + (Hcs[Q][l] + Hdp[Q][l]) + (Hhs[Q][l] + Hho[Q][l]));
         {
           const int r1 = GEN ? (r + 1 < r_end ? r + 1 : r_end) : r + 1, rn = GEN ? (r + 2 < r_end ? r + 2 : r_end) : r + 2;
           load_opt(Q1, r1, l, gen_tag);
@@ -234,15 +281,22 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         if constexpr (WIND) {
           if (fx_row && own_x[l]) {
             const unsigned p = pcolB[l] + (unsigned)jr * rowB;
-            FV3_MARCH_ST(*fv3_at(dvb, p), sum);
-            FV3_MARCH_ST(*fv3_at(vpb, p), sum);
+            if constexpr (!HEAT) {
+              FV3_MARCH_ST(*fv3_at(dvb, p), sum);
+              FV3_MARCH_ST(*fv3_at(vpb, p), sum);
+            }
             FV3_MARCH_ST(*fv3_at(vb, p), sum);
           }
           if (fy_row && own_y[l]) {
             const unsigned p = pcolB[l] + (unsigned)jf * rowB;
-            FV3_MARCH_ST(*fv3_at(dub, p), sum);
-            FV3_MARCH_ST(*fv3_at(upb, p), sum);
+            if constexpr (!HEAT) {
+              FV3_MARCH_ST(*fv3_at(dub, p), sum);
+              FV3_MARCH_ST(*fv3_at(upb, p), sum);
+            }
             FV3_MARCH_ST(*fv3_at(ub, p), sum);
+          }
+          if constexpr (HEAT) {
+            if (fx_row && own_y[l]) FV3_MARCH_ST(*fv3_at(hob, pcolB[l] + (unsigned)jr * rowB), sum);
           }
         } else {
           if (fx_row && own_y[l]) FV3_MARCH_ST(*fv3_at(outb, pcolB[l] + (unsigned)jr * rowB), sum);
@@ -256,6 +310,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         {
 #if PX_ABL == 2
           PX_KEEP(Ou[Q1][l]); PX_KEEP(Odx[Q1][l]); PX_KEEP(Okf[Q1][l]); PX_KEEP(Ov[Q1][l]); PX_KEEP(Ody[Q1][l]);
+          PX_KEEP(Hvd[Q1][l]); PX_KEEP(Hrx[Q1][l]); PX_KEEP(Hry[Q1][l]); PX_KEEP(Hrs[Q1][l]); PX_KEEP(Hcs[Q1][l]); PX_KEEP(Hdp[Q1][l]); PX_KEEP(Hhs[Q1][l]); PX_KEEP(Hho[Q1][l]);
           PX_KEEP(MN[Q1][l].du); PX_KEEP(MN[Q1][l].dv); PX_KEEP(MN[Q1][l].ra); PX_KEEP(MN[Q1][l].qa);
           PX_KEEP(R[Q2][l].qy); PX_KEEP(R[Q2][l].cx); PX_KEEP(R[Q2][l].xv); PX_KEEP(R[Q2][l].ar); PX_KEEP(R[Q2][l].cy); PX_KEEP(R[Q2][l].yv);
 #else
@@ -383,7 +438,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
           zxo[l] = ox;
           h_zy0[l] = zyp[l];
         }
-        if constexpr (WIND) {  // the vorticity-damping increments of v (row r-3) / u (face r-2); the damping-heat kernel reads them again: stored
+        if constexpr (WIND && !HEAT) {  // the vorticity-damping increments of v (row r-3) / u (face r-2); the damping-heat kernel reads them again: stored
           if (fx_row && own_x[l]) FV3_MARCH_ST(*fv3_at(dvb, pcolB[l] + (unsigned)jr * rowB), ox);
           if (fy_row && own_y[l]) FV3_MARCH_ST(*fv3_at(dub, pcolB[l] + (unsigned)jf * rowB), oy);
         }
@@ -402,8 +457,13 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
           const Real vn = Ov[Q][l] * Ody[Q][l] + wkr[l] - Okf[Q][l] - v;
           if (fx_row && own_x[l]) {
             const unsigned p = pcolB[l] + (unsigned)jr * rowB;
-            FV3_MARCH_ST(*fv3_at(vpb, p), vn);
+            if constexpr (!HEAT) FV3_MARCH_ST(*fv3_at(vpb, p), vn);
             FV3_MARCH_ST(*fv3_at(vb, p), vn - ox);
+          }
+          if constexpr (HEAT) {  // vb / fx of the v face (i, r-3): damping field of corner rows r-3 (previous step's) and r-2
+            const Real rdy0 = Hry[Q][l];
+            s_vb[l] = (vdp[l] - Hvd[Q][l] - ox) * rdy0;
+            s_fx[l] = vn * rdy0;
           }
         } else {
           fxk[l] = v;
@@ -446,10 +506,28 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
           const Real un = Ou[Q][l] * Odx[Q][l] + Okf[Q][l] - ke_e + v;
           if (fy_row && own_y[l]) {
             const unsigned p = pcolB[l] + (unsigned)jf * rowB;
-            FV3_MARCH_ST(*fv3_at(upb, p), un);
+            if constexpr (!HEAT) FV3_MARCH_ST(*fv3_at(upb, p), un);
             FV3_MARCH_ST(*fv3_at(ub, p), un + h_oy[l]);
           }
           wkr[l] = Okf[Q][l];  // ke(i, jr) of the next step = this step's ke(i, jf)
+          if constexpr (HEAT) {
+            // the cell (i, r-3): u faces r-3 (ub0 / fy0: the previous step's) and r-2, v faces i (the lane's) and i + 1 (the next lane's)
+            const Real vd01 = Hvd[Q][l], vd11 = FV3_LANE_SHL(1, Hvd[Q], l, lane), rdx1 = Hrx[Q][l];
+            const Real ub1 = (vd01 - vd11 + h_oy[l]) * rdx1, fy1 = un * rdx1;
+            const Real ub0 = ubp[l], fy0 = fyq[l];
+            const Real vb0 = s_vb[l], vb1 = FV3_LANE_SHL(1, s_vb, l, lane), fx0 = s_fx[l], fx1 = FV3_LANE_SHL(1, s_fx, l, lane);
+            Real hs = Hhs[Q][l];
+            if (dcon > (Real)1.0e-5) {
+              const Real gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0_ = fx0 * vb0, gx1_ = fx1 * vb1;
+              const Real u2 = fy0 + fy1, du2 = ub0 + ub1, v2_ = fx0 + fx1, dv2 = vb0 + vb1;
+              hs = Hdp[Q][l] * (hs - (Real)0.25 * dcon * Hrs[Q][l] *
+                                         ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0_ + gx1_) - Hcs[Q][l] * (u2 * dv2 + v2_ * du2 + du2 * dv2)));
+            }
+            if (fx_row && own_y[l]) FV3_MARCH_ST(*fv3_at(hob, pcolB[l] + (unsigned)jr * rowB), Hho[Q][l] + hs);
+            ubp[l] = ub1;
+            fyq[l] = fy1;
+            vdp[l] = px_move(vd01);
+          }
         } else {
           const Real fxe = FV3_LANE_SHL(1, fxk, l, lane), xje = FV3_LANE_SHL(1, xjr, l, lane), zx1 = FV3_LANE_SHL(1, zxo, l, lane);
           const Real qc = w2[l];  // q(i, r-3)
@@ -497,12 +575,31 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
   });
 }
 
+// The winds on the faces between segments / strips, copied before the HEAT march updates the winds in place: u on the first face row of every
+// segment but the first, v on the first face column of every strip but the first (the geometry of single_march_t's launch).
+void sx_side_copy(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, Real *u_side, Real *v_side, int k_lo, int k_hi) {
+  const Geo g = c->g;
+  const int nk = k_hi - k_lo + 1;
+  if (nk <= 0) return;
+  const int nstrip = (g.nx + 1 + SX_OUT - 1) / SX_OUT;
+  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
+  const int nseg = (g.ny + seg - 1) / seg;
+  launch3(c, s, Box{1, g.nx, 1, nseg - 1, k_lo, k_hi}, [=] FV3_HD(int t, int k, int i, int js) {
+    const long p = t * g.st + k * g.sk + IX(i, 1 + js * seg);
+    u_side[p] = u[p];
+  });
+  launch3(c, s, Box{1, g.ny, 1, nstrip - 1, k_lo, k_hi}, [=] FV3_HD(int t, int k, int j, int bs) {
+    const long p = t * g.st + k * g.sk + IX(1 + bs * SX_OUT, j);
+    v_side[p] = v[p];
+  });
+}
+
 }  // namespace
 
 // kind 1: the vorticity transport of d_sw with the wind update (epi: wind_u / wind_v / wind_ke / wind_du / wind_dv / wind_u_pre / wind_v_pre, fd_coef,
 // fd_add); kind 2: the interface-height transport of update_dz_d (epi: out, fd_coef).  Levels k0 .. k1 all run their del-n chain inside the march.
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
-                       const TpEpi *epi) {
+                       const TpEpi *epi, const TpHeat *heat) {
   SxArgs a;
   memset(&a, 0, sizeof(a));
   a.q = q;
@@ -522,7 +619,19 @@ void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, cons
     a.add = epi->fd_add;
     a.pfx = epi->wind_dv;
     a.pfy = epi->wind_du;
-    single_march_t<SX_WIND>(c, s, a, k0, k1);
+    if (heat && heat->vdamp) {
+      a.vdamp = heat->vdamp;
+      a.ndelp = heat->ndelp;
+      a.heat_s = heat->heat_s;
+      a.heat_src = heat->heat_src;
+      a.dcon = heat->dcon;
+      a.u_side = epi->wind_u_pre;  // (the arrays the epilogue makes redundant serve as the side copies)
+      a.v_side = epi->wind_v_pre;
+      sx_side_copy(c, s, epi->wind_u, epi->wind_v, epi->wind_u_pre, epi->wind_v_pre, k0, k1);
+      single_march_t<SX_WIND, true>(c, s, a, k0, k1);
+    } else {
+      single_march_t<SX_WIND>(c, s, a, k0, k1);
+    }
   } else {
     a.out = epi->out;
     a.pfx = epi->zfx;

@@ -445,6 +445,25 @@ def test_single_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layou
             assert np.array_equal(res["new"][r][name], res["old"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (200, (1, 1), "32")])
+def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend, monkeypatch, n, layout, seg):
+    """d_sw's damping heat formed as the epilogue of the vorticity march (fv3_tp2x.hip HEAT: the pre-damping winds and the damping increments
+    never stored) against the round-4 sequence (the march stores them, the damping-heat kernel reads them back; FV3_DSW_HEAT=separate): the
+    heat enters pt through the diffusive heating at the end of the call -- every field bitwise equal."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("fused", "separate"):
+        monkeypatch.setenv("FV3_DSW_HEAT", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
 def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
     """update_dz_d: the del-n chain of the interface heights run inside the transport march (tp2d_stream_t TF_FD, strips away from
