@@ -31,8 +31,17 @@ class StencilFactory:
         device: Optional[str] = None,
         dtype=torch.float64,
         stream: Optional[int] = None,
+        _testing_token=None,
     ):
         config.validate()
+        from . import _testing
+
+        if backend == "hostemu":
+            # (the host emulation is test infrastructure: pace_amd._testing.hostemu_factory)
+            if _testing_token is not _testing._TOKEN:
+                raise ValueError("backend 'hostemu' is not part of the product surface: this package runs on 'hip:gfx950' only (tests: pace_amd._testing)")
+        elif backend not in ("hip:gfx950", "hip"):
+            raise ValueError(f"backend {backend!r}: this build provides 'hip:gfx950'")
         self.backend = backend
         self.hostemu = backend == "hostemu"
         self.config = config

@@ -8,8 +8,10 @@
 // access: measured 40 % slower), so the access is written by hand: a computed branch (`s_getpc` + level x 20 bytes,
 // `s_setpc`) into a table of 80 cases, each `v_accvgpr_write a[2k], lo; v_accvgpr_write a[2k+1], hi; s_branch end` (8 + 8 + 4 bytes).
 // The level is wave-uniform.  The compiler does not know that the values live there: it must not use accumulation registers itself in
-// these kernels -- it does so only when it runs out of architectural registers, and tests/test_kernel_budgets.py pins both counts
-// (architectural <= 256 with no spill, accumulation = exactly the 160 claimed here).
+// these kernels -- it does so only when it runs out of architectural registers.  Guards (tests/test_kernel_budgets.py): the kernels must stay
+// well below the architectural limit (<= 240 of 256, no spill) with exactly the 160 accumulation registers claimed here, and the disassembly
+// of the built library must not name an accumulation register anywhere outside the jump tables of this file; every access statement, reads
+// included, lists a0 .. a159 as clobbered.
 #pragma once
 #include "fv3_common.h"
 
@@ -53,7 +55,10 @@ __device__ __attribute__((always_inline)) inline void fv3_agpr_set(int k, double
 __device__ __attribute__((always_inline)) inline double fv3_agpr_get(int k) {
   int lo, hi;
   const int t = k * 20 + 12;
-  asm volatile(FV3_AG_JUMP FV3_AG_CASES(FV3_AG_R) ".LFV3AG%=:\n" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [t] "s"(t) : "vcc", "scc");
+  // (the clobber list on a READ: it tells the compiler that no value of its own survives in a0 .. a159 across this statement either, so that the
+  //  only live ranges it could ever place there are those between two consecutive accesses -- and tests/test_kernel_budgets.py checks in the
+  //  disassembly that it places none: no instruction outside these tables names an accumulation register)
+  asm volatile(FV3_AG_JUMP FV3_AG_CASES(FV3_AG_R) ".LFV3AG%=:\n" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [t] "s"(t) : "vcc", "scc", FV3_AG_CLOBBERS);
   return __hiloint2double(hi, lo);
 }
 
@@ -116,7 +121,7 @@ __device__ __attribute__((always_inline)) inline void fv3_agpr_set(int k, float 
 __device__ __attribute__((always_inline)) inline float fv3_agpr_get_f32(int k) {
   int lo;
   const int t = k * 12 + 12;
-  asm volatile(FV3_AG_JUMP FV3_AG_CASES1(FV3_AG_R1) ".LFV3AG%=:\n" : [lo] "=&v"(lo) : [t] "s"(t) : "vcc", "scc");
+  asm volatile(FV3_AG_JUMP FV3_AG_CASES1(FV3_AG_R1) ".LFV3AG%=:\n" : [lo] "=&v"(lo) : [t] "s"(t) : "vcc", "scc", FV3_AG_CLOBBERS1);
   return __int_as_float(lo);
 }
 

@@ -37,7 +37,7 @@ namespace {
 #define PX_ORD 6
 enum { PX_AIR = 1, PX_TRC = 2 };
 #ifndef PX_WPE
-#define PX_WPE (sizeof(Real) == 4 ? 4 : 2)
+#define PX_WPE (sizeof(Real) == 4 ? 3 : 2)  // (fp32: 168 registers)
 #endif
 
 template <int ROLE>

@@ -64,6 +64,7 @@ class DycoreHarness:
         ak=None,
         bk=None,
         loopback: bool = False,
+        _testing_token=None,
     ):
         self.c = get_constants()
         self.part = CubedSpherePartitioner(nx_tile, tuple(layout))
@@ -76,7 +77,7 @@ class DycoreHarness:
         self.grids = [make_grid(self.part, r, nz=nz, ak=ak, bk=bk) for r in self.layout.local_ranks]
         if verbose:
             print(f"[harness] grid for ranks {self.layout.local_ranks} in {time.time() - t0:.1f}s", flush=True)
-        self.sf = StencilFactory(self.grids, self.cfg, self.c, backend=backend, device=device, dtype=dtype)
+        self.sf = StencilFactory(self.grids, self.cfg, self.c, backend=backend, device=device, dtype=dtype, _testing_token=_testing_token)
         self.state = DycoreState(self.sf.quantity_factory)
         t0 = time.time()
         on_device = not self.sf.hostemu

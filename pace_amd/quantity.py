@@ -179,8 +179,8 @@ class Quantity:
 
 class QuantityFactory:
     """``QuantityFactory.from_backend(sizer, backend)`` [REF driver/pace/driver/driver.py:183,758].
-    The backend string of this build is ``"hip:gfx950"``; ``"hostemu"`` keeps storage on the CPU
-    for the test-only host-emulation library."""
+    The backend string of this build is ``"hip:gfx950"`` (the CPU storage of the test-only host emulation:
+    ``pace_amd._testing.hostemu_quantity_factory``)."""
 
     def __init__(self, sizer: GridSizer, device="cuda:0", dtype=torch.float64):
         self.sizer = sizer
@@ -189,10 +189,8 @@ class QuantityFactory:
 
     @classmethod
     def from_backend(cls, sizer: GridSizer, backend: str = "hip:gfx950", dtype=torch.float64, device=None):
-        if backend == "hostemu":
-            return cls(sizer, "cpu", dtype)
         if backend not in ("hip:gfx950", "hip"):
-            raise ValueError(f"backend {backend!r}: this build provides 'hip:gfx950' (product) and 'hostemu' (tests)")
+            raise ValueError(f"backend {backend!r}: this build provides 'hip:gfx950'")
         return cls(sizer, device or "cuda:0", dtype)
 
     def _alloc(self, dims, fill=None):

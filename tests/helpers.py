@@ -13,6 +13,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 from pace_amd.config import AcousticDynamicsConfig  # noqa: E402
 from pace_amd.constants import get_constants  # noqa: E402
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory  # noqa: E402
 from pace_amd.grid import make_grid  # noqa: E402
 from pace_amd.init import synthetic_state  # noqa: E402
@@ -36,7 +37,7 @@ class Case:
         self.nz = nz
         self.grids = [make_grid(self.part, r, nz=nz) for r in self.ranks]
         self.doms = [Dom(g, self.c) for g in self.grids]
-        self.sf = StencilFactory(self.grids, self.cfg, self.c, backend=backend, dtype=dtype)
+        self.sf = stencil_factory_for(backend)(self.grids, self.cfg, self.c, dtype=dtype)
         self.qf = self.sf.quantity_factory
         self.states = [synthetic_state(g, seed=seed, rank=r) for g, r in zip(self.grids, self.ranks)]
         self.shape = self.states[0]["u"].shape
@@ -104,7 +105,7 @@ def run_device_cube(backend, part, cfg, grids, ost_init, phis, timestep, n_calls
     from pace_amd.dyn_core import AcousticDynamics, DycoreState
     from pace_amd.halo import Layout
 
-    sf = StencilFactory(grids, cfg, get_constants(), backend=backend, dtype=dtype)
+    sf = stencil_factory_for(backend)(grids, cfg, get_constants(), dtype=dtype)
     per_rank = [dict(s, phis=p) for s, p in zip(ost_init, phis)]
     st = DycoreState.from_arrays(sf.quantity_factory, per_rank)
     dyn = AcousticDynamics(Layout(part, 1, 0), grids, sf, config=cfg, phis=st.phis, state=st)

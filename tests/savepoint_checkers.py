@@ -14,6 +14,7 @@ import numpy as np
 
 from pace_amd.config import AcousticDynamicsConfig
 from pace_amd.constants import get_constants
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory
 from pace_amd.grid import make_grid
 from pace_amd.halo import Layout
@@ -112,7 +113,7 @@ def check_tracer_2d_1l_savepoints(path, backend, nx=12, call=0):
     nz = inp[0]["dp1"].shape[2] - 1  # (the reference's storages are padded to the interface shape)
     part, grids = _grids(path, ranks, nx, nz)
     cfg = _cfg(path, nx, nz)
-    sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+    sf = stencil_factory_for(backend)(grids, cfg, get_constants())
     qf = sf.quantity_factory
     nzp = nz + 1
     Q = {n: qf.from_array([_pad3(x[n], nzp) for x in inp], ("x", "y", "z")) for n in ("dp1", "mfxd", "mfyd", "cxd", "cyd")}
@@ -151,7 +152,7 @@ def check_remapping_savepoints(path, backend, nx=12, call=0):
     nz = inp[0]["delp"].shape[2] - 1
     part, grids = _grids(path, ranks, nx, nz)
     cfg = _cfg(path, nx, nz)
-    sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+    sf = stencil_factory_for(backend)(grids, cfg, get_constants())
     qf = sf.quantity_factory
     nzp = nz + 1
     names = ("pt", "delp", "delz", "peln", "pe", "pk", "pkz", "u", "v", "w", "cappa")
@@ -183,6 +184,7 @@ def check_fv_dynamics_savepoints(path, backend, nx=12):
     FVDynamics-Out, all six ranks (the step needs its neighbours).  The generator stores the WHOLE prognostic state beside the
     nine variables the reference checkpoints (``state_*`` arrays), the tracers as ``tracer_*``."""
     from pace_amd.dyn_core import STATE_NAMES
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
     ranks = ranks_present(path, "FVDynamics-In")
@@ -195,7 +197,7 @@ def check_fv_dynamics_savepoints(path, backend, nx=12):
     tnames = sorted(k for k in inp[0] if k.startswith("tracer_"))
     over = {k: m[k] for k in ("hord_dp", "hord_mt", "hord_tm", "hord_vt", "nord", "d4_bg", "d2_bg", "d2_bg_k1", "d2_bg_k2", "d_con", "dddmp", "vtdm4", "ke_bg", "p_fac", "rf_fast",
                               "rf_cutoff", "tau", "delt_max", "do_vort_damp", "n_sponge") if k in m}
-    h = DycoreHarness(nx, nz=nz, layout=(1, 1), dt_atmos=float(m.get("dt_atmos", 225.0)), k_split=int(m.get("k_split", 1)), n_split=int(m.get("n_split", 1)), backend=backend,
+    h = harness_for(backend)(nx, nz=nz, layout=(1, 1), dt_atmos=float(m.get("dt_atmos", 225.0)), k_split=int(m.get("k_split", 1)), n_split=int(m.get("n_split", 1)),
                       config_overrides=over, n_tracers=len(tnames), hord_tr=int(m.get("hord_tr", 8)), remap=True)
     nzp = nz + 1
     for i in ranks:

@@ -137,12 +137,12 @@ def test_context_memory_goes_with_the_last_reference(hostemu):
     import gc
     import weakref
 
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
     gc.collect()
     gc.disable()
     try:
-        h = DycoreHarness(12, nz=8, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=2, backend="hostemu")
+        h = hostemu_harness(12, nz=8, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=2)
         h.dyn(h.state, 225.0, n_map=1)
         r = weakref.ref(h.sf)
         del h

@@ -92,9 +92,10 @@ def test_c768_l79_fp64_full_size_one_call(gpu_backend):
 
 
 def _conservation_and_tile0_spot_check(backend, nx_tile, nz, layout=(1, 1), dt_atmos=200.0, native_first=False):
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(nx_tile, nz=nz, layout=layout, dt_atmos=dt_atmos, k_split=1, n_split=2, backend=backend)
+    h = harness_for(backend)(nx_tile, nz=nz, layout=layout, dt_atmos=dt_atmos, k_split=1, n_split=2)
     nx = nx_tile // layout[0]
     area = h.sf.grid_fields["area"].storage  # [n_sub, nj, ni]
     nh = 3

@@ -16,12 +16,12 @@ def _worker(rank, world, init_file, out_dir, nx_tile, layout, nz, native):
     os.environ["FV3_HALO_NATIVE"] = native
     import torch.distributed as dist
 
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
     torch.set_num_threads(1)
     os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
-    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=2, n_split=2, world_size=world, proc=rank, backend="hostemu", group=None)
+    h = hostemu_harness(nx_tile, nz, layout, dt_atmos=225.0, k_split=2, n_split=2, world_size=world, proc=rank, group=None)
     h.step()
     out = h.state.to_arrays(["delp", "pt", "u", "v", "w", "delz"])
     np.savez(os.path.join(out_dir, f"proc{rank}.npz"), **{f"{n}_{i}": a[n] for i, a in enumerate(out) for n in a})
@@ -38,9 +38,9 @@ def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, lay
     nz = 5
     monkeypatch.setenv("FV3_HALO_NATIVE", native)
     sys.path.insert(0, ROOT)
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
-    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=2, n_split=2, world_size=1, proc=0, backend="hostemu")
+    h = hostemu_harness(nx_tile, nz, layout, dt_atmos=225.0, k_split=2, n_split=2, world_size=1, proc=0)
     h.step()
     ref = h.state.to_arrays(["delp", "pt", "u", "v", "w", "delz"])
     init_file = str(tmp_path / "init")
@@ -74,12 +74,12 @@ def _tracer_worker(rank, world, init_file, out_dir, nx_tile, layout, nz, scale):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
     torch.set_num_threads(1)
     os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
-    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=world, proc=rank, backend="hostemu", group=None, n_tracers=2, hord_tr=8)
+    h = hostemu_harness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=world, proc=rank, group=None, n_tracers=2, hord_tr=8)
     _tracer_run(h, scale)
     assert h.tracer_advection.n_split >= 2, h.tracer_advection.n_split
     # the acoustic dynamics and the tracer advection share the context's one exchanger (a second one would re-initialise the transport)
@@ -95,9 +95,9 @@ def test_two_process_tracer_advection_with_sub_cycles_matches_single_process(hos
     exchanger -- and the same host transport -- as the acoustic plans."""
     nx_tile, layout, nz = 12, (2, 2), 4
     sys.path.insert(0, ROOT)
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
-    h = DycoreHarness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=1, proc=0, backend="hostemu", n_tracers=2, hord_tr=8)
+    h = hostemu_harness(nx_tile, nz, layout, dt_atmos=225.0, k_split=1, n_split=2, world_size=1, proc=0, n_tracers=2, hord_tr=8)
     scale = _tracer_run(h, None)
     assert h.tracer_advection.n_split >= 2
     ref = {n: [q.numpy(i) for i in range(len(h.grids))] for n, q in h.tracers.items()}
@@ -117,9 +117,9 @@ def test_loopback_share_runs_alone(hostemu):
     """bench.py --emulate-share: one process playing 1 of 8 alone (3 of the 24 sub-domains, its messages looped back) runs the
     multi-process plans and stays finite."""
     sys.path.insert(0, ROOT)
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
-    h = DycoreHarness(12, nz=4, layout=(2, 2), dt_atmos=60.0, k_split=1, n_split=2, world_size=8, proc=0, backend="hostemu", loopback=True)
+    h = hostemu_harness(12, nz=4, layout=(2, 2), dt_atmos=60.0, k_split=1, n_split=2, world_size=8, proc=0, loopback=True)
     assert len(h.grids) == 3 and h.dyn.halo.transport_name.startswith("loopback")
     h.step()
     assert all(ok for _, _, ok in h.sanity().values())
@@ -131,9 +131,9 @@ def test_halo_exchanger_reports_a_released_factory_and_a_foreign_group(hostemu):
     import gc
 
     from pace_amd.halo import HaloExchanger, Layout
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
-    h = DycoreHarness(12, nz=4, layout=(1, 1), backend="hostemu")
+    h = hostemu_harness(12, nz=4, layout=(1, 1))
     ex = h.dyn.halo
     assert HaloExchanger.shared(h.sf, h.layout) is ex
     with pytest.raises(ValueError, match="process group"):

@@ -14,6 +14,7 @@ import torch
 
 from helpers import assert_close, oracle_cube
 from pace_amd.constants import get_constants
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory
 
 import fv3_oracle.dyn_core as o_dyn
@@ -79,7 +80,7 @@ class Dev:
     """All ranks of the cube in one device context; Quantities from lists of per-rank oracle arrays."""
 
     def __init__(self, backend, grids, cfg):
-        self.sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+        self.sf = stencil_factory_for(backend)(grids, cfg, get_constants())
         self.qf = self.sf.quantity_factory
         self.nz = grids[0].nz
 

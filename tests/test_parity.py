@@ -12,6 +12,7 @@ import torch
 from helpers import Case, assert_close, compare_cubes, oracle_cube, run_device_cube
 from pace_amd.config import AcousticDynamicsConfig
 from pace_amd.constants import get_constants
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory
 from pace_amd.grid import make_grid
 from pace_amd.topology import CubedSpherePartitioner
@@ -257,7 +258,7 @@ def test_scalar_pingpong_leaves_every_array_as_the_in_place_sequence_does(backen
         from pace_amd.dyn_core import AcousticDynamics, DycoreState
         from pace_amd.halo import Layout
 
-        sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+        sf = stencil_factory_for(backend)(grids, cfg, get_constants())
         st = DycoreState.from_arrays(sf.quantity_factory, [dict(s_, phis=p) for s_, p in zip(init, phis)])
         for n in ("delp", "pt", "w", "q_con"):
             getattr(st, n).storage[:, nz] = 12345.0 + len(n)  # the caller's level-nz plane (e.g. what restart_state puts there)

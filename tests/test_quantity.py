@@ -106,3 +106,21 @@ def test_quantity_views_share_memory_and_are_ijk():
     assert (f.shape[0], f.shape[1], f.shape[2]) == (12, 13, 8) and f.stride[0] == 1 and f.n_sub == 2
     q2 = qf.zeros([X_DIM, Y_DIM])
     assert q2.is_2d and q2.field.shape[2] == 1
+
+
+def test_the_product_surface_has_one_backend():
+    """``StencilFactory`` / ``QuantityFactory.from_backend`` / ``DycoreHarness`` take ``"hip:gfx950"`` and nothing else: the host emulation the
+    CPU tests run on is reachable through ``pace_amd._testing`` only, never by passing a backend string."""
+    from pace_amd.config import AcousticDynamicsConfig
+    from pace_amd.context import StencilFactory
+    from pace_amd.harness import DycoreHarness
+    from pace_amd.quantity import GridSizer, QuantityFactory
+
+    cfg = AcousticDynamicsConfig(npx=13, npy=13, npz=4)
+    for bad in ("hostemu", "numpy", "cuda"):
+        with pytest.raises(ValueError):
+            StencilFactory([], cfg, backend=bad)
+        with pytest.raises(ValueError):
+            QuantityFactory.from_backend(GridSizer(12, 12, 4, 3, 1), bad)
+    with pytest.raises(ValueError):
+        DycoreHarness(12, nz=4, backend="hostemu")

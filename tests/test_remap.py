@@ -6,6 +6,7 @@ import pytest
 
 from helpers import assert_close, oracle_cube
 from pace_amd.constants import get_constants
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory
 from pace_amd.stencils import LagrangianToEulerian
 
@@ -69,7 +70,7 @@ def test_remap_matches_the_oracle(backend, n, layout, n_tracers, nz):
     """(the third case: the reference's 79 levels -- sponge layers, the thin top layers, the full depth of the edge-value system)"""
     part, cfg, grids, odyn, ost, tr, wsd = _inputs(n, layout, nz, n_tracers)
     c = get_constants()
-    sf = StencilFactory(grids, cfg, c, backend=backend)
+    sf = stencil_factory_for(backend)(grids, cfg, c)
     qf = sf.quantity_factory
     names = ("pt", "delp", "delz", "peln", "pe", "pk", "pkz", "u", "v", "w", "cappa")
     Q = {k: qf.from_array([s[k] for s in ost], ("x", "y", "z")) for k in names}
@@ -106,9 +107,10 @@ def test_acoustic_tracer_remap_cycle_is_stable_and_conserves_mass(backend):
     baroclinic-wave state: everything stays finite and bounded, the global air mass is conserved to round-off, the tracer mass
     to the accuracy the (non-conservative across sub-domain edges to round-off) scheme allows, and the levels come back to
     ak + bk ps after every remap."""
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(12, nz=12, layout=(1, 1), dt_atmos=900.0, k_split=2, n_split=3, backend=backend, init="baroclinic", n_tracers=1, hord_tr=8, remap=True)
+    h = harness_for(backend)(12, nz=12, layout=(1, 1), dt_atmos=900.0, k_split=2, n_split=3, init="baroclinic", n_tracers=1, hord_tr=8, remap=True)
     nz, n = 12, 12
     area = [g.area[3 : 3 + n, 3 : 3 + n] for g in h.grids]
 
@@ -142,9 +144,9 @@ def test_remap_of_an_eulerian_state_is_the_identity(backend):
     """Levels that already sit at ak + bk ps do not move: the remap leaves the winds, w, delz, delp, the tracers and the
     temperature pt * pkz as they were (round-off of the profile integration), and its pkz is p^cappa of the state's own full
     pressure rho R T -- a check of the conversions around the remap that does not depend on the oracle."""
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import harness_for
 
-    h = DycoreHarness(12, nz=12, layout=(1, 1), dt_atmos=900.0, k_split=1, n_split=1, backend=backend, init="baroclinic", n_tracers=1, remap=True)
+    h = harness_for(backend)(12, nz=12, layout=(1, 1), dt_atmos=900.0, k_split=1, n_split=1, init="baroclinic", n_tracers=1, remap=True)
     n, nz, s, c = 12, 12, h.state, h.c
     C = (slice(3, 3 + n), slice(3, 3 + n), slice(0, nz))
     h.dyn.halo.updater("cell", [(s.delp,)]).update()

@@ -6,9 +6,9 @@ import pytest
 
 
 def _harness(backend, **kw):
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import harness_for
 
-    return DycoreHarness(12, nz=6, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=1, backend=backend, **kw)
+    return harness_for(backend)(12, nz=6, layout=(1, 1), dt_atmos=225.0, k_split=1, n_split=1, **kw)
 
 
 def test_restart_round_trip_continues_bitwise(backend, tmp_path):
@@ -101,11 +101,11 @@ def test_restart_refuses_masked_values():
 
 def test_restart_shape_mismatch_is_refused(hostemu, tmp_path):
     from pace_amd import restart
-    from pace_amd.harness import DycoreHarness
+    from pace_amd._testing import hostemu_harness
 
     b = _harness("hostemu")
     restart.save_state(b.state, b.layout.local_ranks, str(tmp_path))
-    other = DycoreHarness(12, nz=5, layout=(1, 1), backend="hostemu")
+    other = hostemu_harness(12, nz=5, layout=(1, 1))
     with pytest.raises(ValueError, match="shape"):
         restart.load_state(other.state, other.layout.local_ranks, str(tmp_path))
     with pytest.raises(FileNotFoundError):

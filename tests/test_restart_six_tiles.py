@@ -205,9 +205,10 @@ def test_real_global_state_a_dozen_model_steps_stay_sane(backend, data):
     reference's SafetyChecker bounds [REF driver/pace/driver/driver.py:557-560], global air mass conserved to round-off, and the
     grid-scale roughness of the fields next to the tile edges does not grow against the interior's (a wrong edge / corner
     formula shows up exactly there)."""
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(N, nz=NZ, layout=(1, 1), dt_atmos=450.0, k_split=1, n_split=3, backend=backend, init="restart", init_data=data, ak=data["ak"], bk=data["bk"],
+    h = harness_for(backend)(N, nz=NZ, layout=(1, 1), dt_atmos=450.0, k_split=1, n_split=3, init="restart", init_data=data, ak=data["ak"], bk=data["bk"],
                       n_tracers=1, hord_tr=8, remap=True)
     area = [g.area[NH : NH + N, NH : NH + N] for g in h.grids]
 

@@ -6,6 +6,7 @@ import pytest
 
 from helpers import assert_close, oracle_cube
 from pace_amd.constants import get_constants
+from pace_amd._testing import stencil_factory_for
 from pace_amd.context import StencilFactory
 from pace_amd.halo import Layout
 from pace_amd.stencils import FiniteVolumeTransport, TracerAdvection
@@ -80,7 +81,7 @@ def test_tracer_advection_matches_the_oracle(backend, n, layout, want_split, n_t
     """n_split = 1 and > 1 (Courant numbers scaled up), even / odd tracer counts, 2 x 2 ranks, multi-strip sub-domains."""
     nz = 4
     part, cfg, grids, odyn, tr, F = _inputs(n, layout, nz, want_split, n_tracers)
-    sf = StencilFactory(grids, cfg, get_constants(), backend=backend)
+    sf = stencil_factory_for(backend)(grids, cfg, get_constants())
     qf = sf.quantity_factory
     pad = lambda a: np.concatenate([a, a[:, :, -1:]], axis=2)  # noqa: E731
     Q = {k: qf.from_array([pad(a) for a in v], ("x", "y", "z")) for k, v in F.items()}
@@ -103,9 +104,10 @@ def test_acoustic_call_plus_tracer_advection_is_mass_consistent(backend):
     remap): the mass fluxes d_sw accumulated over a call rebuild the air mass the call ended with -- dp1 + div(mfxd, mfyd) == delp
     to round-off after EVERY call (which needs the accumulators emptied per call) -- so a constant tracer stays constant and
     tracer mass is conserved through the whole step."""
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(24, nz=6, layout=(1, 1), dt_atmos=450.0, k_split=2, n_split=3, backend=backend, n_tracers=3, hord_tr=8)
+    h = harness_for(backend)(24, nz=6, layout=(1, 1), dt_atmos=450.0, k_split=2, n_split=3, n_tracers=3, hord_tr=8)
     h.tracers["tracer2"].storage.fill_(0.25)
     nx, nz, nh = 24, 6, 3
     area = h.sf.grid_fields["area"].storage[:, nh : nh + nx, nh : nh + nx]

@@ -19,9 +19,10 @@ FIELDS = ("delp", "pt", "u", "v", "w", "delz", "q_con")
 
 
 def run(nx, nz, n_split, dtype, backend):
+    from pace_amd._testing import harness_for
     from pace_amd.harness import DycoreHarness
 
-    h = DycoreHarness(nx, nz=nz, layout=(1, 1), dt_atmos=18.75 * n_split, k_split=1, n_split=n_split, backend=backend, dtype=dtype, noise=0.01)
+    h = harness_for(backend)(nx, nz=nz, layout=(1, 1), dt_atmos=18.75 * n_split, k_split=1, n_split=n_split, dtype=dtype, noise=0.01)
     h.step()
     h.synchronize()
     out = {}
