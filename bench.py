@@ -324,21 +324,32 @@ def main():
             ach = alg / (op_ms["d_sw"] * 1e-3) / 1e9
             # HBM-side bytes of one fv3_d_sw call from the committed PMC passes (rocprofv3 cannot run
             # inside the bench); only quoted when the profile was taken on this very workload
-            traffic, traffic_src = None, None
-            tj = os.path.join(ROOT, "profiles", "traffic_d_sw.json")
-            if os.path.exists(tj) and a.config == "c768" and world == 1 and a.precision == 64 and not a.nz:
-                tr = json.load(open(tj))
-                traffic, traffic_src = tr["bytes"], "profiles/traffic_d_sw.json (" + tr["source"] + ")"
-            # second roof: the VALU-issue floor of the same call (sum of VALU wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz) from the
-            # committed SQ-counter pass (profiles/valu_d_sw.json, tools/prof_sq.sh) -- d_sw cannot go below it however well memory overlaps
-            valu_floor, valu_src = None, None
-            vj = os.path.join(ROOT, "profiles", "valu_d_sw.json")
-            if os.path.exists(vj) and a.config == "c768" and world == 1 and a.precision == 64 and not a.nz:
-                vr = json.load(open(vj))
-                valu_floor, valu_src = vr["valu_floor_ms"], "profiles/valu_d_sw.json (" + vr["source"] + ")"
+            # Both files carry the hash of the kernel sources they were measured on (tools/pmc_traffic.py / pmc_sq.py); the loaded library carries
+            # the hash of the sources it was built from (fv3_build_id).  A counter file of another tree is reported as null with the reason.
+            build_id = h.sf.lib.fv3_build_id().decode()
+            same_workload = a.config == "c768" and world == 1 and a.precision == 64 and not a.nz
+
+            def committed(name, key):
+                pth = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(pth):
+                    return None, f"profiles/{name} not found", None
+                if not same_workload:
+                    return None, f"profiles/{name} was measured on the C768 L79 fp64 one-GPU workload, not on this one", None
+                rec = json.load(open(pth))
+                if rec.get("csrc_hash") != build_id:
+                    return None, f"profiles/{name} was measured on kernel sources {rec.get('csrc_hash')}, this library is built from {build_id}: stale, not quoted", None
+                return rec[key], f"profiles/{name} (" + rec["source"] + f"; kernel sources {build_id})", rec
+
+            traffic, traffic_src, _ = committed("traffic_d_sw.json", "bytes")
+            valu_floor, valu_src, vrec = committed("valu_d_sw.json", "valu_floor_ms")
+            valu_floor_clk = vrec.get("valu_floor_ms_measured_clock") if vrec else None
+            clk = vrec.get("clock_hz_measured") if vrec else None
+            hbm_floor = alg / (HBM_PEAK_GBPS * 1e9) * 1e3
+            # bound: whichever floor of the call is higher (the VALU floor at the clock the chip held while the counters were taken, when known)
+            vf = valu_floor_clk or valu_floor
             line["roofline"] = {
                 "kernel": "d_sw (all launches of one fv3_d_sw call)",
-                "bound": "hbm",
+                "bound": "hbm" if (vf is None or hbm_floor >= vf) else "valu-issue (the HBM fraction below is still the algorithmic bytes over the HBM peak)",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -347,9 +358,12 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_call": alg,
                 "ms_per_call": op_ms["d_sw"],
-                "hbm_floor_ms": alg / (HBM_PEAK_GBPS * 1e9) * 1e3,
+                "hbm_floor_ms": hbm_floor,
                 "valu_floor_ms": valu_floor,
+                "valu_floor_ms_at_measured_clock": valu_floor_clk,
+                "shader_clock_hz_measured": clk,
                 "valu_floor_source": valu_src,
+                "library_build_id": build_id,
             }
         # the same fraction for every operator with a pass count in SURVEY §8a (algorithmic bytes per cell = passes x sizeof(Real))
         passes = {"c_sw": 15, "update_dz_c": 4, "riem_solver_c": 8, "p_grad_c": 7, "d_sw": D_SW_PASSES, "update_dz_d": 6, "riem_solver3": 11, "nh_p_grad": 8}

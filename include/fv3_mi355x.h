@@ -120,6 +120,10 @@ typedef struct {
 int fv3_version(void);
 const char *fv3_last_error(const fv3_ctx *ctx); /* ctx may be NULL: last create error */
 const char *fv3_backend(void);                  /* "hip:gfx950" (product) or "hostemu" (test build) */
+/* sha256 (hex, first 16 digits) of the kernel sources + headers this library was built from (pace_amd/build.py: src_hash): the counter
+ * files bench.py quotes (profiles/traffic_d_sw.json, valu_d_sw.json) carry the hash of the tree they were measured on, and a line built from
+ * another tree reports them as null instead of a stale number */
+const char *fv3_build_id(void);
 
 int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *grid,
                    const fv3_acoustic_config *cfg, const fv3_constants *consts, int device, int dtype);

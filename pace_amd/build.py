@@ -48,6 +48,13 @@ def _digest(paths, extra):
     return h.hexdigest()
 
 
+def src_hash() -> str:
+    """sha256 (first 16 hex digits) of the kernel sources and headers: what a library was built from (embedded as fv3_build_id()) and what a
+    counter file was measured on (tools/pmc_traffic.py, tools/pmc_sq.py write it; bench.py compares the two)."""
+    paths = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return _digest(paths, None)[:16]
+
+
 def _run(cmd):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -77,8 +84,10 @@ def build(precision: int = 64, hostemu: bool = False, force: bool = False, verbo
             if extra:
                 per_file[sname] = extra.split()
 
+    idflag = {"fv3_ctx.hip": [f'-DFV3_SRC_HASH="{src_hash()}"']}
+
     def one(i):
-        _run([cc] + flags + per_file.get(SOURCES[i], []) + ["-c", srcs[i], "-o", objs[i]])
+        _run([cc] + flags + per_file.get(SOURCES[i], []) + idflag.get(SOURCES[i], []) + ["-c", srcs[i], "-o", objs[i]])
 
     with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         list(ex.map(one, range(len(srcs))))

@@ -200,6 +200,11 @@ extern "C" {
 
 int fv3_version(void) { return FV3_ABI_VERSION; }
 
+#ifndef FV3_SRC_HASH
+#define FV3_SRC_HASH "unknown"
+#endif
+const char *fv3_build_id(void) { return FV3_SRC_HASH; }
+
 const char *fv3_backend(void) {
 #ifdef FV3_HOST_EMU
   return "hostemu";

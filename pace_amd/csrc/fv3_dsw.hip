@@ -1221,7 +1221,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   {
     Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
     del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, fdw_k0 - 1);
-    if (tp2d_fd_lean(cf.hord_vt))  // (the round-5 march runs the chain on every strip: only the cube-corner patches come from the staged chain)
+    if (tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1))  // (the round-5 march runs the chain on every strip: only the cube-corner patches come from the staged chain)
       del6_vt_flux_patches(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, fdw_k0, nz1);
     else
       del6_vt_flux_edge_strips(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, fdw_k0, nz1);
@@ -1250,7 +1250,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // sequence (A/B; read per call).
     const char *he = getenv("FV3_DSW_HEAT");
     const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source};
-    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && tp2d_fd_lean(cf.hord_vt) && fdw_k0 <= nz1) {
+    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1)) {
       e.heat = &th;
       heat_k1 = fdw_k0 - 1;
     }

@@ -1362,7 +1362,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
     fv3_wait(c, sa, 2);
   }
   del6_vt_flux(c, sa, zh, d2, fx2, fy2, dn, false, 0, fd_k0 - 1);
-  if (tp2d_fd_lean(c->cfg.hord_tm))  // (the round-5 march runs the chain on every strip: only the cube-corner patches come from the staged chain)
+  if (tp2d_fd_lean(c, c->cfg.hord_tm, fd_k0, nz))  // (the round-5 march runs the chain on every strip: only the cube-corner patches come from the staged chain)
     del6_vt_flux_patches(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);
   else
     del6_vt_flux_edge_strips(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);

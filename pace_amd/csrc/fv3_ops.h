@@ -135,7 +135,7 @@ FV3_HD inline bool q4_corner_tile(int fl, int l0, int ca, int r_end, int nL, int
 // the tiles of a single-tracer FD transport (tp2d_stream_t) that stay with the round-4 kernel: the cube-corner tiles; every other tile runs the round-5
 // march (fv3_tp2x.hip), which evaluates the W / E one-sided formulas of a tile-edge strip in its lanes
 FV3_HD inline bool tp2d_old_tile(int fl, int i0, int ja, int r_end, int nx, int ny) { return q4_corner_tile(fl, i0, ja, r_end, nx, ny); }
-bool tp2d_fd_lean(int hord);  // (fv3_tp2d.hip) will tp2d's FD forms run the round-5 march?  (then only the corner patches of the chain's fluxes are needed)
+bool tp2d_fd_lean(const fv3_ctx *c, int hord, int k0, int k1);  // (fv3_tp2d.hip) will tp2d's FD forms run the round-5 march?  (then only the corner patches of the chain's fluxes are needed)
 // kind 1: d_sw's vorticity transport + wind update, 2: update_dz_d's interface-height transport (TpEpi as for tp2d with fd = 1); PPM order 6
 struct TpEpi;
 // d_sw's damping heat as the epilogue of the vorticity march (kind 1): heat_src += ndelp * (heat_s - 0.25 d_con rsin2 (...)) on the levels with d_con > 1e-5,

@@ -1202,7 +1202,10 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
 
 // Will the FD forms of tp2d (TpEpi::fd != 0, FA contract) run the round-5 march of fv3_tp2x.hip?  It serves every tile of the sub-domains, so the
 // callers then compute the chain's fluxes only on the cube-corner patches (del6_vt_flux_patches) instead of on the whole tile-edge strips.
-bool tp2d_fd_lean(int hord) {
+bool tp2d_fd_lean(const fv3_ctx *c, int hord, int k0, int k1) {
+  // (the contract of the FD forms -- chain of order 2 switched on at every level of the call -- checked on the host tables)
+  for (int k = k0; k <= k1; ++k)
+    if (k >= (int)c->nord_v_h.size() || !(c->nord_v_h[k] == 2 && c->damp_vt_h[k] > 1.0e-5)) return false;
   static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
   static const bool fa_off = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
   const char *me = getenv("FV3_TP2D_MARCH");  // (read per call: the parity test flips it)
@@ -1230,11 +1233,16 @@ static void tp2d_stream(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *c
   // the two big launches of the acoustic sub-step with the PPM order as a constant (reference default 6; FV3_HORD_CONST=0: A/B)
   static const bool hc_off = getenv("FV3_HORD_CONST") && getenv("FV3_HORD_CONST")[0] == '0';
   // (FA: what the two callers of the FD forms guarantee -- fv3_update_dz_d / fv3_d_sw_out pass only levels whose chain is on)
-  static const bool fa_off = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
+  static const bool fa_off_env = getenv("FV3_TP2D_FA") && getenv("FV3_TP2D_FA")[0] == '0';
   if (hord == 6 && !hc_off && !TS_LDS_ONLY) {
     // Round 5: the FA forms run the march of fv3_tp2x.hip (every tile: it evaluates the W / E one-sided formulas in its lanes and the cube-corner
     // remaps / patch fluxes in its general steps).  FV3_TP2D_MARCH=old: the round-4 kernel (A/B; read per call).
-    const bool sx_on = tp2d_fd_lean(hord) && epi && epi->fd_coef;
+    // (FA is the callers' contract "the chain is switched on and of order 2 on every level of this call"; it is CHECKED here on the host
+    //  tables before it is taken as a compile-time fact -- a caller that passes an undamped level gets the general form)
+    bool fa_ok = true;
+    for (int k = k0; k <= k1 && k < (int)c->nord_v_h.size(); ++k) fa_ok = fa_ok && c->nord_v_h[k] == 2 && c->damp_vt_h[k] > 1.0e-5;
+    const bool fa_off = fa_off_env || !fa_ok;
+    const bool sx_on = tp2d_fd_lean(c, hord, k0, k1) && epi && epi->fd_coef;
     if (m == (TF_EPI | TF_AREA | TF_FD)) {
       if (!fa_off && epi->area_form && epi->zfx && epi->out) {
         if (sx_on)

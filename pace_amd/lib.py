@@ -115,6 +115,7 @@ _S = C.c_void_p  # stream
 _PROTOS = {
     "fv3_version": (C.c_int, []),
     "fv3_backend": (C.c_char_p, []),
+    "fv3_build_id": (C.c_char_p, []),
     "fv3_last_error": (C.c_char_p, [C.c_void_p]),
     "fv3_ctx_create": (C.c_int, [P(C.c_void_p), P(fv3_gridspec), P(fv3_griddata), P(fv3_acoustic_config), P(fv3_constants), _I, _I]),
     "fv3_ctx_destroy": (C.c_int, [C.c_void_p]),

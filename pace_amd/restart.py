@@ -71,14 +71,36 @@ def save_state(state: DycoreState, local_ranks: Sequence[int], restart_path: str
     return out
 
 
-def _unmasked(a, path, name):
-    """A restart variable as a plain array.  The netCDF readers hand back masked arrays where a value equals the variable's
-    _FillValue: a restart with missing values is not a state -- refuse it instead of loading the fill value as data."""
+class MissingValuesError(RuntimeError):
+    """a restart variable holds missing values (masked entries, or entries equal to its _FillValue / missing_value attribute)"""
+
+
+def _unmasked(a, path, name, fill=()):
+    """A restart variable as a plain array.  The netCDF4 reader hands back masked arrays where a value equals the variable's
+    _FillValue; h5netcdf and xarray (opened without mask_and_scale) hand back the raw numbers, so the variable's ``_FillValue`` /
+    ``missing_value`` attributes come in through ``fill`` and are compared explicitly.  A restart with missing values is not a
+    state -- refuse it instead of loading the fill value (9.97e36: finite) as data."""
     if np.ma.isMaskedArray(a):
         if np.ma.is_masked(a):
-            raise RuntimeError(f"{path}: variable {name} has {int(np.ma.count_masked(a))} masked (missing / _FillValue) entries")
+            raise MissingValuesError(f"{path}: variable {name} has {int(np.ma.count_masked(a))} masked (missing / _FillValue) entries")
         a = a.filled()  # (nothing masked: filled() only drops the mask)
-    return np.asarray(a)
+    a = np.asarray(a)
+    for f in fill:
+        if f is None:
+            continue
+        try:
+            fv = np.asarray(f, dtype=a.dtype).ravel()
+        except (TypeError, ValueError):
+            continue
+        for v in fv:
+            n = int(np.count_nonzero(a == v)) if not np.isnan(v) else int(np.count_nonzero(np.isnan(a)))
+            if n:
+                raise MissingValuesError(f"{path}: variable {name} has {n} masked (missing / _FillValue = {v!r}) entries")
+    return a
+
+
+def _fill_attrs(attrs):
+    return tuple(attrs.get(k) for k in ("_FillValue", "missing_value") if k in attrs)
 
 
 def _open_variables(path: str):
@@ -101,6 +123,8 @@ def _open_variables(path: str):
             try:
                 with netCDF4.Dataset(path) as ds:
                     return {n: _unmasked(ds.variables[n][:], path, n) for n in ds.variables}
+            except MissingValuesError:
+                raise  # (not a reader failure: reported as what it is)
             except (OSError, RuntimeError) as e:
                 raise RuntimeError(f"{path}: netCDF4 could not read the file ({e})") from e
         try:
@@ -112,7 +136,9 @@ def _open_variables(path: str):
         if reader:
             try:
                 with h5netcdf.File(path, "r") as ds:
-                    return {n: _unmasked(ds.variables[n][...], path, n) for n in ds.variables}
+                    return {n: _unmasked(ds.variables[n][...], path, n, _fill_attrs(ds.variables[n].attrs)) for n in ds.variables}
+            except MissingValuesError:
+                raise
             except (OSError, RuntimeError, KeyError) as e:
                 raise RuntimeError(f"{path}: h5netcdf could not read the file ({e})") from e
         try:
@@ -124,7 +150,9 @@ def _open_variables(path: str):
         if reader:
             try:
                 with xr.open_dataset(path, mask_and_scale=False) as ds:
-                    return {n: _unmasked(ds[n].data, path, n) for n in ds.variables}
+                    return {n: _unmasked(ds[n].data, path, n, _fill_attrs(ds[n].attrs)) for n in ds.variables}
+            except MissingValuesError:
+                raise
             except (OSError, RuntimeError, ValueError) as e:
                 raise RuntimeError(f"{path}: xarray could not read the file ({e})") from e
         raise RuntimeError(f"{path} is a netCDF-4 / HDF5 file (the reference's default restart format) and this environment has none of netCDF4, h5netcdf, "

@@ -11,9 +11,10 @@ from typing import Callable, Dict, Optional
 
 
 class Timer:
-    def __init__(self, enabled: bool = True, sync: Optional[Callable[[], None]] = None):
+    def __init__(self, enabled: bool = True, sync: Optional[Callable[[], None]] = None, sync_names=None):
         self._enabled = enabled
         self._sync = sync
+        self._sync_names = None if sync_names is None else set(sync_names)  # None: every clock synchronises
         self._clock_starts: Dict[str, float] = {}
         self._accumulated: Dict[str, float] = {}
         self._hits: Dict[str, int] = {}
@@ -22,13 +23,13 @@ class Timer:
         if self._enabled:
             if name in self._clock_starts:
                 raise ValueError(f"clock already started for '{name}'")
-            if self._sync:
+            if self._sync and (self._sync_names is None or name in self._sync_names):
                 self._sync()
             self._clock_starts[name] = time.perf_counter()
 
     def stop(self, name: str):
         if self._enabled:
-            if self._sync:
+            if self._sync and (self._sync_names is None or name in self._sync_names):
                 self._sync()
             dt = time.perf_counter() - self._clock_starts.pop(name)
             self._accumulated[name] = self._accumulated.get(name, 0.0) + dt

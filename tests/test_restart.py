@@ -97,6 +97,14 @@ def test_restart_refuses_masked_values():
     a.mask[1, 2] = True
     with pytest.raises(RuntimeError, match="masked"):
         restart._unmasked(a, "f.nc", "u")
+    # readers that do not mask (h5netcdf, xarray without mask_and_scale) hand over the raw numbers + the variable's attributes
+    raw = np.arange(6.0).reshape(2, 3)
+    raw[1, 1] = 9.969209968386869e36
+    with pytest.raises(restart.MissingValuesError, match="masked"):
+        restart._unmasked(raw, "f.nc", "u", restart._fill_attrs({"_FillValue": np.float64(9.969209968386869e36)}))
+    assert restart._unmasked(raw, "f.nc", "u", restart._fill_attrs({"units": "m"})) is not None
+    with pytest.raises(restart.MissingValuesError):
+        restart._unmasked(np.array([1.0, np.nan]), "f.nc", "u", (np.nan,))
 
 
 def test_restart_shape_mismatch_is_refused(hostemu, tmp_path):

@@ -66,7 +66,30 @@ def main(path, flt="", top=40):
         print(", ".join(out))
 
 
-def valu_window(path, first, last, json_out=None, simds=1024, clock_hz=2.4e9):
+def _src_hash():
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pace_amd import build
+
+    return build.src_hash()
+
+
+def measured_clock(path, first, last):
+    """Shader clock while the operator ran: GRBM_GUI_ACTIVE (cycles the GPU was busy, per dispatch) over the dispatch durations of the same window."""
+    rows = [(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(path))]
+    rows.sort()
+    a = next((d for d, n, _, _, _ in rows if n.startswith(first)), None)
+    z = max((d for d, n, _, _, _ in rows if n.startswith(last)), default=None)
+    if a is None or z is None:
+        return None
+    cyc = sum(v for d, n, c, v, _ in rows if a <= d <= z and c == "GRBM_GUI_ACTIVE")
+    ns = sum(t for d, n, c, v, t in rows if a <= d <= z and c == "GRBM_GUI_ACTIVE")
+    return cyc / ns * 1e9 if ns > 0 and cyc > 0 else None
+
+
+def valu_window(path, first, last, json_out=None, simds=1024, clock_hz=2.4e9, clock_csv=None):
     """Sum of SQ_INSTS_VALU over the dispatches of one operator call (first launch of kernel `first` .. last launch of kernel `last`)
     = the operator's VALU-issue floor: every VALU wave-instruction occupies its SIMD for 4 cycles, so the call cannot take less
     than  sum(VALU wave-instructions) * 4 / SIMDs / clock  however well memory is overlapped.  SQ_INSTS_VALU is reported summed
@@ -82,7 +105,9 @@ def valu_window(path, first, last, json_out=None, simds=1024, clock_hz=2.4e9):
     valu = sum(v for d, n, c, v in rows if a <= d <= z and c == "SQ_INSTS_VALU")
     launches = len({d for d, n, c, v in rows if a <= d <= z})
     floor_ms = valu * 4.0 / simds / clock_hz * 1e3
-    out = {"window": [first, last], "launches": launches, "valu_wave_instructions": valu, "simds": simds, "clock_hz": clock_hz, "valu_floor_ms": floor_ms,
+    clk = measured_clock(clock_csv, first, last) if clock_csv else None
+    out = {"csrc_hash": _src_hash(), "clock_hz_measured": clk, "valu_floor_ms_measured_clock": (valu * 4.0 / simds / clk * 1e3) if clk else None,
+           "window": [first, last], "launches": launches, "valu_wave_instructions": valu, "simds": simds, "clock_hz": clock_hz, "valu_floor_ms": floor_ms,
            "source": "rocprofv3 --pmc SQ_INSTS_VALU (kernel trace only), summed over the launches of one operator call; floor = instructions x 4 cycles / 1024 SIMDs / 2.4 GHz"}
     print(f"operator window {first} .. {last}: {launches} launches, {valu:.4g} VALU wave-instructions -> VALU-issue floor {floor_ms:.2f} ms at {clock_hz / 1e9:.1f} GHz")
     if json_out:
@@ -92,6 +117,6 @@ def valu_window(path, first, last, json_out=None, simds=1024, clock_hz=2.4e9):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--valu-window":
-        valu_window(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
+        valu_window(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None, clock_csv=sys.argv[6] if len(sys.argv) > 6 else None)
     else:
         main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "", int(sys.argv[3]) if len(sys.argv) > 3 else 40)

@@ -16,6 +16,16 @@ import sys
 from collections import defaultdict
 
 
+def _src_hash():
+    """hash of the kernel sources this run measured (the snapshot the script runs in): bench.py quotes the file only for a library built from them"""
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pace_amd import build
+
+    return build.src_hash()
+
+
 def short(name):
     m = re.search(r"fv3_k(?:wg|3n|fr|[23bw])<(?:\d+, )*(.*?)::\{lambda.*?#(\d+)\}", name)
     if m:
@@ -74,7 +84,7 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, j
             if json_out:
                 import json
 
-                json.dump({"window": [first, last], "launches": n1, "read_bytes": r * kb * rs, "write_bytes": w * kb * ws, "bytes": r * kb * rs + w * kb * ws,
+                json.dump({"csrc_hash": _src_hash(), "window": [first, last], "launches": n1, "read_bytes": r * kb * rs, "write_bytes": w * kb * ws, "bytes": r * kb * rs + w * kb * ws,
                            "read_scale": rs, "write_scale": ws, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"},
                           open(json_out, "w"))
     print("| kernel | calls | avg ms (pmc run) | read GB/launch | write GB/launch | GB/s |")
