@@ -14,7 +14,7 @@ from pace_amd.topology import STAGGER, CubedSpherePartitioner, build_halo_map, b
 from . import c_sw as _c_sw
 from . import d_sw as _d_sw
 from . import nh as _nh
-from .util import Dom
+from .util import Dom, alt
 
 STATE_3D = (
     "u v w ua va uc vc delp delz pt pe pk peln pkz q_con omga cappa mfxd mfyd cxd cyd diss_estd".split()
@@ -133,7 +133,8 @@ class OracleAcousticDynamics:
             # flux capacitors"); n_map only matters for what the caller does with end_step
             for n in ("mfxd", "mfyd", "cxd", "cyd"):
                 states[r][n][...] = 0.0
-            self.tmp[r]["heat_source"][...] = 0.0
+            if not alt("heat_zero_first_call") or n_map == 1:  # (FV3_ALT: DESIGN §2, uncertain restatement 5)
+                self.tmp[r]["heat_source"][...] = 0.0
             states[r]["diss_estd"][...] = 0.0
         for it in range(n_split):
             remap_step = it == n_split - 1
@@ -198,6 +199,6 @@ class OracleAcousticDynamics:
                 s, t, D = states[r], self.tmp[r], self.doms[r]
                 hs = t["heat_source"][:, :, :nz]
                 _nh.del2_cubed(D, hs, cd, nmax=min(3, cfg.nord + 1))
-                from .util import alt
+
 
                 _nh.apply_diffusive_heating(D, s["delp"], s["delz"], s["cappa"], t["heat_source"], s["pt"], abs((timestep if alt("heat_dt_full") else dt) * cfg.delt_max))

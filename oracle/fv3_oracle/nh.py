@@ -13,7 +13,7 @@ import numpy as np
 
 from .a2b_ord4 import a2b_ord4
 from .fvtp2d import del6_vt_flux, fv_tp_2d
-from .util import Dom, copy_corners, fill_4corners
+from .util import Dom, alt, copy_corners, fill_4corners
 
 
 # ---------------------------------------------------------------------------
@@ -99,7 +99,7 @@ def update_dz_d(D: Dom, cfg, col, dp_ref, zs, zh, crx, cry, xfx, yfx, ws, dt):
     dz_min = D.c.DZ_MIN
     damp = np.append(col["damp_vt"], col["damp_vt"][-1])
     ndif = np.append(col["nord_v"], col["nord_v"][-1]).astype(int)
-    from .util import alt
+
 
     damp_on = damp.copy()  # (the switch "is this interface damped" is the raw coefficient in both forms)
     if alt("dz_damp_scaled"):  # FV3_ALT=dz_damp_scaled: the coefficient d_sw's vorticity damping uses
@@ -403,7 +403,8 @@ def ray_fast(D: Dom, cfg, u, v, w, dp, pfull, dt, ptop):
         x = a[R][:, :, :nz]
         dmdir = np.sum(((1.0 - rf) * dp)[damped] * x[:, :, damped], axis=-1, keepdims=True)
         x[:, :, damped] = x[:, :, damped] * rf[damped]
-        x[:, :, nudged] = x[:, :, nudged] + dmdir / dm
+        if not alt("ray_fast_plain"):  # (FV3_ALT=ray_fast_plain: the older form without the momentum fix -- DESIGN §2, uncertain restatement 4)
+            x[:, :, nudged] = x[:, :, nudged] + dmdir / dm
         a[R + (slice(0, nz),)] = x
     R = S(D.is_, D.ie, D.js, D.je)
     x = w[R][:, :, :nz]

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .util import Dom, tr
+from .util import Dom, tr, alt
 
 P1 = 7.0 / 12.0
 P2 = -1.0 / 12.0
@@ -69,7 +69,8 @@ def _flux_from_blbr(D, q, c, bl, br, j0, j1, mord, cfl_scale=None):
     if mord == 5:
         smt5 = (bl * br) < 0.0
     else:
-        smt5 = (3.0 * np.abs(b0)) < np.abs(bl - br)
+        # (FV3_ALT=smt5_lim_fac: tp_core.F90 writes abs(lim_fac * b0) with the namelist default lim_fac = 1 -- DESIGN §2, uncertain restatement 3)
+        smt5 = ((1.0 if alt("smt5_lim_fac") else 3.0) * np.abs(b0)) < np.abs(bl - br)
     R0 = S(D.is_, D.ie + 1, j0, j1)
     Rm = S(D.is_ - 1, D.ie, j0, j1)
     cc = c[R0]

@@ -231,8 +231,11 @@ def fill_corners_dgrid_vector(D: Dom, x, y, sign=-1.0):
 # debugging session per suspect.  Known names:
 #   dz_damp_scaled   update_dz_d hands del6_vt_flux (damp_vt * da_min_c)^(nord_v + 1) instead of the raw damp_vt column value
 #   heat_dt_full     apply_diffusive_heating limits with |timestep * delt_max| (the whole acoustic call) instead of the sub-step dt
+#   smt5_lim_fac     hord 6: the linear-scheme switch is |lim_fac * b0| < |bl - br| with the Fortran default lim_fac = 1 instead of pyFV3's 3 |b0|
+#   ray_fast_plain   ray_fast without the redistribution of the damped column momentum (the older plain damping u, v, w /= 1 + rf)
+#   heat_zero_first_call   heat_source is emptied on the first acoustic call of a step only (n_map == 1) instead of at the top of every call
 # ---------------------------------------------------------------------------------------------
-ALT_NAMES = ("dz_damp_scaled", "heat_dt_full")
+ALT_NAMES = ("dz_damp_scaled", "heat_dt_full", "smt5_lim_fac", "ray_fast_plain", "heat_zero_first_call")
 
 
 def alt(name: str) -> bool:

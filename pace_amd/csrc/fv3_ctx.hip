@@ -240,6 +240,11 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
 #endif
   fv3_ctx *c = new fv3_ctx();
   c->cfg = *cfg;
+  if (fv3_alt("smt5_lim_fac")) {  // (FV3_ALT, DESIGN §2, uncertain restatement 3: order 6 with lim_fac = 1 is "order 7" inside the library: fv3_ppm.h)
+    int *hs[4] = {&c->cfg.hord_dp, &c->cfg.hord_mt, &c->cfg.hord_tm, &c->cfg.hord_vt};
+    for (int *h : hs)
+      if (*h == 6) *h = 7;
+  }
   c->cst = *consts;
   c->device = device;
   c->dtype = dtype;

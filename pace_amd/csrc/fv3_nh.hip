@@ -1434,6 +1434,7 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_
   if (nn == 0) return FV3_OK;
   const Real dm = (Real)c->rf_dm;
   const Real *rf = (const Real *)c->tab_rf;
+  const bool momentum_fix = !fv3_alt("ray_fast_plain");  // (FV3_ALT: DESIGN §2, uncertain restatement 4)
   launch2_pass(c, (fv3_stream_t)stream, Box{1, g.nx + 1, 1, g.ny + 1, 0, 0}, c->frame_pass, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;
     const unsigned pix = IX(i, j);
@@ -1446,7 +1447,8 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_
         K_(a, k) = K_(a, k) * rf[k];
       }
       const Real add = dmdir / dm;
-      for (int k = 0; k < nn; ++k) K_(a, k) = K_(a, k) + add;
+      if (momentum_fix)
+        for (int k = 0; k < nn; ++k) K_(a, k) = K_(a, k) + add;
     };
     if (i <= g.nx) wind(u);
     if (j <= g.ny) wind(v);

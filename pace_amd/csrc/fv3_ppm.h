@@ -40,9 +40,11 @@ FV3_HD inline Real ppm_al(Q q, M m, int s, bool lo, bool hi, int np_) {
 //  the reference's default hord = 6 everywhere (template parameter HC of dsw_scalars_t / tp2d_stream_t): the test folds to one
 //  comparison.  Evaluating both tests and selecting the lane mask instead was measured too: +2 live SGPR pairs, 12 - 14 spilled
 //  VGPRs in the two-tracer marches.)
+// (mord 7 = order 6 with the Fortran namelist default lim_fac = 1 in the switch -- FV3_ALT=smt5_lim_fac, DESIGN §2, uncertain restatement 3: the
+//  context maps hord 6 to 7 under that switch; the kernels with the order as a compile-time constant only exist for 6)
 FV3_HD inline bool ppm_smt5(Real bl, Real br, int mord) {
   const Real b0 = bl + br;
-  return mord == 5 ? (bl * br) < (Real)0 : ((Real)3.0 * fabs(b0)) < fabs(bl - br);
+  return mord == 5 ? (bl * br) < (Real)0 : ((mord == 7 ? (Real)1.0 : (Real)3.0) * fabs(b0)) < fabs(bl - br);
 }
 
 // flux-form value crossing face s (between cells s-1 and s) with Courant number c.

@@ -197,7 +197,8 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     RUN(FV3_OP_GLUE, fv3_zero(c, &st->cxd, stream));
     RUN(FV3_OP_GLUE, fv3_zero(c, &st->cyd, stream));
   }
-  RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
+  if (n_map == 1 || !fv3_alt("heat_zero_first_call"))  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
+    RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
   RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
   for (int it = 0; it < n_split; ++it) {
     const int remap_step = it == n_split - 1;

@@ -1356,6 +1356,7 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, const fv3_field *q_, const fv3_field *cr
     if (!mass) return FV3_ERR_ARG;
   }
   if (hord != 5 && hord != 6) return fv3_fail(c, FV3_ERR_UNSUPPORTED, "hord must be 5 or 6");
+  if (hord == 6 && fv3_alt("smt5_lim_fac")) hord = 7;  // (FV3_ALT: see fv3_ppm.h)
   if (nord > 2) return fv3_fail(c, FV3_ERR_UNSUPPORTED, "fv_tp_2d damping order must be <= 2 (halo of 3)");
   Deln d;
   memset(&d, 0, sizeof(d));

@@ -266,7 +266,8 @@ class AcousticDynamics:
         if update_temporaries:
             for q in (state.mfxd, state.mfyd, state.cxd, state.cyd):  # every call ("empty the flux capacitors")
                 sf.call("zero", q.fref)
-            sf.call("zero", self._heat_source.fref)
+            if n_map == 1 or "heat_zero_first_call" not in [x.strip() for x in os.environ.get("FV3_ALT", "").split(",")]:  # (FV3_ALT: DESIGN §2, restatement 5)
+                sf.call("zero", self._heat_source.fref)
             sf.call("zero", state.diss_estd.fref)
         for it in range(n_split):
             remap_step = cfg.breed_vortex_inline or (it == n_split - 1)

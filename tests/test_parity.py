@@ -289,7 +289,7 @@ def test_operator_contexts_do_not_allocate_the_pingpong_buffers(backend):
     assert cs.sf.scratch_bytes - before < ni * nj * nk * 8  # (small per-operator tables may appear; no full 3-D field)
 
 
-@pytest.mark.parametrize("name", ["dz_damp_scaled", "heat_dt_full"])
+@pytest.mark.parametrize("name", ["dz_damp_scaled", "heat_dt_full", "smt5_lim_fac", "ray_fast_plain", "heat_zero_first_call"])
 def test_named_alternatives_switch_oracle_and_library_together(backend, name, monkeypatch):
     """FV3_ALT=<name> selects the alternative form of a restatement DESIGN §2 lists as uncertain in the oracle AND in the library
     (native sequencer and its Python twin): under the switch the two still agree to the usual tolerances, and the switch does
@@ -301,12 +301,14 @@ def test_named_alternatives_switch_oracle_and_library_together(backend, name, mo
             monkeypatch.setenv("FV3_ALT", env)
         else:
             monkeypatch.delenv("FV3_ALT", raising=False)
-        part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=2))
+        n_calls = 2 if name == "heat_zero_first_call" else 1  # (two acoustic calls of one step: n_map = 1, 2)
+        part, cfg, grids, ost, phis, odyn = oracle_cube(12, (1, 1), nz, dict(n_split=2, k_split=n_calls))
         init = [{k: v.copy() for k, v in s.items()} for s in ost]
-        odyn(ost, 225.0, 1)
-        got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0)
+        for n in range(n_calls):
+            odyn(ost, 225.0, n + 1)
+        got, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0, n_calls=n_calls)
         compare_cubes(got, ost, part, nz, STATE, TOL)
-        got_py, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0, native=False)
+        got_py, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 225.0, n_calls=n_calls, native=False)
         for r in range(part.total_ranks):
             for n in ("delz", "w", "pt"):
                 assert np.array_equal(got[r][n], got_py[r][n]), n
@@ -314,6 +316,12 @@ def test_named_alternatives_switch_oracle_and_library_together(backend, name, mo
             base = ost
         elif name == "dz_damp_scaled":  # the interface-height damping changes: the thickness differs from the default form
             assert max(np.abs(a["delz"] - b["delz"]).max() for a, b in zip(ost, base)) > 1e-9
+        elif name == "smt5_lim_fac":  # more cells take the linear scheme: every transported field moves
+            assert max(np.abs(a["pt"] - b["pt"]).max() for a, b in zip(ost, base)) > 1e-9
+        elif name == "ray_fast_plain":  # the damped momentum is not given back to the column: the winds of the top levels differ
+            assert max(np.abs(a["u"] - b["u"]).max() for a, b in zip(ost, base)) > 1e-9
+        elif name == "heat_zero_first_call":  # the second call's heating includes the first call's heat source: pt differs
+            assert max(np.abs(a["pt"] - b["pt"]).max() for a, b in zip(ost, base)) > 1e-12
     monkeypatch.setenv("FV3_ALT", "no_such_form")
     with pytest.raises(ValueError, match="unknown alternative"):
         oracle_cube(12, (1, 1), 3, dict(n_split=1))[5]([{k: v.copy() for k, v in s.items()} for s in oracle_cube(12, (1, 1), 3, dict(n_split=1))[3]], 10.0, 1)

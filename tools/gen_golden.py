@@ -28,6 +28,7 @@ Consumers: tests/test_reference_golden.py (C_SW, D_SW), tests/test_reference_gol
 import argparse
 import json
 import os
+import sys
 from collections import defaultdict
 
 import numpy as np
@@ -80,7 +81,16 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--eta-file", default="tests/main/input/eta79.nc")
     ap.add_argument("--dry", action="store_true", help="zero the water species of the initial state (the dry configuration this build remaps)")
+    ap.add_argument("--list-alts", action="store_true",
+                    help="print the FV3_ALT names (the named alternatives of the uncertain restatements, DESIGN §2) one per line and exit: "
+                         "`for a in '' $(python tools/gen_golden.py --list-alts); do FV3_ALT=$a pytest tests/test_reference_golden*.py; done` tries them in one pass")
     a = ap.parse_args()
+    if a.list_alts:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        from fv3_oracle.util import ALT_NAMES
+
+        print("\n".join(ALT_NAMES))
+        return
     mpi = None
     try:
         from mpi4py import MPI
