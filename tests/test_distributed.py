@@ -34,7 +34,7 @@ def _worker(rank, world, init_file, out_dir, nx_tile, layout, nz, native):
 # native = "0": the torch.distributed reference path (Python callback per update)
 @pytest.mark.parametrize("native", ["1", "0"])
 @pytest.mark.parametrize("nx_tile, layout", [(12, (1, 1)), (12, (2, 2))])
-def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, layout, native, monkeypatch):
+def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, layout, native, monkeypatch, world=2):
     nz = 5
     monkeypatch.setenv("FV3_HALO_NATIVE", native)
     sys.path.insert(0, ROOT)
@@ -44,15 +44,24 @@ def test_two_process_gloo_matches_single_process(hostemu, tmp_path, nx_tile, lay
     h.step()
     ref = h.state.to_arrays(["delp", "pt", "u", "v", "w", "delz"])
     init_file = str(tmp_path / "init")
-    mp.spawn(_worker, args=(2, init_file, str(tmp_path), nx_tile, layout, nz, native), nprocs=2, join=True)
-    per = len(ref) // 2
-    for p in range(2):
+    mp.spawn(_worker, args=(world, init_file, str(tmp_path), nx_tile, layout, nz, native), nprocs=world, join=True)
+    per = len(ref) // world
+    for p in range(world):
         got = np.load(tmp_path / f"proc{p}.npz")
         for i in range(per):
             for n in ("delp", "pt", "u", "v", "w", "delz"):
                 a, b = got[f"{n}_{i}"], ref[p * per + i][n]
                 sl = (slice(3, -4), slice(3, -4), slice(0, nz))
                 assert np.array_equal(a[sl], b[sl]), (p, i, n, np.abs(a[sl] - b[sl]).max())
+
+
+
+def test_eight_process_headline_partition_matches_single_process(hostemu, tmp_path, monkeypatch):
+    """The partition of the headline configuration (layout 2 x 2 = 24 sub-domains over 8 processes, 3 per process, `3g .. 3g+2`
+    -- the four sub-tiles of a cube tile straddle two processes, every process has on-device neighbours AND neighbours in two or more other
+    processes) on a C24 cube (12^2 sub-domains): the native halo plans over the host-driven transport must reproduce the one-process
+    result bit for bit, WHOLE FIELDS compared (compute domain of every sub-domain)."""
+    test_two_process_gloo_matches_single_process(hostemu, tmp_path, 24, (2, 2), "1", monkeypatch, world=8)
 
 
 def _tracer_run(h, scale):

@@ -120,13 +120,15 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4), (48, 1, 6)])
+@pytest.mark.parametrize("nx, layout, world", [(48, 1, 2), (24, 2, 4), (48, 1, 6), (24, 2, 8)])
 def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, world):
     """The same cube stepped by one process and by `world` processes (C48: 6 sub-domains split 3 + 3;
     C24 layout 2x2: 24 sub-domains, 6 per process, tiles straddling processes as on 4 / 8 GPUs; C48 on 6 processes: ONE
-    sub-domain per process, the shape of BASELINE's "6 tiles -> 6 GPUs" configuration;
+    sub-domain per process, the shape of BASELINE's "6 tiles -> 6 GPUs" configuration; C24 layout 2x2 on 8 processes: the partition of the
+    headline run, 3 sub-domains per process, every tile straddling two processes;
     messages over gloo staged through pinned host memory because the box has one GPU; the 8-GPU
-    bench uses RCCL with the identical pack / unpack plans) must give bitwise equal fields."""
+    bench uses RCCL with the identical pack / unpack plans) must give bitwise equal FIELDS (tools/multi_gpu_check.py compares a hash of every
+    sub-domain's whole compute-domain array besides its sum and maximum)."""
     import subprocess
     import sys
 
