@@ -76,7 +76,8 @@ def _src_hash():
 
 
 def measured_clock(path, first, last):
-    """Shader clock while the operator ran: GRBM_GUI_ACTIVE (cycles the GPU was busy, per dispatch) over the dispatch durations of the same window."""
+    """Shader clock while the operator ran: GRBM_GUI_ACTIVE (busy cycles per dispatch, reported SUMMED over the 8 XCDs of the MI355X -- a
+    bandwidth-bound stage kernel reads 19 cycles / ns = 8 x 2.37 GHz, profiles/r05_ablation.md) over the dispatch durations of the same window."""
     rows = [(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             for r in csv.DictReader(open(path))]
     rows.sort()
@@ -86,7 +87,7 @@ def measured_clock(path, first, last):
         return None
     cyc = sum(v for d, n, c, v, _ in rows if a <= d <= z and c == "GRBM_GUI_ACTIVE")
     ns = sum(t for d, n, c, v, t in rows if a <= d <= z and c == "GRBM_GUI_ACTIVE")
-    return cyc / ns * 1e9 if ns > 0 and cyc > 0 else None
+    return cyc / ns * 1e9 / 8.0 if ns > 0 and cyc > 0 else None
 
 
 def valu_window(path, first, last, json_out=None, simds=1024, clock_hz=2.4e9, clock_csv=None):
