@@ -1511,44 +1511,42 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
       const bool upd = i >= 1 - nt && i <= g.nx + nt && j >= 1 - nt && j <= g.ny + nt;
       const unsigned p0 = IX(i, j);
       Real mvx0 = (Real)0, mvx1 = (Real)0, muy0 = (Real)0, muy1 = (Real)0, cra = (Real)0;
+      // the six points of the stencil as in-plane offsets, formed ONCE (they do not depend on the level): the corner-halo remaps
+      // (cc_index: a dozen compares and selects per point) were evaluated per level inside the loop -- the kernel ran at 2.8 TB/s on its
+      // 5.5 GB because of that index arithmetic, not because of its bytes
+      unsigned pxw = p0, pxc = p0, pxe = p0, pys = p0, pyc = p0, pyn = p0;
       if (upd) {
         mvx0 = (g.del6_v + m2)[p0];
         mvx1 = (g.del6_v + m2)[IX(i + 1, j)];
         muy0 = (g.del6_u + m2)[p0];
         muy1 = (g.del6_u + m2)[IX(i, j + 1)];
         cra = cd * (g.rarea + m2)[p0];
+        if (nt > 0) {
+          pxw = cc_index<1>(g, fl, i - 1, j);
+          pxc = cc_index<1>(g, fl, i, j);
+          pxe = cc_index<1>(g, fl, i + 1, j);
+          pys = cc_index<2>(g, fl, i, j - 1);
+          pyc = cc_index<2>(g, fl, i, j);
+          pyn = cc_index<2>(g, fl, i, j + 1);
+        } else {
+          pxw = IX(i - 1, j);
+          pxe = IX(i + 1, j);
+          pys = IX(i, j - 1);
+          pyn = IX(i, j + 1);
+        }
       }
-#pragma unroll 1
+#pragma unroll 2
       for (int kk = 0; kk < FV3_KC; ++kk) {
         const int k = FV3_KC * kp + kk;
         if (k > nz1) break;
-        i = i_;
-        j = j_;
-        FV3_LAUNDER(i);
-        FV3_LAUNDER(j);
         const long b = t * g.st + k * g.sk;
         const Real *qq = qin + b;
-        const unsigned p = IX(i, j);
-        Real v = qq[p];
+        Real v = qq[p0];
         if (upd) {
-          Real xw, xc, xe, ys, yc, yn;
-          if (nt > 0) {
-            xw = cc<1>(qq, g, fl, i - 1, j);
-            xc = cc<1>(qq, g, fl, i, j);
-            xe = cc<1>(qq, g, fl, i + 1, j);
-            ys = cc<2>(qq, g, fl, i, j - 1);
-            yc = cc<2>(qq, g, fl, i, j);
-            yn = cc<2>(qq, g, fl, i, j + 1);
-          } else {
-            xw = qq[IX(i - 1, j)];
-            xe = qq[IX(i + 1, j)];
-            ys = qq[IX(i, j - 1)];
-            yn = qq[IX(i, j + 1)];
-            xc = yc = v;
-          }
+          const Real xw = qq[pxw], xc = qq[pxc], xe = qq[pxe], ys = qq[pys], yc = qq[pyc], yn = qq[pyn];
           v = v + cra * (mvx0 * (xw - xc) - mvx1 * (xc - xe) + muy0 * (ys - yc) - muy1 * (yc - yn));
         }
-        (out + b)[p] = v;
+        (out + b)[p0] = v;
       }
     });
     in = out;
