@@ -1535,10 +1535,16 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
           pyn = IX(i, j + 1);
         }
       }
-#pragma unroll 2
+#ifndef FV3_DEL2_UNROLL
+#define FV3_DEL2_UNROLL 2
+#endif
+      // (no early exit inside the loop: a level past the last one is clamped and its store masked, so that the unrolled body has the
+      //  loads of several levels in flight -- with `break` every level waited for its own seven loads)
+#pragma unroll FV3_DEL2_UNROLL
       for (int kk = 0; kk < FV3_KC; ++kk) {
-        const int k = FV3_KC * kp + kk;
-        if (k > nz1) break;
+        const int k_ = FV3_KC * kp + kk;
+        const bool live = k_ <= nz1;
+        const int k = live ? k_ : nz1;
         const long b = t * g.st + k * g.sk;
         const Real *qq = qin + b;
         Real v = qq[p0];
@@ -1546,7 +1552,7 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
           const Real xw = qq[pxw], xc = qq[pxc], xe = qq[pxe], ys = qq[pys], yc = qq[pyc], yn = qq[pyn];
           v = v + cra * (mvx0 * (xw - xc) - mvx1 * (xc - xe) + muy0 * (ys - yc) - muy1 * (yc - yn));
         }
-        (out + b)[p0] = v;
+        if (live) (out + b)[p0] = v;
       }
     });
     in = out;
