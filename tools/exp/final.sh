@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-4: GPU suite + bench + kernel stats + PMC traffic + SQ counters of the current build
+# round-5: GPU suite + bench + kernel stats + PMC traffic + SQ counters (+ shader clock) of the current build
 set -u
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-bash tools/collect_profiles.sh r04_final --steps 5 --warmup 2
-bash tools/prof_sq.sh r04_sq
-cat gpurun_out/r04_sq/valu_d_sw.log
+bash tools/collect_profiles.sh r05_final --steps 5 --warmup 2
+bash tools/prof_sq.sh r05_sq
+cat gpurun_out/r05_sq/valu_d_sw.log
