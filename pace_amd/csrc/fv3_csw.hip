@@ -724,10 +724,20 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       (va + b)[p] = (vt_ - ut_ * cs) * rs2;
     }
   };
+  // Round 5: the boundary windows of stages A and B read u / v (and, within two cells of a tile edge, the window's own ua / va) and write
+  // window cells only; the interior march reads the five inputs and writes interior cells only.  Neither waits for the other, so the eight
+  // small window launches (1.0 ms of a few dozen waves each) go to the auxiliary stream and run BESIDE the march; stage C -- whose windows
+  // read the march's ut / vt across the rim -- joins them.  FV3_CSW_WIN_OVERLAP=0: in program order (A/B; same values).  Events 0 = fork, 1 = join.
+  static const bool win_overlap = !(getenv("FV3_CSW_WIN_OVERLAP") && getenv("FV3_CSW_WIN_OVERLAP")[0] == '0');
+  fv3_stream_t sw_ = (fused && b_split && win_overlap) ? fv3_aux(c, s) : s;
+  if (sw_ != s) {
+    fv3_signal(c, s, 0);
+    fv3_wait(c, sw_, 0);
+  }
   if (b_split) {
     // the four windows along the sub-domain boundary (launch_frame: W / E as narrow 8 x 32 workgroups, S / N as they lie)
     const int e0 = g.nx - 3;
-    launch_frame(c, s, Frame{{Box{-1, 5, -1, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, -1, g.ny + 2, 0, 0}, Box{6, g.nx - 4, -1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_a);
+    launch_frame(c, sw_, Frame{{Box{-1, 5, -1, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, -1, g.ny + 2, 0, 0}, Box{6, g.nx - 4, -1, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_a);
   } else {
     launch3(c, s, Box{-1, g.nx + 2, -1, g.ny + 2, 0, nkc - 1}, stage_a);
   }
@@ -938,10 +948,14 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
       // (one right-sized launch per window: launch3w sizes every window's grid for the largest one)
       // (the 6-column W / E windows run as 8-column x 32-row workgroups: launch_frame)
       const int e0 = g.nx - 3;
-      launch_frame(c, s, Frame{{Box{0, 5, 0, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 2, 0, 0}, Box{6, g.nx - 4, 0, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_b);
+      launch_frame(c, sw_, Frame{{Box{0, 5, 0, g.ny + 2, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 2, 0, 0}, Box{6, g.nx - 4, 0, 5, 0, 0}, Box{6, g.nx - 4, g.ny - 4, g.ny + 2, 0, 0}}}, stage_b);
     } else {
       launch3(c, s, nat, stage_b);
     }
+  }
+  if (sw_ != s) {
+    fv3_signal(c, sw_, 1);
+    fv3_wait(c, s, 1);
   }
 
   // the in-place corner fixes of ua / va the reference leaves behind (checkpointed as uad / vad)
