@@ -85,6 +85,15 @@ FV3_HD inline Real px_quot(Real x, Real y, Real r) {
 
 // element at (uniform base) + (32-bit byte offset)
 FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff); }
+// ... of a 3-D field row a wave reads ONCE (-DPX_NT_LOADS: with the streaming hint, so that the rows of the 2-D metric terms, which the
+// sixteen levels of a tile share through the XCD's L2, are not evicted by them -- experiment R5-15)
+FV3_HD inline Real px_ld3(const Real *base, unsigned boff) {
+#if defined(PX_NT_LOADS) && !defined(FV3_HOST_EMU)
+  return __builtin_nontemporal_load(fv3_at(base, boff));
+#else
+  return *fv3_at(base, boff);
+#endif
+}
 
 // The edge value at the low face of cell s next to a W / E tile edge (fv3_ppm.h: ppm_al), for the lane that holds cell s: kind 1 = the face one
 // before the edge (s == 0 / np-1), 2 = the edge face itself (the two-sided, width-weighted mean; s == 1 / np), 3 = the face one behind it

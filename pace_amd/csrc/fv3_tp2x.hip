@@ -163,12 +163,12 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
       const int rf = GEN ? (r - 2 < jsd ? jsd : r - 2) : r - 2;
       const unsigned p0 = pcolB[l] + (unsigned)r * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
       Row w;
-      w.qy = px_ld(qb, p0);
-      w.cx = px_ld(crxb, p0);
-      w.xv = px_ld(xfxb, p0);
+      w.qy = px_ld3(qb, p0);
+      w.cx = px_ld3(crxb, p0);
+      w.xv = px_ld3(xfxb, p0);
       w.ar = px_ld(areab, p0);
-      w.cy = px_ld(cryb, pf);
-      w.yv = px_ld(yfxb, pf);
+      w.cy = px_ld3(cryb, pf);
+      w.yv = px_ld3(yfxb, pf);
       return w;
     };
     auto load_opt = [&](int q, int r, int l, auto gen_tag) {  // what step r consumes: face r-2, row r-3 (into set q)
@@ -180,25 +180,25 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
         // of the next strip's first face.  Their owners update them IN PLACE at a time of their own, so these two are read from copies made
         // before the march (sx_side_copy); without the epilogue the values computed on faces a wave does not own are discarded.
         if (HEAT && GEN && side_row && rf == jb + 1)
-          Ou[q][l] = px_ld(usideb, pf);
+          Ou[q][l] = px_ld3(usideb, pf);
         else
-          Ou[q][l] = px_ld(ub, pf);
+          Ou[q][l] = px_ld3(ub, pf);
         Odx[q][l] = px_ld(dxb, pf);
-        Okf[q][l] = px_ld(keb, pf);
+        Okf[q][l] = px_ld3(keb, pf);
         if constexpr (HEAT)
-          Ov[q][l] = *fv3_at(vsrc[l], p3);
+          Ov[q][l] = px_ld3(vsrc[l], p3);
         else
-          Ov[q][l] = px_ld(vb, p3);
+          Ov[q][l] = px_ld3(vb, p3);
         Ody[q][l] = px_ld(dyb, p3);
         if constexpr (HEAT) {
-          Hvd[q][l] = px_ld(vdb, pf);
+          Hvd[q][l] = px_ld3(vdb, pf);
           Hrx[q][l] = px_ld(rdxb, pf);
           Hry[q][l] = px_ld(rdyb, p3);
           Hrs[q][l] = px_ld(rs2b, p3);
           Hcs[q][l] = px_ld(csb, p3);
-          Hdp[q][l] = px_ld(ndpb, p3);
-          Hhs[q][l] = px_ld(hsb, p3);
-          Hho[q][l] = px_ld(hob, p3);
+          Hdp[q][l] = px_ld3(ndpb, p3);
+          Hhs[q][l] = px_ld3(hsb, p3);
+          Hho[q][l] = px_ld3(hob, p3);
         }
       }
     };

@@ -164,13 +164,13 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       const int rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
       const unsigned p0 = pcolB[l] + (unsigned)r * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
       Row w;
-      w.q0 = px_ld(q0b, p0);
-      w.q1 = px_ld(q1b, p0);
-      w.cx = px_ld(crLb, p0);
-      w.xv = px_ld(afLb, p0);
+      w.q0 = px_ld3(q0b, p0);
+      w.q1 = px_ld3(q1b, p0);
+      w.cx = px_ld3(crLb, p0);
+      w.xv = px_ld3(afLb, p0);
       w.ar = px_ld(areab, p0);
-      w.cy = px_ld(crMb, pf);
-      w.yv = px_ld(afMb, pf);
+      w.cy = px_ld3(crMb, pf);
+      w.yv = px_ld3(afMb, pf);
       return w;
     };
     auto load_opt = [&](int q, int r, int l, auto gen_tag) {  // what step r consumes: row r-3, face r-2 (into set q)
@@ -178,12 +178,12 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       const int r3 = GEN ? (r - 3 < Msd ? Msd : r - 3) : r - 3, rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
       const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
       if constexpr (AIR) {
-        Ox[q][l] = px_ld(accLb, p3);
-        Oy[q][l] = px_ld(accMb, pf);
+        Ox[q][l] = px_ld3(accLb, p3);
+        Oy[q][l] = px_ld3(accMb, pf);
       } else {
-        Ox[q][l] = px_ld(flLb, p3);
-        Oy[q][l] = px_ld(flMb, pf);
-        Om[q][l] = px_ld(oldmb, pf);
+        Ox[q][l] = px_ld3(flLb, p3);
+        Oy[q][l] = px_ld3(flMb, pf);
+        Om[q][l] = px_ld3(oldmb, pf);
       }
     };
     auto load_met = [&](int r, int l) -> Met {
