@@ -203,7 +203,10 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
       s4 = (g.sin_sg4 + m2)[IX(i, j - 1)];
       s2 = (g.sin_sg2 + m2)[p];
     }
-#pragma unroll 1
+#ifndef FV3_FXADV_UNROLL
+#define FV3_FXADV_UNROLL 1
+#endif
+#pragma unroll FV3_FXADV_UNROLL
     for (int kk = 0; kk < FV3_KC; ++kk) {
       const int k = FV3_KC * kp + kk;
       if (k > g.nz - 1) break;

@@ -6,4 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 bash tools/collect_profiles.sh r05_final --steps 5 --warmup 2
 bash tools/prof_sq.sh r05_sq
+python3 -m pytest tests/test_baseline_configs.py -m gpu -q -s -k "fp32_build" 2>&1 | grep -E "fp32 vs|passed|failed" > gpurun_out/r05_final/fp32_errors.log
+cat gpurun_out/r05_final/fp32_errors.log
 cat gpurun_out/r05_sq/valu_d_sw.log
