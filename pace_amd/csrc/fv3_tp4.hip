@@ -955,7 +955,9 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
     // The few levels below fd_k0 are launches of a handful of waves per CU that last as long as one wave's march: they go to the
     // auxiliary stream and run BESIDE the marches of the other levels (disjoint levels of the same arrays; the q_con + pt march of
     // a level follows the delp + w march of that level on either stream).  Events: 2 = fork, 3 = join.
-    fv3_stream_t s2 = kf > 0 && kf <= nz1 ? fv3_aux(c, s) : s;
+    // (FV3_DSW_SPONGE_SERIAL=1: the sponge-level launches in program order on the caller's stream -- experiment R5-17)
+    static const bool sponge_serial = getenv("FV3_DSW_SPONGE_SERIAL") && getenv("FV3_DSW_SPONGE_SERIAL")[0] == '1';
+    fv3_stream_t s2 = kf > 0 && kf <= nz1 && !sponge_serial ? fv3_aux(c, s) : s;
     if (s2 != s) {
       fv3_signal(c, s, 2);
       fv3_wait(c, s2, 2);
