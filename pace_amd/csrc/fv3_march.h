@@ -84,7 +84,13 @@ FV3_HD inline Real px_quot(Real x, Real y, Real r) {
 }
 
 // element at (uniform base) + (32-bit byte offset)
+// (-DPX_METRIC_HOT, timing experiment R5-20 only: every 2-D metric read lands in the first 2 KB of its array -- the instruction stream is the
+//  product's, the reads always hit; wrong values.  Never in a product library.)
+#ifdef PX_METRIC_HOT
+FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff & 0x7f8u); }
+#else
 FV3_HD inline Real px_ld(const Real *base, unsigned boff) { return *fv3_at(base, boff); }
+#endif
 // ... of a 3-D field row a wave reads ONCE (-DPX_NT_LOADS: with the streaming hint, so that the rows of the 2-D metric terms, which the
 // sixteen levels of a tile share through the XCD's L2, are not evicted by them -- experiment R5-15)
 FV3_HD inline Real px_ld3(const Real *base, unsigned boff) {
