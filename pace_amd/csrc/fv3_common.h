@@ -262,6 +262,12 @@ struct fv3_ctx {
   int pp_state = 0;
   // set by fv3_acoustic_step around its d_sw call: the workspace divgd is dead after the operator (the next c_sw overwrites it)
   bool seq_divgd_dead = false;
+  // set by fv3_acoustic_step around the d_sw call of a call's FIRST sub-step: the four accumulators of the tracer sub-cycling (mfx, mfy, cx, cy) hold
+  // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (4 KB of zeros: always a cache hit) instead of the field, and the sequencer
+  // does not zero the fields first (fv3_step.hip; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
+  bool seq_acc_first = false;
+  Real *zeros = nullptr;
+  const void *acc_zeroed[4] = {nullptr, nullptr, nullptr, nullptr};  // the accumulator arrays this context has zeroed in full once
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;

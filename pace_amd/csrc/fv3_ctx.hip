@@ -382,6 +382,14 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   }
 #endif
   {
+    const std::vector<Real> z(4096 / sizeof(Real), (Real)0);
+    c->zeros = (Real *)upload(c, z);
+    if (!c->zeros) {
+      fv3_ctx_destroy(c);
+      return fv3_fail(nullptr, FV3_ERR_NOMEM, "device allocation of the zero block failed");
+    }
+  }
+  {
     Geo *gd = (Geo *)fv3_dev_alloc(c, sizeof(Geo));
     if (!gd) {
       fv3_ctx_destroy(c);

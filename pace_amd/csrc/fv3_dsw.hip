@@ -160,6 +160,7 @@ FV3_HD inline bool fxadv_int_v(const Geo &g, int fl, int i, int j) {
 void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx, Real *cry, Real *xfx, Real *yfx, Real *ut, Real *vt, Real dt, Real *cx,
            Real *cy, bool thin_ut) {
   const Geo g = c->g;
+  const bool first = c->seq_acc_first;  // (the sequencer's first sub-step of a call: cx / cy hold nothing yet -- 0 + cr, the field is not read)
   static const bool full_ut = getenv("FV3_FXADV_FULL_UT") != nullptr;  // A/B switch
   if (full_ut) thin_ut = false;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
@@ -226,7 +227,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
             FV3_ST_NT((xfx + b)[p], dy_ * x * s1);
           }
           FV3_ST_NT((crx + b)[p], cr);
-          if (cx) FV3_ST_NT((cx + b)[p], (cx + b)[p] + cr);
+          if (cx) FV3_ST_NT((cx + b)[p], (first ? (Real)0 : (cx + b)[p]) + cr);
         }
       }
       if (int_v) {
@@ -243,7 +244,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
             FV3_ST_NT((yfx + b)[p], dx_ * y * s2);
           }
           FV3_ST_NT((cry + b)[p], cr);
-          if (cy) FV3_ST_NT((cy + b)[p], (cy + b)[p] + cr);
+          if (cy) FV3_ST_NT((cy + b)[p], (first ? (Real)0 : (cy + b)[p]) + cr);
         }
       }
     }
@@ -283,7 +284,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
           (xfx + b)[p] = (g.dy + m2)[p] * x * (g.sin_sg1 + m2)[p];
         }
         (crx + b)[p] = cr;
-        if (cx) (cx + b)[p] += cr;
+        if (cx) (cx + b)[p] = (first ? (Real)0 : (cx + b)[p]) + cr;
       }
     }
     if (j >= 0 && !int_v) {  // vt on isd..ied, js-1..je+3
@@ -300,7 +301,7 @@ void fxadv(fv3_ctx *c, fv3_stream_t s, const Real *uc, const Real *vc, Real *crx
           (yfx + b)[p] = (g.dx + m2)[p] * y * (g.sin_sg2 + m2)[p];
         }
         (cry + b)[p] = cr;
-        if (cy) (cy + b)[p] += cr;
+        if (cy) (cy + b)[p] = (first ? (Real)0 : (cy + b)[p]) + cr;
       }
     }
   });
@@ -797,6 +798,15 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
   }
 }
 
+// Does d_sw take the accumulators' first-sub-step form (fv3_ctx::seq_acc_first) in this configuration?  (the fused scalar marches and fxadv do; the
+// round-1 "separate" transports accumulate through tp2d's epilogue and do not) -- fv3_acoustic_step asks before it leaves out the four zero launches.
+bool dsw_honors_acc_first(const fv3_ctx *c) {
+  int nmax = 0;
+  for (int k = 0; k < c->g.nz; ++k) nmax = std::max(nmax, std::max(c->nord_v_h[k], std::max(c->nord_w_h[k], c->nord_t_h[k])));
+  const char *sc_env = getenv("FV3_DSW_SCALARS");
+  return !(sc_env && !strcmp(sc_env, "separate")) && nmax <= 2 && c->zeros;
+}
+
 // o_*: where the new delp / pt / w / q_con go.  Null: in place (the operator's own contract: the marches write beside the old
 // fields, which their neighbours still read, and a copy-back follows); fv3_acoustic_step hands in the other half of its
 // ping-pong pair instead and the copy-back disappears.
@@ -853,6 +863,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   // FV3_DSW_SCALARS=separate: the four transports as four launches + the division kernel (round-1 form, A/B reference)
   const char *sc_env = getenv("FV3_DSW_SCALARS");  // (read per call: the A/B parity test flips it in one process)
   const bool fused_scalars = !(sc_env && !strcmp(sc_env, "separate")) && nord_max_v <= 2 && nord_max_t <= 2 && nord_max_w <= 2;
+  if (c->seq_acc_first && !fused_scalars) return fv3_fail(c, FV3_ERR_ARG, "d_sw: the sequencer's first-sub-step form of the accumulators needs the fused scalar marches");
   const int scalars_mode = sc_env && !strcmp(sc_env, "quad") ? 0 : 1;
   if (fused_scalars) {
     // ---- air mass, vertical velocity, condensate, potential temperature: the four del-n chains (bandwidth-bound, the
@@ -894,6 +905,8 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     fv3_wait(c, s, 1);
     DswScalars q4{delp, w, q_con, pt, n_dp, n_w, n_qc, n_pt, heat_s, crx, cry, xfx, yfx, mfx, mfy, gx, gy, dA_x, dA_y, dQ_x, dQ_y, dB_x, dB_y, dC_x, dC_y,
                   cf.hord_dp, cf.hord_vt, cf.hord_tm, dn_vt, dn_t, dt, dn_w, fd_k0};
+    q4.acc_first = c->seq_acc_first;
+    q4.zeros = c->zeros;
     dsw_scalars_stream(c, s, q4, scalars_mode);
     if (!oop) launch3<4>(c, s, Box{1, g.nx, 1, g.ny, 0, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);

@@ -1128,32 +1128,53 @@ static void edge_profile_reg(fv3_ctx *c, fv3_stream_t s, const Real *crx, const 
 //           code, 2.5 TB/s);
 //   NZ = 0: any level count -- rolled loops, the forward-eliminated values sit in the lane's LDS line,
 //           inputs prefetched 16 levels ahead (LDS-limited to 4 waves / CU at L79: latency-bound, 3.3 TB/s).
+struct EpSet {  // the fields of one launch as element offsets from the first one's pointers
+  long din[4], dout[4];
+  int n;
+};
 template <int NZ>
-static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *qe, bool xf);
+static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *qe, bool xf, EpSet set = EpSet{{0, 0, 0, 0}, {0, 0, 0, 0}, 1});
 template <int NZ>
 static void edge_profile_wave(fv3_ctx *c, fv3_stream_t s, const Real *crx, const Real *xfx, const Real *cry, const Real *yfx, Real *crx_a, Real *xfx_a, Real *cry_a,
                               Real *yfx_a) {
   // one launch per field: the field pointers stay kernel arguments (selecting among them inside the kernel
   // turns every access into a flat load through a scratch copy of the argument block)
+  // Round 5 (review item 2): FV3_EP_ONE_LAUNCH=1 runs the four solves as ONE launch -- the field of a wave is a wave-uniform ELEMENT OFFSET from
+  // the first field's pointer (four integers among the kernel arguments), so every access stays a global load off one base.  Experiment R5-22.
+  static const bool one = getenv("FV3_EP_ONE_LAUNCH") && getenv("FV3_EP_ONE_LAUNCH")[0] == '1';
+  if (one) {
+    const EpSet set{{0, (long)(xfx - crx), (long)(cry - crx), (long)(yfx - crx)}, {0, (long)(xfx_a - crx_a), (long)(cry_a - crx_a), (long)(yfx_a - crx_a)}, 4};
+    edge_profile_wave1<NZ>(c, s, crx, crx_a, true, set);
+    return;
+  }
   edge_profile_wave1<NZ>(c, s, crx, crx_a, true);
   edge_profile_wave1<NZ>(c, s, xfx, xfx_a, true);
   edge_profile_wave1<NZ>(c, s, cry, cry_a, false);
   edge_profile_wave1<NZ>(c, s, yfx, yfx_a, false);
 }
 template <int NZ>
-static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q, Real *qe, bool xf) {
+static void edge_profile_wave1(fv3_ctx *c, fv3_stream_t s, const Real *q0, Real *qe0, bool xf0, EpSet set) {
   const Geo g = c->g;
   const int nz = g.nz;
   const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
   const int nix = g.nx + 1, ncx = nix * (jed - jsd + 1);  // x-face fields: i in [1, nx+1], every j
   const int niy = ied - isd + 1, ncy = niy * (g.ny + 1);  // y-face fields: every i, j in [1, ny+1]
-  const int ni = xf ? nix : niy, ncol = xf ? ncx : ncy, i0 = xf ? 1 : isd, j0 = xf ? jsd : 1;
+  const int nfield = set.n, nsub = g.nsub;
+  const int ncmax = nfield > 1 ? (ncx > ncy ? ncx : ncy) : (xf0 ? ncx : ncy);
   const long st = g.st, sk = g.sk;
   const int sj32 = g.sj32, go = g.o;
   const Real *gkt = g.ep_gk, *bett = g.ep_bet, *gamd = g.ep_gam;
   constexpr int WPE = NZ == 0 ? 1 : (NZ > 100 ? 1 : 2);
-  launch_waves<WPE>(c, s, (ncol + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub, NZ == 0 ? sizeof(Real) * nz * FV3_WAVE : 0, [=] FV3_HD(const Blk &blk, char *smem_) {
-    const long tb = blk.bz * st;
+  launch_waves<WPE>(c, s, (ncmax + FV3_WAVE - 1) / FV3_WAVE, 1, g.nsub * nfield, NZ == 0 ? sizeof(Real) * nz * FV3_WAVE : 0, [=] FV3_HD(const Blk &blk, char *smem_) {
+    // (set of four: fields 0, 1 are x-face fields, 2, 3 y-face fields)
+    const int f = nfield > 1 ? blk.bz / nsub : 0;
+    const bool xf = nfield > 1 ? f < 2 : xf0;
+    const long din = f == 0 ? set.din[0] : f == 1 ? set.din[1] : f == 2 ? set.din[2] : set.din[3];
+    const long dout = f == 0 ? set.dout[0] : f == 1 ? set.dout[1] : f == 2 ? set.dout[2] : set.dout[3];
+    const Real *const q = q0 + din;
+    Real *const qe = qe0 + dout;
+    const int ni = xf ? nix : niy, ncol = xf ? ncx : ncy, i0 = xf ? 1 : isd, j0 = xf ? jsd : 1;
+    const long tb = (blk.bz - f * nsub) * st;
     FV3_LANES(blk, lane, l) {
       const int cidx = blk.bx * FV3_WAVE + lane;
       if (cidx >= ncol) continue;

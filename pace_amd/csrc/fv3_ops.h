@@ -116,9 +116,14 @@ struct DswScalars {
   Real dt;
   Deln dn_w;  // w's chain (fused form: the march runs it; the other forms only test its switch through g.damp_w)
   int fd_k0;  // levels >= fd_k0 run the del-n chains inside the marches (every chain of order 2 there); nz = never
+  // first sub-step of an acoustic call inside the sequencer (fv3_ctx::seq_acc_first): mfx / mfy hold nothing yet -- the marches add the flux to a zero
+  // read from `zeros` (4 KB, always cached) instead of reading the fields
+  bool acc_first = false;
+  const Real *zeros = nullptr;
 };
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
+bool dsw_honors_acc_first(const fv3_ctx *c);  // (fv3_dsw.hip)
 
 // Does the (strip, segment) tile of a scalar march touch a cube corner of its sub-domain (flags fl)?  Such tiles have the rare paths of the
 // marches in them -- the corner-halo remaps of the rows outside 1..nM, the del-n fluxes read from the FV3_D6_PATCH^2 corner patches -- and

@@ -214,6 +214,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->pp_n = 0;
       c->frame_pass = 0;
       c->seq_divgd_dead = false;
+      c->seq_acc_first = false;
     }
   } pp_guard{c};
 
@@ -230,11 +231,19 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   // "Empty the flux capacitors" (dyn_core.F90): the accumulated mass fluxes / Courant numbers cover ONE call -- the tracer
   // advection that follows each call consumes exactly them (dp2 = dp1 + div(mfx) must be the air mass after this call)
   (void)n_map;
+  // Round 5: the first sub-step's d_sw STORES 0 + flux instead of accumulating into zeroed fields (fv3_ctx::seq_acc_first: the zero is read from a 4 KB
+  // block, not from the field): four 2.3 GB zero launches and four field reads less per call.  A field is zeroed in full the first time this context sees
+  // it, so that the cells d_sw never writes (allocation padding, halo corners) hold the zeros the reference's arrays hold; nothing else writes them.
+  // FV3_ACC_STORE=0: zero + accumulate on every sub-step (A/B; same bits: 0 + x is what the accumulation computes on a zeroed field).
+  const char *acc_env = getenv("FV3_ACC_STORE");  // (read per call: the parity test flips it in one process)
+  const bool acc_store = !(acc_env && acc_env[0] == '0') && n_split > 0 && dsw_honors_acc_first(c);
   {
-    RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfxd, stream));
-    RUN(FV3_OP_GLUE, fv3_zero(c, &st->mfyd, stream));
-    RUN(FV3_OP_GLUE, fv3_zero(c, &st->cxd, stream));
-    RUN(FV3_OP_GLUE, fv3_zero(c, &st->cyd, stream));
+    const fv3_field *acc[4] = {&st->mfxd, &st->mfyd, &st->cxd, &st->cyd};
+    for (int a = 0; a < 4; ++a)
+      if (!acc_store || c->acc_zeroed[a] != acc[a]->ptr) {
+        RUN(FV3_OP_GLUE, fv3_zero(c, acc[a], stream));
+        c->acc_zeroed[a] = acc_store ? acc[a]->ptr : nullptr;
+      }
   }
   if (n_map == 1 || !fv3_alt("heat_zero_first_call"))  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
     RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
@@ -302,15 +311,19 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
         return st_;
       };
       c->seq_divgd_dead = getenv("FV3_SEQ_KEEP_DIVGD") == nullptr;
+      c->seq_acc_first = acc_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
                                     &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
                                     stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt], +start_halo, &mid));
       c->seq_divgd_dead = false;
+      c->seq_acc_first = false;
       cur = nxt;
       c->pp_n = cur ? 4 : 0;
     } else {
+      c->seq_acc_first = acc_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
                                 &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+      c->seq_acc_first = false;
       HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     }
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);

@@ -64,6 +64,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
   const Real *const q0f = AIR ? a.delp : a.q_con, *const q1f = AIR ? a.w : a.pt;
   const Real *const crL = a.crx, *const crM = a.cry, *const afL = a.xfx, *const afM = a.yfx;
   Real *const accL = a.mfx, *const accM = a.mfy;          // AIR: accumulated air-mass fluxes (read + written)
+  const bool acc_first = AIR && a.acc_first && a.zeros;
+  const Real *const zerosb = a.zeros;
   Real *const flL = a.fx, *const flM = a.fy;              // air-mass fluxes of the sub-step: AIR writes, TRC reads
   const Real *const oldm = a.delp;                        // TRC: the old air mass
   Real *const out0 = AIR ? a.o_delp : a.o_q_con, *const out1 = AIR ? a.o_w : a.o_pt, *const heat = a.heat;
@@ -116,6 +118,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     const Real *const dxab = (const Real *)gdxa + m2;
     const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6Lb = (const Real *)gd6L + m2, *const d6Mb = (const Real *)gd6M + m2;
     Real *const accLb = accL + b, *const accMb = accM + b, *const flLb = flL + b, *const flMb = flM + b;
+    // (first sub-step of a call inside the sequencer: the accumulators hold nothing -- the "old value" is read from 2 KB of zeros, an access that always hits)
+    const Real *const accLb_ld = acc_first ? zerosb : accLb, *const accMb_ld = acc_first ? zerosb : accMb;
     const Real *const oldmb = oldm + b;
     Real *const out0b = out0 + b, *const out1b = out1 + b, *const heatb = heat + b;
     const Real damp_vt = deln_damp(dn_vt, k), damp_t = deln_damp(dn_t, k);
@@ -178,8 +182,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       const int r3 = GEN ? (r - 3 < Msd ? Msd : r - 3) : r - 3, rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
       const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
       if constexpr (AIR) {
-        Ox[q][l] = px_ld3(accLb, p3);
-        Oy[q][l] = px_ld3(accMb, pf);
+        Ox[q][l] = px_ld3(accLb_ld, acc_first ? (p3 & 0x7f8u) : p3);
+        Oy[q][l] = px_ld3(accMb_ld, acc_first ? (pf & 0x7f8u) : pf);
       } else {
         Ox[q][l] = px_ld3(flLb, p3);
         Oy[q][l] = px_ld3(flMb, pf);

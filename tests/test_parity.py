@@ -473,6 +473,24 @@ def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend,
             assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, kw, n_calls", [(24, (2, 2), dict(n_split=3), 2), (130, (1, 1), dict(n_split=2), 1)])
+def test_first_sub_step_store_of_the_flux_accumulators_is_bitwise_zero_plus_accumulate(backend, monkeypatch, n, layout, kw, n_calls):
+    """fv3_acoustic_step's first sub-step has d_sw STORE 0 + flux into mfx / mfy / cx / cy (the zero read from a 4 KB block; four zero launches and
+    four field reads less per call) against zeroing the four fields and accumulating on every sub-step as the reference does (FV3_ACC_STORE=0):
+    every field bitwise equal, the accumulators included -- over two calls (the second one finds arrays the first call has filled)."""
+    nz = 5
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, kw)
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV3_ACC_STORE", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=n_calls)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["1"][r][name], res["0"][r][name]), f"{name} rank {r}"
+        assert np.abs(res["1"][r]["mfxd"]).max() > 0.0 and np.abs(res["1"][r]["cxd"]).max() > 0.0
+
+
 @pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])
 def test_height_del_n_chain_inside_the_transport_march_is_bitwise_the_del6_launch(backend, monkeypatch, n, layout):
     """update_dz_d: the del-n chain of the interface heights run inside the transport march (tp2d_stream_t TF_FD, strips away from
