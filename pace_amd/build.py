@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 HOSTEMU_DIR = os.path.join(ROOT, "tests", "_hostemu")
 
-SOURCES = ["fv3_ctx.hip", "fv3_tp2d.hip", "fv3_tp2x.hip", "fv3_tp4.hip", "fv3_tp4x.hip", "fv3_a2b.hip", "fv3_csw.hip", "fv3_dsw.hip", "fv3_nh.hip", "fv3_pgf.hip", "fv3_step.hip", "fv3_halo.hip", "fv3_tracer.hip", "fv3_remap.hip"]
+SOURCES = ["fv3_ctx.hip", "fv3_tp2d.hip", "fv3_tp2x.hip", "fv3_tp4.hip", "fv3_tp4x.hip", "fv3_a2b.hip", "fv3_csw.hip", "fv3_dsw.hip", "fv3_nh.hip", "fv3_del2x.hip", "fv3_pgf.hip", "fv3_step.hip", "fv3_halo.hip", "fv3_tracer.hip", "fv3_remap.hip"]
 HEADERS = ["fv3_common.h", "fv3_ops.h", "fv3_ppm.h", "fv3_a2b.h", "fv3_math.h", "fv3_agpr.h", "fv3_march.h", os.path.join("..", "..", "include", "fv3_mi355x.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1479,6 +1479,35 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, const fv3_field *u_, const fv3_field *v_
   return fv3_post(c, (fv3_stream_t)stream, "ray_fast");
 }
 
+// the three cells at every cube corner of a sub-domain become their mean (del2_cubed, before each iteration), in place
+void del2_fill_corners(fv3_ctx *c, fv3_stream_t s, Real *qin) {
+  const Geo g = c->g;
+  const int nz1 = g.nz - 1;
+  launch3(c, s, Box{1, 1, 1, 1, 0, nz1}, [=] FV3_HD(int t, int k, int, int) {
+    const int fl = g.flags[t];
+    const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
+    Real *qq = qin + t * g.st + k * g.sk;
+    const int npx = g.npx, npy = g.npy, ie = g.nx, je = g.ny;
+    const Real r3 = (Real)(1.0 / 3.0);
+    if (W && S) {
+      const Real a = (qq[IX(1, 1)] + qq[IX(0, 1)] + qq[IX(1, 0)]) * r3;
+      qq[IX(1, 1)] = a; qq[IX(0, 1)] = a; qq[IX(1, 0)] = a;
+    }
+    if (E && S) {
+      const Real a = (qq[IX(ie, 1)] + qq[IX(npx, 1)] + qq[IX(ie, 0)]) * r3;
+      qq[IX(ie, 1)] = a; qq[IX(npx, 1)] = a; qq[IX(ie, 0)] = a;
+    }
+    if (E && N) {
+      const Real a = (qq[IX(ie, je)] + qq[IX(npx, je)] + qq[IX(ie, npy)]) * r3;
+      qq[IX(ie, je)] = a; qq[IX(npx, je)] = a; qq[IX(ie, npy)] = a;
+    }
+    if (W && N) {
+      const Real a = (qq[IX(1, je)] + qq[IX(0, je)] + qq[IX(1, npy)]) * r3;
+      qq[IX(1, je)] = a; qq[IX(0, je)] = a; qq[IX(1, npy)] = a;
+    }
+  });
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int nmax, void *stream) {
   if (!c) return FV3_ERR_ARG;
@@ -1502,29 +1531,7 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, const fv3_field *q_, double cdd, int n
     Real *out = nt == 0 ? (ntimes == 1 ? bufA : q) : (nt % 2 ? bufA : bufB);
     if (out == in) out = out == bufA ? bufB : bufA;
     Real *qin = in;
-    launch3(c, s, Box{1, 1, 1, 1, 0, nz1}, [=] FV3_HD(int t, int k, int, int) {
-      const int fl = g.flags[t];
-      const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
-      Real *qq = qin + t * g.st + k * g.sk;
-      const int npx = g.npx, npy = g.npy, ie = g.nx, je = g.ny;
-      const Real r3 = (Real)(1.0 / 3.0);
-      if (W && S) {
-        const Real a = (qq[IX(1, 1)] + qq[IX(0, 1)] + qq[IX(1, 0)]) * r3;
-        qq[IX(1, 1)] = a; qq[IX(0, 1)] = a; qq[IX(1, 0)] = a;
-      }
-      if (E && S) {
-        const Real a = (qq[IX(ie, 1)] + qq[IX(npx, 1)] + qq[IX(ie, 0)]) * r3;
-        qq[IX(ie, 1)] = a; qq[IX(npx, 1)] = a; qq[IX(ie, 0)] = a;
-      }
-      if (E && N) {
-        const Real a = (qq[IX(ie, je)] + qq[IX(npx, je)] + qq[IX(ie, npy)]) * r3;
-        qq[IX(ie, je)] = a; qq[IX(npx, je)] = a; qq[IX(ie, npy)] = a;
-      }
-      if (W && N) {
-        const Real a = (qq[IX(1, je)] + qq[IX(0, je)] + qq[IX(1, npy)]) * r3;
-        qq[IX(1, je)] = a; qq[IX(0, je)] = a; qq[IX(1, npy)] = a;
-      }
-    });
+    del2_fill_corners(c, s, qin);
     launch3(c, s, Box{isd, ied, jsd, jed, 0, nkc - 1}, [=] FV3_HD(int t, int kp, int i_, int j_) {
       const int fl = g.flags[t];
       const long m2 = t * g.st2;

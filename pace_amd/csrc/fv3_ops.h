@@ -124,6 +124,10 @@ struct DswScalars {
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
 bool dsw_honors_acc_first(const fv3_ctx *c);  // (fv3_dsw.hip)
+void del2_fill_corners(fv3_ctx *c, fv3_stream_t s, Real *qin);  // (fv3_nh.hip)
+// fv3_del2x.hip: del2_cubed (three iterations) + apply_diffusive_heating as one pass; 1 = no fused form for this configuration
+int fv3_del2_heat_fused(fv3_ctx *c, const fv3_field *q, double cd, int nmax, const fv3_field *delp, const fv3_field *delz, const fv3_field *cappa,
+                        const fv3_field *pt, double delt, bool keep_q, void *stream);
 
 // Does the (strip, segment) tile of a scalar march touch a cube corner of its sub-domain (flags fl)?  Such tiles have the rare paths of the
 // marches in them -- the corner-halo remaps of the rows outside 1..nM, the del-n fluxes read from the FV3_D6_PATCH^2 corner patches -- and

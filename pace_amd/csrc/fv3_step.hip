@@ -400,9 +400,20 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     const double cd = 0.20 * c->g.da_min;
     int nmax = cf.nord + 1;
     if (nmax > 3) nmax = 3;
-    RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_del2_cubed(c, &ws->heat_source, cd, nmax, stream));
     const double delt = (fv3_alt("heat_dt_full") ? timestep : dt) * cf.delt_max;  // (FV3_ALT: DESIGN §2, uncertain restatement 2)
-    RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_apply_diffusive_heating(c, &st->delp, &st->delz, &st->cappa, &ws->heat_source, &st->pt, delt < 0 ? -delt : delt, stream));
+    // Round 5: the three smoothing iterations and the heating of pt as one pass (fv3_del2x.hip; the smoothed field is stored only when the heat
+    // is kept over calls -- FV3_ALT heat_zero_first_call); 1 = no fused form for this configuration (fewer iterations, tiny sub-domains,
+    // FV3_DEL2_FUSED=0): the two staged operators, same bits.
+    int fused_st;
+    {
+      OpTimer tm_(c, s, FV3_OP_DIFFUSIVE_HEATING);
+      fused_st = fv3_del2_heat_fused(c, &ws->heat_source, cd, nmax, &st->delp, &st->delz, &st->cappa, &st->pt, delt < 0 ? -delt : delt, fv3_alt("heat_zero_first_call"), stream);
+    }
+    if (fused_st != FV3_OK && fused_st != 1) return fused_st;
+    if (fused_st == 1) {
+      RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_del2_cubed(c, &ws->heat_source, cd, nmax, stream));
+      RUN(FV3_OP_DIFFUSIVE_HEATING, fv3_apply_diffusive_heating(c, &st->delp, &st->delz, &st->cappa, &ws->heat_source, &st->pt, delt < 0 ? -delt : delt, stream));
+    }
   }
   return FV3_OK;
 }

@@ -473,6 +473,28 @@ def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend,
             assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, alt", [(12, (1, 1), ""), (24, (2, 2), ""), (59, (1, 1), ""), (140, (2, 2), ""), (130, (1, 1), ""), (24, (1, 1), "heat_zero_first_call")])
+def test_fused_smoothing_and_heating_is_bitwise_the_staged_operators(backend, monkeypatch, n, layout, alt):
+    """fv3_acoustic_step's damping-heat tail as one pass (fv3_del2x.hip: three del2_cubed iterations in LDS + apply_diffusive_heating) against the staged
+    operators (three launches + the heating kernel, FV3_DEL2_FUSED=0): every field bitwise equal.  The sizes put tile boundaries of the fused kernel at
+    their natural places (C130, C24) and at the shifted ones next to the far tile edge (12 and 70 rows: boundary moved in j; 59 columns: in i), with one
+    and with several cube corners per tile; under FV3_ALT=heat_zero_first_call the smoothed heat is kept and carried into a second call."""
+    nz = 5
+    if alt:
+        monkeypatch.setenv("FV3_ALT", alt)
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("tiles", "tiles+heat", "staged"):  # (default: LDS-tile smoothing + heating launch; heating as the tile kernel's epilogue; round-4 operators)
+        monkeypatch.setenv("FV3_DEL2_FUSED", "0" if mode == "staged" else "1")
+        monkeypatch.setenv("FV3_DEL2_HEAT", "fused" if mode == "tiles+heat" else "split")
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2 if alt else 1)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["tiles"][r][name], res["staged"][r][name]), f"{name} rank {r}"
+            assert np.array_equal(res["tiles+heat"][r][name], res["staged"][r][name]), f"{name} rank {r} (heating in the tile kernel)"
+
+
 @pytest.mark.parametrize("n, layout, kw, n_calls", [(24, (2, 2), dict(n_split=3), 2), (130, (1, 1), dict(n_split=2), 1)])
 def test_first_sub_step_store_of_the_flux_accumulators_is_bitwise_zero_plus_accumulate(backend, monkeypatch, n, layout, kw, n_calls):
     """fv3_acoustic_step's first sub-step has d_sw STORE 0 + flux into mfx / mfy / cx / cy (the zero read from a 4 KB block; four zero launches and
