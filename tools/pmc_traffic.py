@@ -11,6 +11,7 @@ kernel (reads N*8 B, writes N*8 B): the script prints the raw per-launch values 
 to its known byte count and applies that ratio (read_scale / write_scale) to every kernel.
 """
 import csv
+import os
 import re
 import sys
 from collections import defaultdict
@@ -85,7 +86,8 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, j
                 import json
 
                 json.dump({"csrc_hash": _src_hash(), "window": [first, last], "launches": n1, "read_bytes": r * kb * rs, "write_bytes": w * kb * ws, "bytes": r * kb * rs + w * kb * ws,
-                           "read_scale": rs, "write_scale": ws, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"},
+                           "read_scale": rs, "write_scale": ws, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"
+                           + ("; " + os.environ["FV3_PMC_NOTE"] if os.environ.get("FV3_PMC_NOTE") else "")},
                           open(json_out, "w"))
     print("| kernel | calls | avg ms (pmc run) | read GB/launch | write GB/launch | GB/s |")
     print("|---|---:|---:|---:|---:|---:|")

@@ -5,6 +5,7 @@ set -u
 tag=${1:-sq}
 shift || true
 for kv in "$@"; do export "$kv"; done
+export FV3_ACC_STORE=0  # (the profiled sub-step is the first of its call: run the accumulating form the other five sub-steps run, as tools/collect_profiles.sh does)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
