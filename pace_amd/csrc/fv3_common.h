@@ -266,8 +266,9 @@ struct fv3_ctx {
   // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (4 KB of zeros: always a cache hit) instead of the field, and the sequencer
   // does not zero the fields first (fv3_step.hip; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
   bool seq_acc_first = false;
+  bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step
   Real *zeros = nullptr;
-  const void *acc_zeroed[4] = {nullptr, nullptr, nullptr, nullptr};  // the accumulator arrays this context has zeroed in full once
+  const void *acc_zeroed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the accumulator arrays this context has zeroed in full once (mfx, mfy, cx, cy, heat_source)
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;

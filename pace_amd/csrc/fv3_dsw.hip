@@ -1265,7 +1265,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // increments are not stored and the damping-heat kernel below only serves the levels under fdw_k0.  FV3_DSW_HEAT=separate: the round-4
     // sequence (A/B; read per call).
     const char *he = getenv("FV3_DSW_HEAT");
-    const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source};
+    const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source, c->seq_heat_first ? c->zeros : nullptr};
     if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1)) {
       e.heat = &th;
       heat_k1 = fdw_k0 - 1;
@@ -1275,6 +1275,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   }
 
   const bool heat_on = cf.d_con > 1.0e-5;
+  const bool heat_first = c->seq_heat_first;  // (the sequencer's first sub-step of a call: heat_source holds nothing yet -- 0 + heat, the field is not read)
   // (two levels per thread: the six metric terms are read once)
   if (heat_k1 >= 0) launch3(c, s, Box{1, g.nx, 1, g.ny, 0, (heat_k1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
@@ -1301,7 +1302,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         hs = (o_delp + b)[p] * (hs - (Real)0.25 * dcon * rs2 *
                                      ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + (Real)2.0 * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2)));
       }
-      if (heat_on) FV3_ST_NT((heat_source + b)[p], (heat_source + b)[p] + hs);
+      if (heat_on) FV3_ST_NT((heat_source + b)[p], (heat_first ? (Real)0 : (heat_source + b)[p]) + hs);
     }
   });
   return fv3_post(c, s, "d_sw");

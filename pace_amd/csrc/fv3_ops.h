@@ -153,6 +153,7 @@ struct TpEpi;
 struct TpHeat {
   const Real *vdamp, *ndelp, *heat_s, *dcon;
   Real *heat_src;
+  const Real *zeros = nullptr;  // non-null: first sub-step of a call inside the sequencer -- the accumulated heat is read as zero from this block, not from heat_src
 };
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
                        const TpEpi *epi, const TpHeat *heat = nullptr);

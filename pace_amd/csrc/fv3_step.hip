@@ -215,6 +215,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->frame_pass = 0;
       c->seq_divgd_dead = false;
       c->seq_acc_first = false;
+      c->seq_heat_first = false;
     }
   } pp_guard{c};
 
@@ -245,16 +246,27 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
         c->acc_zeroed[a] = acc_store ? acc[a]->ptr : nullptr;
       }
   }
-  if (n_map == 1 || !fv3_alt("heat_zero_first_call"))  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
+  // (the accumulated damping heat the same way: zeroed in full once per context, then the first sub-step's d_sw forms 0 + heat without reading it)
+  const bool heat_reset = n_map == 1 || !fv3_alt("heat_zero_first_call");  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
+  const bool heat_store = acc_store && heat_reset && cf.d_con > 1.0e-5;
+  if (heat_reset && (!heat_store || c->acc_zeroed[4] != ws->heat_source.ptr)) {
     RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
+    c->acc_zeroed[4] = heat_store ? ws->heat_source.ptr : nullptr;
+  }
   RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
+  const char *gz_env = getenv("FV3_GZ_FIRST");  // (read per call: the parity test flips it in one process)
+  const bool gz_direct = !(gz_env && !strcmp(gz_env, "copy"));
   for (int it = 0; it < n_split; ++it) {
     const int remap_step = it == n_split - 1;
     if (!w_started) HALO(FV3_HALO_W, 0);
     w_started = false;
     if (it == 0) {
-      RUN(FV3_OP_GLUE, fv3_set_gz(c, &ws->zs, &st->delz, &ws->gz, stream));
-      HALO(FV3_HALO_GZ, 0);
+      // Round 5: the heights of the call go straight into zh (with zh's halo plan) and update_dz_c runs its zh -> gz form, as in every other sub-step:
+      // no gz -> zh copy (0.8 ms) and no in-place update_dz_c (two kernels, 4.6 ms, instead of one, 2.6).  The reference fills gz, updates its halo, copies
+      // it to zh and updates gz in place -- the same values in every cell an operator reads (gz's outer halo cells, which only the copy would define, are
+      // read by none).  FV3_GZ_FIRST=copy: the reference's order (A/B; same bits).
+      RUN(FV3_OP_GLUE, fv3_set_gz(c, &ws->zs, &st->delz, gz_direct ? &ws->zh : &ws->gz, stream));
+      HALO(gz_direct ? FV3_HALO_ZH : FV3_HALO_GZ, 0);
       HALO(FV3_HALO_DELP__PT, 1);
     }
     HALO(FV3_HALO_U__V, 1);
@@ -262,7 +274,10 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     RUN(FV3_OP_C_SW, fv3_c_sw(c, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
                               &ws->delpc, &ws->ptc, dt2, stream));
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 0);
-    if (it == 0) {
+    if (it == 0 && gz_direct) {
+      HALO(FV3_HALO_ZH, 1);
+      RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c_from(c, &ws->zs, &ws->ut, &ws->vt, &ws->zh, &ws->gz, &ws->ws3, dt2, stream));
+    } else if (it == 0) {
       HALO(FV3_HALO_GZ, 1);
       RUN(FV3_OP_GLUE, fv3_copy(c, &ws->gz, &ws->zh, stream));
       RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c(c, &ws->zs, &ws->ut, &ws->vt, &ws->gz, &ws->ws3, dt2, stream));
@@ -312,18 +327,22 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       };
       c->seq_divgd_dead = getenv("FV3_SEQ_KEEP_DIVGD") == nullptr;
       c->seq_acc_first = acc_store && it == 0;
+      c->seq_heat_first = heat_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
                                     &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
                                     stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt], +start_halo, &mid));
       c->seq_divgd_dead = false;
       c->seq_acc_first = false;
+      c->seq_heat_first = false;
       cur = nxt;
       c->pp_n = cur ? 4 : 0;
     } else {
       c->seq_acc_first = acc_store && it == 0;
+      c->seq_heat_first = heat_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
                                 &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
       c->seq_acc_first = false;
+      c->seq_heat_first = false;
       HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     }
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);

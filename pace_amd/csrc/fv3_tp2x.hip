@@ -36,6 +36,7 @@ struct SxArgs {
   // heat source (read + written), the per-level fraction d_con
   const Real *vdamp, *ndelp, *heat_s, *dcon;
   Real *heat_src;
+  const Real *heat_zeros = nullptr;  // non-null (first sub-step of a call inside the sequencer): the accumulated heat is read as zero from this 4 KB block
   // HEAT: copies (made before the march) of the u rows / v columns on the boundaries between segments / strips -- see sx_side_copy
   const Real *u_side, *v_side;
   // SX_AREA
@@ -120,6 +121,8 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
     Real *const outb = AREA ? A.out + b : nullptr;
     const Real *const vdb = HEAT ? A.vdamp + b : nullptr, *const ndpb = HEAT ? A.ndelp + b : nullptr, *const hsb = HEAT ? A.heat_s + b : nullptr;
     Real *const hob = HEAT ? A.heat_src + b : nullptr;
+    const bool heat_first = HEAT && A.heat_zeros;
+    const Real *const hob_ld = heat_first ? A.heat_zeros : hob;
     const Real *const rdxb = (const Real *)grdx + m2, *const rdyb = (const Real *)grdy + m2, *const rs2b = (const Real *)grs2 + m2, *const csb = (const Real *)gcs + m2;
     const Real dcon = HEAT ? A.dcon[k] : (Real)0;
     const Real *const usideb = HEAT ? A.u_side + b : nullptr, *const vsideb = HEAT ? A.v_side + b : nullptr;
@@ -198,7 +201,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
           Hcs[q][l] = px_ld(csb, p3);
           Hdp[q][l] = px_ld3(ndpb, p3);
           Hhs[q][l] = px_ld3(hsb, p3);
-          Hho[q][l] = px_ld3(hob, p3);
+          Hho[q][l] = px_ld3(hob_ld, heat_first ? (p3 & 0x7f8u) : p3);
         }
       }
     };
@@ -624,6 +627,7 @@ void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, cons
       a.ndelp = heat->ndelp;
       a.heat_s = heat->heat_s;
       a.heat_src = heat->heat_src;
+      a.heat_zeros = heat->zeros;
       a.dcon = heat->dcon;
       a.u_side = epi->wind_u_pre;  // (the arrays the epilogue makes redundant serve as the side copies)
       a.v_side = epi->wind_v_pre;

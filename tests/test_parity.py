@@ -473,6 +473,22 @@ def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend,
             assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout", [(24, (2, 2)), (48, (1, 1))])
+def test_heights_of_a_call_straight_into_zh_is_bitwise_the_reference_order(backend, monkeypatch, n, layout):
+    """First sub-step of fv3_acoustic_step: set_gz -> zh, zh's halo update, update_dz_c in its zh -> gz form (no gz -> zh copy, no in-place update_dz_c)
+    against the reference's order (gz filled, halo-updated, copied to zh, updated in place; FV3_GZ_FIRST=copy): every field bitwise equal over two calls."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("direct", "copy"):
+        monkeypatch.setenv("FV3_GZ_FIRST", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["direct"][r][name], res["copy"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout, alt", [(12, (1, 1), ""), (24, (2, 2), ""), (59, (1, 1), ""), (140, (2, 2), ""), (130, (1, 1), ""), (24, (1, 1), "heat_zero_first_call")])
 def test_fused_smoothing_and_heating_is_bitwise_the_staged_operators(backend, monkeypatch, n, layout, alt):
     """fv3_acoustic_step's damping-heat tail as one pass (fv3_del2x.hip: three del2_cubed iterations in LDS + apply_diffusive_heating) against the staged
@@ -495,12 +511,15 @@ def test_fused_smoothing_and_heating_is_bitwise_the_staged_operators(backend, mo
             assert np.array_equal(res["tiles+heat"][r][name], res["staged"][r][name]), f"{name} rank {r} (heating in the tile kernel)"
 
 
-@pytest.mark.parametrize("n, layout, kw, n_calls", [(24, (2, 2), dict(n_split=3), 2), (130, (1, 1), dict(n_split=2), 1)])
-def test_first_sub_step_store_of_the_flux_accumulators_is_bitwise_zero_plus_accumulate(backend, monkeypatch, n, layout, kw, n_calls):
+@pytest.mark.parametrize("n, layout, kw, n_calls, alt", [(24, (2, 2), dict(n_split=3), 2, ""), (130, (1, 1), dict(n_split=2), 1, ""), (24, (1, 1), dict(n_split=2), 3, "heat_zero_first_call")])
+def test_first_sub_step_store_of_the_flux_accumulators_is_bitwise_zero_plus_accumulate(backend, monkeypatch, n, layout, kw, n_calls, alt):
     """fv3_acoustic_step's first sub-step has d_sw STORE 0 + flux into mfx / mfy / cx / cy (the zero read from a 4 KB block; four zero launches and
     four field reads less per call) against zeroing the four fields and accumulating on every sub-step as the reference does (FV3_ACC_STORE=0):
-    every field bitwise equal, the accumulators included -- over two calls (the second one finds arrays the first call has filled)."""
+    every field bitwise equal, the accumulators included -- over two calls (the second one finds arrays the first call has filled).  The accumulated
+    damping heat (heat_source) is treated the same way; under FV3_ALT=heat_zero_first_call it is reset by the first call only and carried through the others."""
     nz = 5
+    if alt:
+        monkeypatch.setenv("FV3_ALT", alt)
     part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, kw)
     init = [{k: v.copy() for k, v in s.items()} for s in ost]
     res = {}
