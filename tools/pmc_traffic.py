@@ -76,6 +76,10 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, j
         raw_w = wr[c][1] / wr[c][0] * kb
         rs, ws = copy_bytes / raw_r, copy_bytes / raw_w
         print(f"calibration on {c}: known {copy_bytes / 1e6:.1f} MB each way per launch; raw FETCH_SIZE {raw_r / 1e6:.1f} MB (scale {rs:.3f}), raw WRITE_SIZE {raw_w / 1e6:.1f} MB (scale {ws:.3f})\n")
+    elif copy_bytes:
+        # (the sequencer's default order has no fv3_copy launch any more: the counter passes run with FV3_GZ_FIRST=copy to have one -- tools/collect_profiles.sh)
+        print("NO CALIBRATION KERNEL (fv3_copy) in the counter files: raw counter units below, no traffic file written\n")
+        json_out = None
     if first and last:
         r, n1 = window(fetch_csv, "FETCH_SIZE", first, last)
         w, n2 = window(write_csv, "WRITE_SIZE", first, last)
