@@ -263,7 +263,7 @@ struct fv3_ctx {
   // set by fv3_acoustic_step around its d_sw call: the workspace divgd is dead after the operator (the next c_sw overwrites it)
   bool seq_divgd_dead = false;
   // set by fv3_acoustic_step around the d_sw call of a call's FIRST sub-step: the four accumulators of the tracer sub-cycling (mfx, mfy, cx, cy) hold
-  // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (4 KB of zeros: always a cache hit) instead of the field, and the sequencer
+  // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (one level plane of zeros, 1.2 MB at C768: it stays in L2) instead of the field, and the sequencer
   // does not zero the fields first (fv3_step.hip; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
   bool seq_acc_first = false;
   bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step

@@ -382,7 +382,7 @@ int fv3_ctx_create(fv3_ctx **out, const fv3_gridspec *spec, const fv3_griddata *
   }
 #endif
   {
-    const std::vector<Real> z(4096 / sizeof(Real), (Real)0);
+    const std::vector<Real> z((size_t)g.sk, (Real)0);  // (one level plane: the marches read it with the in-plane offsets of the field it stands in for)
     c->zeros = (Real *)upload(c, z);
     if (!c->zeros) {
       fv3_ctx_destroy(c);

@@ -117,7 +117,7 @@ struct DswScalars {
   Deln dn_w;  // w's chain (fused form: the march runs it; the other forms only test its switch through g.damp_w)
   int fd_k0;  // levels >= fd_k0 run the del-n chains inside the marches (every chain of order 2 there); nz = never
   // first sub-step of an acoustic call inside the sequencer (fv3_ctx::seq_acc_first): mfx / mfy hold nothing yet -- the marches add the flux to a zero
-  // read from `zeros` (4 KB, always cached) instead of reading the fields
+  // read from `zeros` (one level plane, read with the field's own in-plane offsets; it stays in L2) instead of reading the fields
   bool acc_first = false;
   const Real *zeros = nullptr;
 };

@@ -232,7 +232,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   // "Empty the flux capacitors" (dyn_core.F90): the accumulated mass fluxes / Courant numbers cover ONE call -- the tracer
   // advection that follows each call consumes exactly them (dp2 = dp1 + div(mfx) must be the air mass after this call)
   (void)n_map;
-  // Round 5: the first sub-step's d_sw STORES 0 + flux instead of accumulating into zeroed fields (fv3_ctx::seq_acc_first: the zero is read from a 4 KB
+  // Round 5: the first sub-step's d_sw STORES 0 + flux instead of accumulating into zeroed fields (fv3_ctx::seq_acc_first: the zero is read from a one-plane
   // block, not from the field): four 2.3 GB zero launches and four field reads less per call.  A field is zeroed in full the first time this context sees
   // it, so that the cells d_sw never writes (allocation padding, halo corners) hold the zeros the reference's arrays hold; nothing else writes them.
   // FV3_ACC_STORE=0: zero + accumulate on every sub-step (A/B; same bits: 0 + x is what the accumulation computes on a zeroed field).

@@ -36,7 +36,7 @@ struct SxArgs {
   // heat source (read + written), the per-level fraction d_con
   const Real *vdamp, *ndelp, *heat_s, *dcon;
   Real *heat_src;
-  const Real *heat_zeros = nullptr;  // non-null (first sub-step of a call inside the sequencer): the accumulated heat is read as zero from this 4 KB block
+  const Real *heat_zeros = nullptr;  // non-null (first sub-step of a call inside the sequencer): the accumulated heat is read as zero from this one-plane block of zeros
   // HEAT: copies (made before the march) of the u rows / v columns on the boundaries between segments / strips -- see sx_side_copy
   const Real *u_side, *v_side;
   // SX_AREA
@@ -201,7 +201,7 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
           Hcs[q][l] = px_ld(csb, p3);
           Hdp[q][l] = px_ld3(ndpb, p3);
           Hhs[q][l] = px_ld3(hsb, p3);
-          Hho[q][l] = px_ld3(hob_ld, heat_first ? (p3 & 0x7f8u) : p3);
+          Hho[q][l] = px_ld3(hob_ld, p3);
         }
       }
     };

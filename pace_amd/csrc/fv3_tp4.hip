@@ -352,8 +352,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       const int r3 = r - 3 < Msd ? Msd : r - 3, rf = r - 2 < Msd ? Msd : r - 2;
       const unsigned p3 = pcol[l] + (unsigned)(r3 * MS), pf = pcol[l] + (unsigned)(rf * MS);
       if constexpr (HAS_AIR) {
-        n_ax[l] = (a.acc_first ? a.zeros : a.mfx + b)[a.acc_first ? (p3 & 255u) : p3];
-        n_ay[l] = (a.acc_first ? a.zeros : a.mfy + b)[a.acc_first ? (pf & 255u) : pf];
+        n_ax[l] = (a.acc_first ? a.zeros : a.mfx + b)[p3];
+        n_ay[l] = (a.acc_first ? a.zeros : a.mfy + b)[pf];
       } else {
         n_mx[l] = (a.fx + b)[p3];
         n_my[l] = (a.fy + b)[pf];

@@ -118,7 +118,7 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     const Real *const dxab = (const Real *)gdxa + m2;
     const Real *const areab = (const Real *)garea + m2, *const rab = (const Real *)grarea + m2, *const d6Lb = (const Real *)gd6L + m2, *const d6Mb = (const Real *)gd6M + m2;
     Real *const accLb = accL + b, *const accMb = accM + b, *const flLb = flL + b, *const flMb = flM + b;
-    // (first sub-step of a call inside the sequencer: the accumulators hold nothing -- the "old value" is read from 2 KB of zeros, an access that always hits)
+    // (first sub-step of a call inside the sequencer: the accumulators hold nothing -- the "old value" is read from one plane of zeros, which stays in L2)
     const Real *const accLb_ld = acc_first ? zerosb : accLb, *const accMb_ld = acc_first ? zerosb : accMb;
     const Real *const oldmb = oldm + b;
     Real *const out0b = out0 + b, *const out1b = out1 + b, *const heatb = heat + b;
@@ -182,8 +182,8 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       const int r3 = GEN ? (r - 3 < Msd ? Msd : r - 3) : r - 3, rf = GEN ? (r - 2 < Msd ? Msd : r - 2) : r - 2;
       const unsigned p3 = pcolB[l] + (unsigned)r3 * rowB, pf = pcolB[l] + (unsigned)rf * rowB;
       if constexpr (AIR) {
-        Ox[q][l] = px_ld3(accLb_ld, acc_first ? (p3 & 0x7f8u) : p3);
-        Oy[q][l] = px_ld3(accMb_ld, acc_first ? (pf & 0x7f8u) : pf);
+        Ox[q][l] = px_ld3(accLb_ld, p3);
+        Oy[q][l] = px_ld3(accMb_ld, pf);
       } else {
         Ox[q][l] = px_ld3(flLb, p3);
         Oy[q][l] = px_ld3(flMb, pf);
