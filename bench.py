@@ -345,11 +345,13 @@ def main():
             valu_floor_clk = vrec.get("valu_floor_ms_measured_clock") if vrec else None
             clk = vrec.get("clock_hz_measured") if vrec else None
             hbm_floor = alg / (HBM_PEAK_GBPS * 1e9) * 1e3
-            # bound: whichever floor of the call is higher (the VALU floor at the clock the chip held while the counters were taken, when known)
+            # bound: whichever floor of the call is higher -- the HBM floor of the bytes the call actually moves (the measured traffic when the committed
+            # counter file is current, else the algorithmic bytes) against the VALU floor at the clock the chip held while the counters were taken
             vf = valu_floor_clk or valu_floor
+            hbm_floor_traffic = (traffic / (HBM_PEAK_GBPS * 1e9) * 1e3) if traffic else None
             line["roofline"] = {
                 "kernel": "d_sw (all launches of one fv3_d_sw call)",
-                "bound": "hbm" if (vf is None or hbm_floor >= vf) else "valu-issue (the HBM fraction below is still the algorithmic bytes over the HBM peak)",
+                "bound": "hbm" if (vf is None or max(hbm_floor, hbm_floor_traffic or 0.0) >= vf) else "valu-issue (the HBM fraction below is still the algorithmic bytes over the HBM peak)",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -359,6 +361,7 @@ def main():
                 "algorithmic_bytes_per_call": alg,
                 "ms_per_call": op_ms["d_sw"],
                 "hbm_floor_ms": hbm_floor,
+                "hbm_floor_ms_at_measured_traffic": hbm_floor_traffic,
                 "valu_floor_ms": valu_floor,
                 "valu_floor_ms_at_measured_clock": valu_floor_clk,
                 "shader_clock_hz_measured": clk,
