@@ -225,8 +225,9 @@ def main():
 
     # ---- per-operator HIP-event timing: fv3_acoustic_step brackets every operator with an event
     #      pair on the stream it launches on (fv3_ctx_set_profiling / fv3_profile_read)
+    # (N > 1: d_sw only -- the roofline kernel; ~50 event pairs per sub-step cost up to 2 % of a 12 ms sub-step, measured on the emulated 1/8 share)
     if not a.no_op_timing:
-        h.sf.set_profiling(True)
+        h.sf.set_profiling(1 if world == 1 else 2)
 
     def barrier():
         if world > 1:
@@ -379,7 +380,8 @@ def main():
         # (measurement inside the measurement, stated: the per-operator numbers come from one HIP-event pair per operator recorded INSIDE the
         #  timed region -- 13 pairs per sub-step on the compute stream; `--no-op-timing` runs without them: 108.46 / 108.75 ms per sub-step with,
         #  108.70 / 108.44 without, at C768 on one box -- no difference above the run-to-run spread)
-        line["operator_timing"] = "HIP event pair around every operator inside the timed region" if not a.no_op_timing else "off"
+        line["operator_timing"] = ("off" if a.no_op_timing else "HIP event pair around every operator inside the timed region" if world == 1
+                                   else "HIP event pair around d_sw (the roofline kernel) inside the timed region")
         if not a.no_cpu_baseline:
             per_cell, sample, cores = cpu_baseline()
             t_step_cpu = per_cell * h.cells_global * n_sub_steps

@@ -135,8 +135,8 @@ class StencilFactory:
         if st != 0:
             raise _lib.Fv3Error(f"fv3_{name} failed ({st}): {self.lib.fv3_last_error(self._ctx).decode()}")
 
-    def set_profiling(self, on: bool):
-        """HIP-event pairs around every operator of ``fv3_acoustic_step`` (read with ``profile()``)."""
+    def set_profiling(self, on):
+        """HIP-event pairs around every operator of ``fv3_acoustic_step`` (read with ``profile()``); ``on == 2``: around d_sw only."""
         self.lib.fv3_ctx_set_profiling(self._ctx, int(on))
 
     def profile(self, reset: bool = True):

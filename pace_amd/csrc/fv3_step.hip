@@ -23,7 +23,10 @@ struct OpTimer {
 #else
   hipEvent_t e0, e1;
 #endif
-  OpTimer(fv3_ctx *c_, fv3_stream_t s_, int id_) : c(c_), s(s_), id(id_), on(c_->profiling != 0) {
+  // profiling 1: every operator; 2: d_sw only (and what is nested in it: the halo start its time is reduced by) -- the roofline kernel of the bench line
+  // at two event pairs per sub-step instead of ~50 (the multi-GPU runs, where a sub-step is 12 - 45 ms and the pairs cost up to 2 % of it)
+  OpTimer(fv3_ctx *c_, fv3_stream_t s_, int id_)
+      : c(c_), s(s_), id(id_), on(c_->profiling == 1 || (c_->profiling == 2 && (id_ == FV3_OP_D_SW || c_->prof_parent == FV3_OP_D_SW))) {
     if (!on) return;
 #ifdef FV3_HOST_EMU
     t0 = std::chrono::steady_clock::now();
@@ -248,7 +251,9 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   }
   // (the accumulated damping heat the same way: zeroed in full once per context, then the first sub-step's d_sw forms 0 + heat without reading it)
   const bool heat_reset = n_map == 1 || !fv3_alt("heat_zero_first_call");  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
-  const bool heat_store = acc_store && heat_reset && cf.d_con > 1.0e-5;
+  // (not under the FV3_ALT: there the smoothed heat is copied back into the field after every call, never-read corner-halo cells included, and the full
+  //  zero of a step's first call is what keeps those cells from drifting)
+  const bool heat_store = acc_store && heat_reset && cf.d_con > 1.0e-5 && !fv3_alt("heat_zero_first_call");
   if (heat_reset && (!heat_store || c->acc_zeroed[4] != ws->heat_source.ptr)) {
     RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
     c->acc_zeroed[4] = heat_store ? ws->heat_source.ptr : nullptr;
