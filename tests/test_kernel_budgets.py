@@ -55,6 +55,9 @@ BUDGETS = [
     (("single_march_tILi1ELb0E",), 1, 224, 0, 0),   # vorticity transport + winds
     (("single_march_tILi1ELb1E",), 1, 256, 0, 128), # ... with the damping-heat epilogue
     (("single_march_tILi2ELb0E",), 1, 208, 0, 0),   # interface heights
+    # the LDS-tile smoothing of the damping-heat tail (fv3_del2x.hip): three workgroups of four waves per CU need <= 170 registers
+    (("d2_launchILb0ELb0E",), 1, 168, 0, 0),        # plain tiles, heating as its own launch (the product form)
+    (("d2_launchILb1ELb0E",), 1, 256, 0, 0),        # tiles with a cube corner (six LDS offsets per cell; 4 workgroups per sub-domain and level block)
 ]
 
 
