@@ -377,7 +377,12 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
 #define KE_SEG 64
 #define KE_PF 2
 
-static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1) {
+// wk (optional, round 5): the march also forms the cell-mean relative vorticity of the cells (i, jf - 1) under its owned corners -- it holds u of rows jf - 1 / jf
+// and v of row jf - 1 in every lane (v of column i + 1 in the next lane) -- so that the vorticity launch only serves the frame the march does not cover
+// (experiment R5-30, FV3_DSW_VORT_IN_KE=1; off by default: what the vorticity launch saves, this march pays).  vabs: the absolute
+// vorticity, stored on the levels below fdw_k0 (the sponge layers' transport reads it).  The expressions are the vorticity launch's.
+static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1,
+                      Real *wk = nullptr, Real *vabs = nullptr, int fdw_k0 = 0) {
   const Geo g = c->g;
   const int nk = k1 - k0 + 1;
   const int nstrip = (g.nx + 1 + KE_OUT - 1) / KE_OUT;
@@ -388,6 +393,8 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
   const int nx = g.nx, ny = g.ny, nh = g.nh, npx = g.npx, npy = g.npy, sj32 = g.sj32, go = g.o;
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr cosa = g.cosa, rsina = g.rsina, rdx = g.rdx, rdy = g.rdy;
+  const MPtr gdx = g.dx, gdy = g.dy, gra = g.rarea, gf0 = g.f0;
+  const bool VORT = wk != nullptr;
   // Level-major launch geometry (round 4; as in the transport marches, fv3_tp4.hip): KB levels of one (strip, segment) tile are consecutive
   // workgroups of an XCD, so the tile's four metric rows (cosa, rsina, rdx, rdy: 4 of the 9 row reads of a step) are fetched into that XCD's L2
   // once per KB levels -- plane-major, the 4.8 MB of metric terms of a 384^2 sub-domain do not survive a 4 MB L2 from one level to the next.
@@ -425,14 +432,18 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
     const int imax = nx + nh + 1, jmax = ny + nh;
     const Real *ub_ = u + b, *vb_ = v + b, *ucb = uc + b, *vcb = vc + b;
     const MPtr cob = cosa + m2, rsb = rsina + m2, rdxb = rdx + m2, rdyb = rdy + m2;
+    const MPtr dxb = gdx + m2, dyb = gdy + m2, rab = gra + m2, f0b = gf0 + m2;
+    const bool abs_on = VORT && vabs && k < fdw_k0;
     const Real dt5 = (Real)0.5 * dt;
     struct Row {  // row jf = r - 2 of everything but v, whose window runs two rows ahead
       Real vnew, uu, ucc, vcc, vcm, co, rs, rx, rxm, ry;
+      Real dxr, dyc, rac;  // VORT: dx of row jf; dy, 1 / area of row jf - 1 (the vorticity's cell row)
     };
     Row pf[KE_PF][FV3_LPT];
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_v[FV3_LPT];
     PpmCell cv[FV3_LPT];
     Real uc_prev[FV3_LPT], ry_prev[FV3_LPT];
+    Real a_prev[FV3_LPT];  // VORT: u * dx of row jf - 1
     unsigned pcol[FV3_LPT];
     bool own[FV3_LPT];
     const int r_beg = j0 - 1, r_end = j1 + 2;  // v rows j0-3 .. are fed by the start-up below
@@ -453,13 +464,22 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
       w.rx = rdxb[p];
       w.rxm = rdxb[p - (p != 0u)];
       w.ry = rdyb[p];
+      w.dxr = w.dyc = w.rac = (Real)0;
+      if (VORT) {
+        int jc = r - 3 < 1 - nh ? 1 - nh : r - 3;
+        if (jc > jmax) jc = jmax;
+        const unsigned pc = pcol[l] + (unsigned)(jc * sj32);
+        w.dxr = dxb[p];
+        w.dyc = dyb[pc];
+        w.rac = rab[pc];
+      }
       return w;
     };
     FV3_LANES(blk, lane, l) {
       const int i = i0 - 3 + lane, ic = i < imax ? i : imax;
       pcol[l] = (unsigned)(go * sj32 + ic + go);
       own[l] = i >= ilo && i <= ihi;
-      w2[l] = w3[l] = w4[l] = w5[l] = al_v[l] = uc_prev[l] = ry_prev[l] = (Real)0;
+      w2[l] = w3[l] = w4[l] = w5[l] = al_v[l] = uc_prev[l] = ry_prev[l] = a_prev[l] = (Real)0;
       cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       if (lane < 3) lu[lane] = lu[FV3_WAVE + 3 + lane] = (Real)0;
     }
@@ -473,6 +493,7 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
       const int rn = r + KE_PF;
       const int jf = r - 2;  // face of ytp_v / row of everything else
       Real uu_[FV3_LPT], ubv_[FV3_LPT], vbv_[FV3_LPT], vfl_[FV3_LPT], rx_[FV3_LPT], rxm_[FV3_LPT];
+      Real va_[FV3_LPT], va1_[FV3_LPT], ve_[FV3_LPT], vra_[FV3_LPT];  // VORT: u * dx of rows jf - 1 / jf, v * dy, 1 / area of row jf - 1
       FV3_LANES(blk, lane, l) {
         const Row cu = pf[0][l];
 #pragma unroll
@@ -498,6 +519,14 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
         rx_[l] = cu.rx;
         rxm_[l] = cu.rxm;
         lu[3 + lane] = cu.uu;
+        if (VORT) {
+          const Real a1 = cu.uu * cu.dxr;
+          va_[l] = a_prev[l];
+          va1_[l] = a1;
+          a_prev[l] = a1;
+          ve_[l] = w2[l] * cu.dyc;  // (w2 = v of row r - 3 = jf - 1)
+          vra_[l] = cu.rac;
+        }
       }
       blk.wave_sync();
       const bool row_ok = jf >= j0 && jf <= j1;
@@ -505,6 +534,16 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
         const Real *a = lu + lane;  // a[0] = u(i-3, jf)
         const Real ufl = ppm_flux_int_cfl(a[0], a[1], a[2], a[3], a[4], a[5], ubv_[l], hord, rxm_[l], rx_[l]);
         if (row_ok && own[l]) (ke + b)[pcol[l] + (unsigned)(jf * sj32)] = (Real)0.5 * (vbv_[l] * vfl_[l] + ubv_[l] * ufl);
+        if (VORT) {
+          // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1]) of cell (i, jf - 1)
+          const Real e1 = FV3_LANE_SHL(1, ve_, l, lane);
+          const Real wkv = vra_[l] * (va_[l] - va1_[l] - ve_[l] + e1);
+          if (row_ok && own[l]) {
+            const unsigned pw = pcol[l] + (unsigned)((jf - 1) * sj32);
+            (wk + b)[pw] = wkv;
+            if (abs_on) (vabs + b)[pw] = wkv + f0b[pw];  // (the sponge layers only: f0 fetched where it is used, not with the row ahead)
+          }
+        }
       }
       blk.wave_sync();
     }
@@ -1017,8 +1056,14 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         fdw_k0 = k;
       }
   }
+  // Round 5, FV3_DSW_VORT_IN_KE=1 (experiment R5-30, off by default): the corner-KE march, which reads u and v anyway, forms the vorticity of the cells under
+  // its corners -- columns 4 .. nx - 2, rows 3 .. ny - 3 at least -- and this launch only serves the four windows of the frame around them (sub-domains
+  // without a tile edge on a side get those cells from both: the same values).  Same bits; measured neutral: the launch goes from 1.61 to 0.25 ms, the march
+  // from 3.00 to 4.15 (23 more registers at four waves per SIMD, three more metric rows, one more store stream).
+  const char *vk_env = getenv("FV3_DSW_VORT_IN_KE");  // (read per call: the parity test flips it in one process)
+  const bool vort_in_ke = vk_env && vk_env[0] == '1' && !keep_uv_dx && getenv("FV3_KE_STAGED") == nullptr && g.nx >= 12 && g.ny >= 12;
   // (two levels per thread: the six metric terms are read once)
-  launch3(c, s, Box{isd, ied, jsd, jed, 0, (nz1 + FV3_KC) / FV3_KC - 1}, [=] FV3_HD(int t, int kp, int i, int j) {
+  auto vort_cells = [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
     const unsigned p = IX(i, j), pn = IX(i, j + 1), pe_ = IX(i + 1, j);
     const Real dx0 = (g.dx + m2)[p], dx1 = (g.dx + m2)[pn], dy0 = (g.dy + m2)[p], dy1 = (g.dy + m2)[pe_], ra = (g.rarea + m2)[p], f0v = (g.f0 + m2)[p];
@@ -1038,7 +1083,14 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         (ut2 + b)[p] = e;
       }
     }
-  });
+  };
+  {
+    const int nkc = (nz1 + FV3_KC) / FV3_KC;
+    if (vort_in_ke)
+      launch_frame(c, s, Frame{{Box{isd, 3, jsd, jed, 0, nkc - 1}, Box{g.nx - 1, ied, jsd, jed, 0, 0}, Box{4, g.nx - 2, jsd, 2, 0, 0}, Box{4, g.nx - 2, g.ny - 2, jed, 0, 0}}}, vort_cells);
+    else
+      launch3(c, s, Box{isd, ied, jsd, jed, 0, nkc - 1}, vort_cells);
+  }
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
   static const bool ke_staged = getenv("FV3_KE_STAGED") != nullptr;  // A/B switch for profiling
   // ke_point: one corner, any position (tile-edge forms of ub / vb, one-sided PPM, corner overrides)
@@ -1105,7 +1157,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   if (ke_staged) {
     launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, ke_point);
   } else {
-    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, nz1);
+    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, nz1, vort_in_ke ? wk : nullptr, vabs, fdw_k0);
     // frame: the 3 outermost corner rows / columns next to a cube-tile edge
     // (W / E: columns 1..3 / npx-2..npx as narrow windows, S / N: rows 1..3 / npy-2..npy; the corner cells belong to the column windows)
     launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, 0, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},

@@ -473,6 +473,27 @@ def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend,
             assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, seg", [(24, (2, 2), "0"), (130, (1, 1), "0"), (140, (2, 2), "32"), (48, (1, 1), "0")])
+def test_vorticity_inside_the_corner_ke_march_is_bitwise_the_vorticity_launch(backend, monkeypatch, n, layout, seg):
+    """d_sw's cell-mean relative vorticity formed by the corner-KE march for the cells under its corners (the march reads u and v anyway; the vorticity
+    launch then only serves the frame around them; FV3_DSW_VORT_IN_KE=1, measured neutral and off by default) against the launch on the whole padded plane:
+    every field bitwise equal -- the
+    vorticity feeds the wind update, the Smagorinsky damping and the damping heat, so a wrong or missing cell shows in u / v / pt.  Sub-domains with and
+    without tile edges on every side (2 x 2 layouts), one and several strips and row segments."""
+    nz = 5
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV3_DSW_VORT_IN_KE", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["1"][r][name], res["0"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout", [(24, (2, 2)), (48, (1, 1))])
 def test_heights_of_a_call_straight_into_zh_is_bitwise_the_reference_order(backend, monkeypatch, n, layout):
     """First sub-step of fv3_acoustic_step: set_gz -> zh, zh's halo update, update_dz_c in its zh -> gz form (no gz -> zh copy, no in-place update_dz_c)
