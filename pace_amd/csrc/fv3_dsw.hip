@@ -381,8 +381,9 @@ extern "C" int fv3_fxadv(fv3_ctx *c, const fv3_field *uc_, const fv3_field *vc_,
 // and v of row jf - 1 in every lane (v of column i + 1 in the next lane) -- so that the vorticity launch only serves the frame the march does not cover
 // (experiment R5-30, FV3_DSW_VORT_IN_KE=1; off by default: what the vorticity launch saves, this march pays).  vabs: the absolute
 // vorticity, stored on the levels below fdw_k0 (the sponge layers' transport reads it).  The expressions are the vorticity launch's.
-static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1,
-                      Real *wk = nullptr, Real *vabs = nullptr, int fdw_k0 = 0) {
+template <bool VORT>
+static void ke_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1, Real *wk,
+                        Real *vabs, int fdw_k0) {
   const Geo g = c->g;
   const int nk = k1 - k0 + 1;
   const int nstrip = (g.nx + 1 + KE_OUT - 1) / KE_OUT;
@@ -394,7 +395,6 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
   const long st = g.st, sk = g.sk, st2 = g.st2;
   const MPtr cosa = g.cosa, rsina = g.rsina, rdx = g.rdx, rdy = g.rdy;
   const MPtr gdx = g.dx, gdy = g.dy, gra = g.rarea, gf0 = g.f0;
-  const bool VORT = wk != nullptr;
   // Level-major launch geometry (round 4; as in the transport marches, fv3_tp4.hip): KB levels of one (strip, segment) tile are consecutive
   // workgroups of an XCD, so the tile's four metric rows (cosa, rsina, rdx, rdy: 4 of the 9 row reads of a step) are fetched into that XCD's L2
   // once per KB levels -- plane-major, the 4.8 MB of metric terms of a 384^2 sub-domain do not survive a 4 MB L2 from one level to the next.
@@ -548,6 +548,14 @@ static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, 
       blk.wave_sync();
     }
   });
+}
+
+static void ke_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *uc, const Real *vc, Real *ke, Real dt, int hord, int k0, int k1,
+                      Real *wk = nullptr, Real *vabs = nullptr, int fdw_k0 = 0) {
+  if (wk)
+    ke_stream_t<true>(c, s, u, v, uc, vc, ke, dt, hord, k0, k1, wk, vabs, fdw_k0);
+  else
+    ke_stream_t<false>(c, s, u, v, uc, vc, ke, dt, hord, k0, k1, nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,7 +40,8 @@ BUDGETS = [
     ((_tp(TF_WIND | TF_FD),), 1, 256, 8, 32),                   # AT the limit (documented: 4 - 8 spilled)
     (("csw_fused_stream", "fv3_kwgILi2ELi4E"), 1, 256, 0, 0),   # c_sw interior march
     (("nh_pgf_fused", "fv3_kwILi2E"), 1, 256, 0, 0),            # fused nh_p_grad march
-    (("ke_stream", "fv3_kwILi4E"), 1, 128, 0, 0),               # corner kinetic energy: four waves / SIMD
+    (("ke_stream_tILb0E", "fv3_kwILi4E"), 1, 128, 0, 0),        # corner kinetic energy: four waves / SIMD
+    (("ke_stream_tILb1E", "fv3_kwILi4E"), 1, 128, 0, 0),        # ... forming the cell-mean vorticity too (FV3_DSW_VORT_IN_KE=1, off by default)
     (("fv3_riem_solver_c", "fv3_kwILi1E", "IbLb0E"), 1, 256, 0, 0),       # wave Riemann solvers, gam through the scratch field (FV3_RIEM_REGS=0): the LDS line sets their occupancy
     (("fv3_riem_solver3", "fv3_kwILi1E", "IbLb0EES5_"), 1, 256, 0, 0),      # (not the last sub-step)
     # ... the product form: gam in 160 accumulation registers that fv3_agpr.h addresses by hand.  The compiler must not use the
