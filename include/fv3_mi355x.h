@@ -323,7 +323,11 @@ typedef int (*fv3_halo_fn)(void *user, int update /* fv3_halo_update */, int pha
 int fv3_ctx_set_halo_plans(fv3_ctx *, fv3_halo_plan *const *plans, int n);
 
 /* n_split acoustic sub-steps (+ the once-per-call diffusive heating when d_con > 1e-5);
- * timestep = dt_atmos / k_split, n_map = 1..k_split.  halo == NULL: the registered plans (fv3_ctx_set_halo_plans). */
+ * timestep = dt_atmos / k_split, n_map = 1..k_split.  halo == NULL: the registered plans (fv3_ctx_set_halo_plans).
+ * The flux accumulators of the state (mfxd, mfyd, cxd, cyd) hold this call's fluxes on return [dyn_core.F90: emptied at the start of
+ * every call]; the library zeroes each array in full the first time the context sees its pointer and afterwards has the first
+ * sub-step store into the cells d_sw writes ("Flux accumulators").  With a halo callback the first sub-step asks for
+ * FV3_HALO_ZH where the reference's sequence updates gz (the heights of a call are computed straight into zh). */
 int fv3_acoustic_step(fv3_ctx *, const fv3_state *state, const fv3_workspace *work, double timestep, int n_map,
                       fv3_halo_fn halo, void *halo_user, void *stream);
 
@@ -370,7 +374,7 @@ enum fv3_op {
   FV3_OP_HALO,
   FV3_OP_COUNT
 };
-int fv3_ctx_set_profiling(fv3_ctx *, int on); /* record an event pair around every operator of fv3_acoustic_step */
+int fv3_ctx_set_profiling(fv3_ctx *, int on); /* 1: record an event pair around every operator of fv3_acoustic_step; 2: around d_sw only; 0: off */
 const char *fv3_op_name(int op);
 /* accumulated milliseconds and call counts per fv3_op (arrays of FV3_OP_COUNT); waits for the events */
 int fv3_profile_read(fv3_ctx *, double *ms_sum, int64_t *calls, int reset);
