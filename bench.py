@@ -341,7 +341,9 @@ def main():
                     return None, f"profiles/{name} was measured on kernel sources {rec.get('csrc_hash')}, this library is built from {build_id}: stale, not quoted", None
                 return rec[key], f"profiles/{name} (" + rec["source"] + f"; kernel sources {build_id})", rec
 
-            traffic, traffic_src, _ = committed("traffic_d_sw.json", "bytes")
+            traffic, traffic_src, trec = committed("traffic_d_sw.json", "bytes")
+            # the rate fv3_copy (one field read, one written) reached in the SAME counter pass: what "bandwidth-bound" means on this chip for this access pattern
+            copy_gbps = trec.get("copy_GBps") if trec else None
             valu_floor, valu_src, vrec = committed("valu_d_sw.json", "valu_floor_ms")
             valu_floor_clk = vrec.get("valu_floor_ms_measured_clock") if vrec else None
             clk = vrec.get("clock_hz_measured") if vrec else None
@@ -357,6 +359,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS,
+                "frac_of_measured_copy": (ach / copy_gbps) if copy_gbps else None,
+                "measured_copy_GBps": copy_gbps,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_call": alg,
@@ -368,6 +372,9 @@ def main():
                 "shader_clock_hz_measured": clk,
                 "valu_floor_source": valu_src,
                 "library_build_id": build_id,
+                # non-null: NOT the product build (extra compile flags / per-file overrides / a variant tag: pace_amd/build.py variant_suffix) -- the committed
+                # counter files never match such an id, so traffic / VALU floors are null for it
+                "library_variant": (build_id.partition("+")[2] or None),
             }
         # the same fraction for every operator with a pass count in SURVEY §8a (algorithmic bytes per cell = passes x sizeof(Real))
         passes = {"c_sw": 15, "update_dz_c": 4, "riem_solver_c": 8, "p_grad_c": 7, "d_sw": D_SW_PASSES, "update_dz_d": 6, "riem_solver3": 11, "nh_p_grad": 8}
@@ -376,6 +383,16 @@ def main():
                 "frac": p_ * (8 if a.precision == 64 else 4) * h.cells_local / (op_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             for k, p_ in passes.items() if k in op_ms and op_ms[k] > 0
         }
+        if "d_sw" in op_ms:
+            # counter traffic of every operator (one sub-step, the same two PMC passes as roofline.traffic; null + reason when the file is of another tree / workload)
+            orec_ops, orec_src, orec = committed("traffic_operators.json", "operators")
+            for k, v in line["roofline_operators"].items():
+                t_ = (orec_ops or {}).get(k, {}).get("traffic_GB")
+                v["traffic_GB"] = t_
+                v["traffic_over_algorithmic"] = (t_ / v["algorithmic_GB"]) if t_ else None
+                cg = orec.get("copy_GBps") if orec else None
+                v["frac_of_measured_copy"] = (v["algorithmic_GB"] / (v["ms"] * 1e-3) / cg) if cg else None
+            line["roofline_operators_traffic_source"] = orec_src
         line["operators_ms_per_substep"] = op_ms
         # (measurement inside the measurement, stated: the per-operator numbers come from one HIP-event pair per operator recorded INSIDE the
         #  timed region -- 13 pairs per sub-step on the compute stream; `--no-op-timing` runs without them: 108.46 / 108.75 ms per sub-step with,

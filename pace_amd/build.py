@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 HOSTEMU_DIR = os.path.join(ROOT, "tests", "_hostemu")
 
-SOURCES = ["fv3_ctx.hip", "fv3_tp2d.hip", "fv3_tp2x.hip", "fv3_tp4.hip", "fv3_tp4x.hip", "fv3_a2b.hip", "fv3_csw.hip", "fv3_dsw.hip", "fv3_nh.hip", "fv3_del2x.hip", "fv3_pgf.hip", "fv3_step.hip", "fv3_halo.hip", "fv3_tracer.hip", "fv3_remap.hip"]
+SOURCES = ["fv3_ctx.hip", "fv3_tp2d.hip", "fv3_tp2x.hip", "fv3_tp4.hip", "fv3_tp4x.hip", "fv3_a2b.hip", "fv3_csw.hip", "fv3_dsw.hip", "fv3_wind.hip", "fv3_nh.hip", "fv3_del2x.hip", "fv3_pgf.hip", "fv3_step.hip", "fv3_halo.hip", "fv3_tracer.hip", "fv3_remap.hip"]
 HEADERS = ["fv3_common.h", "fv3_ops.h", "fv3_ppm.h", "fv3_a2b.h", "fv3_math.h", "fv3_agpr.h", "fv3_march.h", os.path.join("..", "..", "include", "fv3_mi355x.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -55,6 +55,18 @@ def src_hash() -> str:
     return _digest(paths, None)[:16]
 
 
+def variant_suffix() -> str:
+    """"" for the product build; "+<8 hex>[.<tag>]" when anything changes what the SAME sources compile to: FV3_EXTRA_FLAGS, a per-file FV3_FLAGS_<stem>
+    override, or a variant tag (FV3_LIB_TAG).  It is appended to the embedded build id, so a diagnostic library (ablation builds, always-hit metric reads --
+    wrong values by design) never matches the counter files bench.py quotes for the product tree, and the bench line shows what it ran on."""
+    extra = os.environ.get("FV3_EXTRA_FLAGS", "").split()
+    per = sorted((k, v) for k, v in os.environ.items() if k.startswith("FV3_FLAGS_") and v.strip())
+    tag = os.environ.get("FV3_LIB_TAG", "")
+    if not extra and not per and not tag:
+        return ""
+    return "+" + hashlib.sha256(repr((extra, per)).encode()).hexdigest()[:8] + (("." + tag) if tag else "")
+
+
 def _run(cmd):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -84,7 +96,7 @@ def build(precision: int = 64, hostemu: bool = False, force: bool = False, verbo
             if extra:
                 per_file[sname] = extra.split()
 
-    idflag = {"fv3_ctx.hip": [f'-DFV3_SRC_HASH="{src_hash()}"']}
+    idflag = {"fv3_ctx.hip": [f'-DFV3_SRC_HASH="{src_hash()}{"" if hostemu else variant_suffix()}"']}
 
     def one(i):
         _run([cc] + flags + per_file.get(SOURCES[i], []) + idflag.get(SOURCES[i], []) + ["-c", srcs[i], "-o", objs[i]])

@@ -264,11 +264,10 @@ struct fv3_ctx {
   bool seq_divgd_dead = false;
   // set by fv3_acoustic_step around the d_sw call of a call's FIRST sub-step: the four accumulators of the tracer sub-cycling (mfx, mfy, cx, cy) hold
   // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (one level plane of zeros, 1.2 MB at C768: it stays in L2) instead of the field, and the sequencer
-  // does not zero the fields first (fv3_step.hip; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
+  // zeroes only the cells d_sw never writes (zero_unwritten, fv3_step.hip: every call, no cached state; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
   bool seq_acc_first = false;
   bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step
   Real *zeros = nullptr;
-  const void *acc_zeroed[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the accumulator arrays this context has zeroed in full once (mfx, mfy, cx, cy, heat_source)
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};
   void *pp_to[4] = {nullptr, nullptr, nullptr, nullptr};
   int pp_n = 0;

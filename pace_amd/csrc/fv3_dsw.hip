@@ -648,8 +648,9 @@ static void divdamp_staged(fv3_ctx *c, fv3_stream_t s, Real *divgd, Real *uc, Re
 #define DD_SEG 64
 #define DD_NMAX 3
 #define DD_PF 2
-#define DD_PATCH 8
+#define DD_PATCH WS_PATCH
 
+static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1);
 static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
   const Geo g = c->g;
   const int nk = k1 - k0 + 1;
@@ -788,7 +789,14 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
       }
     }
   });
-  // cube-corner patches (all corners in one set of launches when their windows are disjoint)
+  divdamp_patches(c, s, divgd, out, uc, vc, tmp, nord_max, k0, k1);
+}
+
+// The chain's cube-corner patches: the DD_PATCH^2 corners next to every cube corner of the context's sub-domains, recomputed by the staged form on a private
+// copy (tmp) of a window around them and written into `out` (all corners in one chained launch when their windows are disjoint).  uc / vc: the work arrays
+// of the iteration (the reference uses the dead C-grid winds; the fused wind stage, whose march still reads them, hands in scratch).
+static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
+  const Geo g = c->g;
   int any = 0;
   for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
   const int *nk_ = g.nord;
@@ -1070,6 +1078,22 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   // from 3.00 to 4.15 (23 more registers at four waves per SIMD, three more metric rows, one more store stream).
   const char *vk_env = getenv("FV3_DSW_VORT_IN_KE");  // (read per call: the parity test flips it in one process)
   const bool vort_in_ke = vk_env && vk_env[0] == '1' && !keep_uv_dx && getenv("FV3_KE_STAGED") == nullptr && g.nx >= 12 && g.ny >= 12;
+  // Round 6: levels from kfz on run the FUSED wind stage (fv3_wind.hip: vorticity, corner KE, damping chain, corner interpolation and the damping in one
+  // march); the launches below then only serve the levels under kfz (the sponge layers: no chain, absolute-vorticity field).  FV3_DSW_WINDSTAGE=staged:
+  // every level through the staged kernels (A/B; read per call: the parity test flips it).
+  int kfz = g.nz;
+  {
+    const char *we = getenv("FV3_DSW_WINDSTAGE");
+    static const bool ke_staged_env = getenv("FV3_KE_STAGED") != nullptr, dd_staged_env = getenv("FV3_DIVDAMP_STAGED") != nullptr;
+    const bool off = (we && !strcmp(we, "staged")) || ke_staged_env || dd_staged_env || keep_uv_dx || vort_in_ke || nord_max > DD_NMAX || nord_max <= 0 || g.nx < 8 || g.ny < 8;
+    if (!off)
+      for (int k = g.nz - 1; k >= fdw_k0; --k) {
+        if (!(c->nord_h[k] >= 1 && c->nord_h[k] <= DD_NMAX)) break;
+        kfz = k;
+      }
+  }
+  const int ks1 = kfz - 1;  // last level of the staged kernels
+  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] fused wind stage on levels %d..%d of %d\n", kfz, nz1, g.nz);
   // (two levels per thread: the six metric terms are read once)
   auto vort_cells = [=] FV3_HD(int t, int kp, int i, int j) {
     const long m2 = t * g.st2;
@@ -1078,7 +1102,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
 #pragma unroll 1
     for (int kk = 0; kk < FV3_KC; ++kk) {
       const int k = FV3_KC * kp + kk;
-      if (k > nz1) break;
+      if (k > ks1) break;
       const long b = t * g.st + k * g.sk;
       // wk = rarea * (u*dx - (u*dx)[j+1] - v*dy + (v*dy)[i+1])
       const Real a = (u + b)[p] * dx0, a1 = (u + b)[pn] * dx1;
@@ -1093,16 +1117,17 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     }
   };
   {
-    const int nkc = (nz1 + FV3_KC) / FV3_KC;
-    if (vort_in_ke)
+    const int nkc = (ks1 + FV3_KC) / FV3_KC;
+    if (nkc <= 0) {
+    } else if (vort_in_ke)
       launch_frame(c, s, Frame{{Box{isd, 3, jsd, jed, 0, nkc - 1}, Box{g.nx - 1, ied, jsd, jed, 0, 0}, Box{4, g.nx - 2, jsd, 2, 0, 0}, Box{4, g.nx - 2, g.ny - 2, jed, 0, 0}}}, vort_cells);
     else
       launch3(c, s, Box{isd, ied, jsd, jed, 0, nkc - 1}, vort_cells);
   }
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
   static const bool ke_staged = getenv("FV3_KE_STAGED") != nullptr;  // A/B switch for profiling
-  // ke_point: one corner, any position (tile-edge forms of ub / vb, one-sided PPM, corner overrides)
-  auto ke_point = [=] FV3_HD(int t, int k, int i, int j) {
+  // ke_value: one corner, any position (tile-edge forms of ub / vb, one-sided PPM, corner overrides)
+  auto ke_value = [=] FV3_HD(int t, int k, int i, int j) -> Real {
     const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
@@ -1160,15 +1185,17 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       }
       kev = (Real)0.5 * (vbv * vflux + ubv * uflux);
     }
-    (ke + b)[p] = kev;
+    return kev;
   };
-  if (ke_staged) {
-    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nz1}, ke_point);
+  auto ke_point = [=] FV3_HD(int t, int k, int i, int j) { (ke + t * g.st + k * g.sk)[IX(i, j)] = ke_value(t, k, i, j); };
+  if (ks1 < 0) {
+  } else if (ke_staged) {
+    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, ks1}, ke_point);
   } else {
-    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, nz1, vort_in_ke ? wk : nullptr, vabs, fdw_k0);
+    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, ks1, vort_in_ke ? wk : nullptr, vabs, fdw_k0);
     // frame: the 3 outermost corner rows / columns next to a cube-tile edge
     // (W / E: columns 1..3 / npx-2..npx as narrow windows, S / N: rows 1..3 / npy-2..npy; the corner cells belong to the column windows)
-    launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, 0, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
+    launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, 0, ks1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
                    [=] FV3_HD(int w_, int t, int k, int i, int j) {
       const int fl = g.flags[t];
       if (!(fl & (w_ == 0 ? FV3_W : w_ == 1 ? FV3_E : w_ == 2 ? FV3_S : FV3_N))) return;
@@ -1236,7 +1263,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       divdamp_staged(c, s, divgd, uc, vc, nord_max, 0, nz1, nullptr);
     } else if (nord_max > 0) {
       dnew = c->scratch[SC_L];
-      divdamp_stream(c, s, divgd, dnew, uc, vc, c->scratch[SC_M], nord_max, 0, nz1);
+      if (ks1 >= 0) divdamp_stream(c, s, divgd, dnew, uc, vc, c->scratch[SC_M], nord_max, 0, ks1);
     }
   }
   // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
@@ -1249,7 +1276,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // next c_sw overwrites the workspace field -- the sequencer says so (seq_divgd_dead) and the copy of the iteration's result into divgd
     // (one field write per call) is skipped when the iteration wrote beside it.
     const bool keep_divgd = !(c->seq_divgd_dead && dd_sep);
-    a2b_ord4_t<8>(c, s, wk, 0, 0, g.nz, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
+    if (ks1 >= 0) a2b_ord4_t<8>(c, s, wk, 0, 0, ks1 + 1, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
       const int nord = g.nord[k];
       if (nord == 0) return;
       const long b = t * g.st + k * g.sk;
@@ -1263,6 +1290,37 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       (vdamp + b)[p] = vd;
       (ke + b)[p] += vd;
     });
+    // ---- the fused wind stage on the levels kfz .. nz1 (fv3_wind.hip).  Order: the damping chain's cube-corner patches first (the march reads their values
+    //      where its own chain is wrong; their work arrays are scratch here -- the march still reads the C-grid winds), the march, then ONE per-point launch on
+    //      the three outermost corner rows / columns next to a cube-tile edge: kinetic energy (ke_value), corner vorticity (a2b_point on the wk the march has
+    //      stored) and the damping, with the iterated divergence the march exported there.
+    if (kfz <= nz1) {
+      divdamp_patches(c, s, divgd, dnew, c->scratch[SC_TP_FY2], c->scratch[SC_TP_FX2], c->scratch[SC_M], nord_max, kfz, nz1);
+      const WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
+      wind_stage_march(c, s, ws);
+      launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, kfz, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
+                     [=] FV3_HD(int w_, int t, int k, int i, int j) {
+        const int fl = g.flags[t];
+        if (!(fl & (w_ == 0 ? FV3_W : w_ == 1 ? FV3_E : w_ == 2 ? FV3_S : FV3_N))) return;
+        if (w_ >= 2 && (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2))) return;  // covered by the column windows
+        const long b = t * g.st + k * g.sk;
+        const unsigned p = IX(i, j);
+        const Real kev = ke_value(t, k, i, j);
+        const Real wkbv = a2b_point(g, wk + b, t, i, j);
+        const Real dpc = (divgd + b)[p];
+        Real vo = (Real)0;
+        if (dddmp >= (Real)1.0e-5) vo = fabs(dt) * sqrt(dpc * dpc + wkbv * wkbv);
+        const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, dddmp * vo));
+        const Real vd = damp2 * dpc + tab.dd8[k] * (dnew + b)[p];
+        (vdamp + b)[p] = vd;
+        (ke + b)[p] = kev + vd;
+      });
+      // (the operator's own contract leaves the iterated divergence in divgd; inside the sequencer nobody reads it)
+      if (keep_divgd) launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kfz, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
+        const long pp = t * g.st + k * g.sk + IX(i, j);
+        divgd[pp] = dnew[pp];
+      });
+    }
   }
 
   };
@@ -1326,11 +1384,10 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // sequence (A/B; read per call).
     const char *he = getenv("FV3_DSW_HEAT");
     const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source, c->seq_heat_first ? c->zeros : nullptr};
-    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1)) {
-      e.heat = &th;
-      heat_k1 = fdw_k0 - 1;
-    }
+    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1)) e.heat = &th;
     tp2d(c, s, wk, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, fdw_k0, nz1, &e);
+    // (whether the march took the heat over is what the dispatch DID, not what was predicted above: a form that ignores TpEpi::heat leaves every level to the kernel below)
+    if (th.consumed) heat_k1 = fdw_k0 - 1;
     if (sv != s) fv3_wait(c, s, 3);
   }
 

@@ -129,21 +129,6 @@ void del2_fill_corners(fv3_ctx *c, fv3_stream_t s, Real *qin);  // (fv3_nh.hip)
 int fv3_del2_heat_fused(fv3_ctx *c, const fv3_field *q, double cd, int nmax, const fv3_field *delp, const fv3_field *delz, const fv3_field *cappa,
                         const fv3_field *pt, double delt, bool keep_q, void *stream);
 
-// Does the (strip, segment) tile of a scalar march touch a cube corner of its sub-domain (flags fl)?  Such tiles have the rare paths of the
-// marches in them -- the corner-halo remaps of the rows outside 1..nM, the del-n fluxes read from the FV3_D6_PATCH^2 corner patches -- and
-// stay with the round-4 kernel (dsw_scalars_t, tile_sel = 1); every other tile of the interior launches runs the round-5 march
-// (fv3_tp4x.hip).  l0: first owned L face of the strip (lanes cover l0-3 .. l0+60); ca: first owned row; r_end: last row the tile's march
-// consumes.  Conservative: a tile near a corner without rare work in it may count as a corner tile.
-FV3_HD inline bool q4_corner_tile(int fl, int l0, int ca, int r_end, int nL, int nM) {
-  const bool lo_strip = l0 - 3 <= FV3_D6_PATCH, hi_strip = l0 + FV3_WAVE - 4 >= nL + 2 - FV3_D6_PATCH;
-  const bool lo_seg = ca - 3 <= FV3_D6_PATCH + 3, hi_seg = r_end >= nM + 2 - FV3_D6_PATCH;
-  const bool c_ll = (fl & (FV3_W | FV3_S)) == (FV3_W | FV3_S), c_hl = (fl & (FV3_E | FV3_S)) == (FV3_E | FV3_S);
-  const bool c_hh = (fl & (FV3_E | FV3_N)) == (FV3_E | FV3_N), c_lh = (fl & (FV3_W | FV3_N)) == (FV3_W | FV3_N);
-  return (c_ll && lo_strip && lo_seg) || (c_hl && hi_strip && lo_seg) || (c_hh && hi_strip && hi_seg) || (c_lh && lo_strip && hi_seg);
-}
-// the tiles of a single-tracer FD transport (tp2d_stream_t) that stay with the round-4 kernel: the cube-corner tiles; every other tile runs the round-5
-// march (fv3_tp2x.hip), which evaluates the W / E one-sided formulas of a tile-edge strip in its lanes
-FV3_HD inline bool tp2d_old_tile(int fl, int i0, int ja, int r_end, int nx, int ny) { return q4_corner_tile(fl, i0, ja, r_end, nx, ny); }
 bool tp2d_fd_lean(const fv3_ctx *c, int hord, int k0, int k1);  // (fv3_tp2d.hip) will tp2d's FD forms run the round-5 march?  (then only the corner patches of the chain's fluxes are needed)
 // kind 1: d_sw's vorticity transport + wind update, 2: update_dz_d's interface-height transport (TpEpi as for tp2d with fd = 1); PPM order 6
 struct TpEpi;
@@ -154,12 +139,32 @@ struct TpHeat {
   const Real *vdamp, *ndelp, *heat_s, *dcon;
   Real *heat_src;
   const Real *zeros = nullptr;  // non-null: first sub-step of a call inside the sequencer -- the accumulated heat is read as zero from this block, not from heat_src
+  // set by the dispatch that actually launches the HEAT march (tp2d_single_march): the caller derives the level range its damping-heat kernel still has to serve
+  // from THIS, not from a prediction of the dispatch (the two predicates -- d_sw's and tp2d_stream's -- could drift apart silently otherwise)
+  mutable bool consumed = false;
 };
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
                        const TpEpi *epi, const TpHeat *heat = nullptr);
 // the round-5 two-tracer march on the tiles without a cube corner (fv3_tp4x.hip); role 1 = delp + w, 2 = q_con + pt; levels k_lo .. k_hi must
 // all run their del-n chains inside the march (>= fd_k0), PPM order 6
 void dsw_pair_march(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int role, int k_lo, int k_hi);
+
+// d_sw's wind-branch stage kernels as one march (fv3_wind.hip): reads u, v, uc, vc, divgd (the un-iterated corner divergence); writes wk (cell-mean relative
+// vorticity, every cell of the padded plane), ke (corner kinetic energy + damping) and vdamp (the corner damping field) on the corners that take the interior
+// formulas (>= 4 from a cube-tile edge), and exports the iterated divergence to dnew on the other corners of the compute domain (the per-point launch of the
+// caller finishes those; store_dn: on every corner).  dnew must already hold the staged chain's values on the WS_PATCH^2 corners next to a cube corner.
+// Levels k0 .. k1 must all run the damping chain (0 < nord <= 3).
+#define WS_PATCH 8
+struct WindStage {
+  const Real *u, *v, *uc, *vc, *divgd;
+  Real *ke, *vdamp, *wk, *dnew;
+  const Real *dd8;  // per-level (da_min_c * d4_bg)^(nord+1)
+  Real dt, dddmp;
+  int hord;
+  bool store_dn;
+  int k0, k1;
+};
+void wind_stage_march(fv3_ctx *c, fv3_stream_t s, const WindStage &a);
 
 // two tracers riding on given mass fluxes (the TRC march alone: tracer_2d_1l): a.q_con / a.pt = the two tracers, a.delp = the
 // old air mass, a.o_delp = the new one, a.fx / a.fy = the mass fluxes, outputs a.o_q_con / a.o_pt; no damping (dn_* off)

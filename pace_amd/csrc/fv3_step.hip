@@ -115,6 +115,65 @@ int copy_frames(fv3_ctx *c, int n, const fv3_field *const *src, const fv3_field 
   return fv3_post(c, (fv3_stream_t)stream, "copy_frames");
 }
 
+// What the first-sub-step form of the accumulators (fv3_ctx::seq_acc_first / seq_heat_first) leaves to the sequencer: the first d_sw of a call STORES 0 + flux on
+// every face / cell it owns, so the only cells of mfx / mfy / cx / cy / heat_source that still need the reference's zero_data are the ones d_sw never writes -- the
+// frame of every plane outside the operator's write set and the padding level nz.  They are zeroed here on EVERY call (a thread per frame cell and level, as
+// copy_frames; ~4 % of a field for the five of them together), so the result does not depend on what the arrays held before the call: no "zeroed once" flag keyed on a
+// pointer (round 5), which a host write into those cells or an allocator re-using the address went past unseen [REF tests/main/fv3core/test_dycore_call.py:169-190].
+// Write sets (first sub-step; fxadv, the AIR march, the two heat sites): cx [1, nx+1] x [jsd, jed], cy [isd, ied] x [1, ny+1], mfx [1, nx+1] x [1, ny],
+// mfy [1, nx] x [1, ny+1], heat_source [1, nx] x [1, ny].  A null field takes no part (it gets the full zero instead).
+int zero_unwritten(fv3_ctx *c, const fv3_field *mfx_, const fv3_field *mfy_, const fv3_field *cx_, const fv3_field *cy_, const fv3_field *heat_, void *stream) {
+  Real *f[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const fv3_field *in[5] = {mfx_, mfy_, cx_, cy_, heat_};
+  bool any = false;
+  for (int q = 0; q < 5; ++q)
+    if (in[q]) {
+      f[q] = fv3_chk(c, in[q], "zero_unwritten");
+      if (!f[q]) return FV3_ERR_ARG;
+      any = true;
+    }
+  if (!any) return FV3_OK;
+  Real *mfx = f[0], *mfy = f[1], *cx = f[2], *cy = f[3], *heat = f[4];
+  const Geo g = c->g;
+  const int ia = -g.o, ja = -g.o;
+  const int nlo = 1 - ja, nhi = g.nj - 1 - g.o - g.ny;  // rows below / above the compute rows
+  const int wlo = 1 - ia, whi = g.ni - 1 - g.o - g.nx;  // columns left / right of the compute columns
+  const int n_rows = (nlo + nhi) * g.ni, n_cols = (wlo + whi) * g.ny, n_frame = n_rows + n_cols;
+  const int W = (n_frame + 3) / 4;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  launch3<4>(c, (fv3_stream_t)stream, Box{1, W, 1, 4, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int ii, int jj) {
+    const int idx = (jj - 1) * W + (ii - 1);
+    if (idx >= n_frame) return;
+    int i, j;
+    if (idx < n_rows) {  // the row bands: full width
+      const int r = idx / g.ni;
+      i = ia + (idx - r * g.ni);
+      j = r < nlo ? ja + r : g.ny + 1 + (r - nlo);
+    } else {  // the column bands beside the compute rows
+      const int m = idx - n_rows, w = wlo + whi, r = m / w, cidx = m - r * w;
+      j = 1 + r;
+      i = cidx < wlo ? ia + cidx : g.nx + 1 + (cidx - wlo);
+    }
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    const bool xf = i >= 1 && i <= g.nx + 1, yf = j >= 1 && j <= g.ny + 1;  // on an owned x face column / y face row
+    const bool xc = i >= 1 && i <= g.nx, yc = j >= 1 && j <= g.ny;
+    if (mfx && !(xf && yc)) mfx[p] = (Real)0;
+    if (mfy && !(xc && yf)) mfy[p] = (Real)0;
+    if (cx && !(xf && j >= jsd && j <= jed)) cx[p] = (Real)0;
+    if (cy && !(yf && i >= isd && i <= ied)) cy[p] = (Real)0;
+    if (heat) heat[p] = (Real)0;  // (every frame cell lies outside [1, nx] x [1, ny])
+  });
+  launch3<4>(c, (fv3_stream_t)stream, Box{ia, g.ni - 1 - g.o, ja, g.nj - 1 - g.o, g.nz, g.nz}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    if (mfx) mfx[p] = (Real)0;
+    if (mfy) mfy[p] = (Real)0;
+    if (cx) cx[p] = (Real)0;
+    if (cy) cy[p] = (Real)0;
+    if (heat) heat[p] = (Real)0;
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "zero_unwritten");
+}
+
 }  // namespace
 
 extern "C" int fv3_ctx_set_profiling(fv3_ctx *c, int on) {
@@ -236,28 +295,23 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   // advection that follows each call consumes exactly them (dp2 = dp1 + div(mfx) must be the air mass after this call)
   (void)n_map;
   // Round 5: the first sub-step's d_sw STORES 0 + flux instead of accumulating into zeroed fields (fv3_ctx::seq_acc_first: the zero is read from a one-plane
-  // block, not from the field): four 2.3 GB zero launches and four field reads less per call.  A field is zeroed in full the first time this context sees
-  // it, so that the cells d_sw never writes (allocation padding, halo corners) hold the zeros the reference's arrays hold; nothing else writes them.
+  // block, not from the field): four 2.3 GB zero launches and four field reads less per call.  Round 6: the cells d_sw never writes (frame of every plane, padding
+  // level) are zeroed on every call by zero_unwritten -- whatever the arrays held before the call, every cell ends up with what zero + accumulate leaves there.
   // FV3_ACC_STORE=0: zero + accumulate on every sub-step (A/B; same bits: 0 + x is what the accumulation computes on a zeroed field).
   const char *acc_env = getenv("FV3_ACC_STORE");  // (read per call: the parity test flips it in one process)
   const bool acc_store = !(acc_env && acc_env[0] == '0') && n_split > 0 && dsw_honors_acc_first(c);
-  {
+  if (!acc_store) {
     const fv3_field *acc[4] = {&st->mfxd, &st->mfyd, &st->cxd, &st->cyd};
-    for (int a = 0; a < 4; ++a)
-      if (!acc_store || c->acc_zeroed[a] != acc[a]->ptr) {
-        RUN(FV3_OP_GLUE, fv3_zero(c, acc[a], stream));
-        c->acc_zeroed[a] = acc_store ? acc[a]->ptr : nullptr;
-      }
+    for (int a = 0; a < 4; ++a) RUN(FV3_OP_GLUE, fv3_zero(c, acc[a], stream));
   }
-  // (the accumulated damping heat the same way: zeroed in full once per context, then the first sub-step's d_sw forms 0 + heat without reading it)
+  // (the accumulated damping heat the same way: the first sub-step's d_sw forms 0 + heat without reading it)
   const bool heat_reset = n_map == 1 || !fv3_alt("heat_zero_first_call");  // (FV3_ALT: DESIGN §2, uncertain restatement 5)
   // (not under the FV3_ALT: there the smoothed heat is copied back into the field after every call, never-read corner-halo cells included, and the full
   //  zero of a step's first call is what keeps those cells from drifting)
   const bool heat_store = acc_store && heat_reset && cf.d_con > 1.0e-5 && !fv3_alt("heat_zero_first_call");
-  if (heat_reset && (!heat_store || c->acc_zeroed[4] != ws->heat_source.ptr)) {
-    RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
-    c->acc_zeroed[4] = heat_store ? ws->heat_source.ptr : nullptr;
-  }
+  if (heat_reset && !heat_store) RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
+  if (acc_store)
+    RUN(FV3_OP_GLUE, zero_unwritten(c, &st->mfxd, &st->mfyd, &st->cxd, &st->cyd, heat_store ? &ws->heat_source : nullptr, stream));
   RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
   const char *gz_env = getenv("FV3_GZ_FIRST");  // (read per call: the parity test flips it in one process)
   const bool gz_direct = !(gz_env && !strcmp(gz_env, "copy"));

@@ -520,8 +520,7 @@ enum { TF_MFX = 1, TF_DAMP = 2, TF_MASS = 4, TF_EPI = 8, TF_AREA = 16, TF_WIND =
 // fv3_store_sel) and ke(i+1, jf) / ke(i, jr) come from the neighbouring lane / the previous step instead of two more loads.
 template <unsigned FEAT, int HC = 0, bool FA = false>
 static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, Real *fx, Real *fy,
-                        const Real *mfx, const Real *mfy, const Real *mass, int hord_, const Deln *dn, int k0, int k1, const TpEpi *epi, int tile_sel = 0) {
-  // tile_sel = 1: only the tiles tp2d_old_tile() names (the others are the round-5 march's, fv3_tp2x.hip), launched compactly; 2: the same test on the full grid
+                        const Real *mfx, const Real *mfy, const Real *mass, int hord_, const Deln *dn, int k0, int k1, const TpEpi *epi) {
   const int hord = HC ? HC : hord_;
   static_assert(!FA || (FEAT & TF_FD), "FA is a property of the FD instantiations");
   Real *const trash = c->trash;
@@ -578,25 +577,7 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
   unsigned long long *const st_buf = fv3_stamp_buf();
   constexpr unsigned long long st_kid = 2000ull + FEAT + 10000ull * HC;
 #endif
-  struct TileList {
-    int n;
-    short id[40];
-  } tiles;
-  tiles.n = 0;
-  if (tile_sel == 1) {
-    if (!KB) return tp2d_stream_t<FEAT, HC, FA>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord_, dn, k0, k1, epi, 2);
-    for (int by = 0; by < nseg && tiles.n < 40; ++by)
-      for (int bx = 0; bx < nstrip && tiles.n < 40; ++bx) {
-        const int i0 = 1 + bx * TS_OUT, ja = 1 + by * seg, jb = by == nseg - 1 ? g.ny + 1 : ja + seg - 1, r_end_ = jb + 3 < g.ny + g.nh ? jb + 3 : g.ny + g.nh;
-        bool any = false;
-        for (int t = 0; t < g.nsub; ++t) any = any || tp2d_old_tile(g.flags[t], i0, ja, r_end_, g.nx, g.ny);
-        if (any) tiles.id[tiles.n++] = (short)(by * nstrip + bx);
-      }
-    if (tiles.n == 0) return;
-    if (tiles.n >= 40) return tp2d_stream_t<FEAT, HC, FA>(c, s, q, crx, cry, xfx, yfx, fx, fy, mfx, mfy, mass, hord_, dn, k0, k1, epi, 2);
-  }
-  const bool compact = tiles.n > 0;
-  launch_waves<TS_WPE>(c, s, KB ? KB : nstrip, compact ? tiles.n : (KB ? nstrip * nseg : nseg), KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+  launch_waves<TS_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
     int t_, k_;
     if (KB) {
@@ -604,9 +585,8 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
       const int kk = (blk_.bz - t_ * nblk) * KB + blk_.bx;
       if (kk >= nk) return;
       k_ = k0 + kk;
-      const int tid_ = compact ? (int)tiles.id[blk_.by] : blk_.by;
-      blk.by = tid_ / nstrip;
-      blk.bx = tid_ - blk.by * nstrip;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
     } else {
       t_ = blk.bz / nk;
       k_ = k0 + (blk.bz - t_ * nk);
@@ -630,10 +610,6 @@ static void tp2d_stream_t(fv3_ctx *c, fv3_stream_t s, const Real *q, const Real 
     const int ja = 1 + blk.by * seg;                            // first owned row / face
     const int jb = blk.by == nseg - 1 ? ny + 1 : ja + seg - 1;  // last owned face (rows stop at ny)
     const int ied = nx + nh, jsd = 1 - nh, jed = ny + nh;
-    if (tile_sel != 0) {
-      const int r_end_ = jb + 3 < jed ? jb + 3 : jed;
-      if (!tp2d_old_tile(fl, i0, ja, r_end_, nx, ny)) return;
-    }
     Real *lq = (Real *)smem_;         // q on the row being loaded (x-sweep view); index = i - i0 + 6
     Real *lqi = lq + TS_LINE;         // q_i three rows behind
     Real *exp_ = lqi + TS_LINE;       // xfx * fx_in of the lane (read by lane - 1)

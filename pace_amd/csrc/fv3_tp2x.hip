@@ -4,11 +4,10 @@
 // away from the W / E tile edges (bitwise equal: FV3_TP2D_MARCH=old is the A/B switch; tests/test_parity.py::
 // test_single_march_is_bitwise_the_round4_march); CPU twin: oracle/fv3_oracle/fvtp2d.py, d_sw.py, nh.py.  [SURVEY A.3.7, A.4, A.8]
 //
-// The construction is that of fv3_tp4x.hip (see there for the reasons): no rare path in the row step -- the strips that touch a W / E tile
-// edge (per-lane one-sided formulas) and the tiles at a cube corner stay with the round-4 kernel, launched compactly on exactly those tiles
-// (tile_sel); the rows either side of a S / N tile edge and the rows a segment does not own run a general form of the step --, the march
-// unrolled by three with static rotation of the sets in flight, scalar-base addressing, the L sweeps' reconstruction shared between
-// neighbouring lanes, one refined reciprocal per denominator pair.
+// The construction is that of fv3_tp4x.hip (see there for the reasons): no rare path in the branch-free row step -- the rows either side of a S / N tile
+// edge, the rows a segment does not own and the cube-corner remaps / patch fluxes run a general form of the step; the W / E one-sided formulas are
+// evaluated in the lanes of a tile-edge strip (px_al_edge), so the march serves EVERY tile --, the march unrolled by three with static rotation of the sets
+// in flight, scalar-base addressing, the L sweeps' reconstruction shared between neighbouring lanes, one refined reciprocal per denominator pair.
 #include <type_traits>
 
 #include "fv3_ops.h"
@@ -633,6 +632,7 @@ void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, cons
       a.v_side = epi->wind_v_pre;
       sx_side_copy(c, s, epi->wind_u, epi->wind_v, epi->wind_u_pre, epi->wind_v_pre, k0, k1);
       single_march_t<SX_WIND, true>(c, s, a, k0, k1);
+      heat->consumed = true;
     } else {
       single_march_t<SX_WIND>(c, s, a, k0, k1);
     }

@@ -87,9 +87,7 @@ FV3_HD inline void q4_for(F &&f) {
 // HC: 0 = the PPM orders are run-time values (hord_dp / hord_vt / hord_tm of the call); 5 / 6 = all three equal that constant (the
 // reference configs: 6 everywhere): the limiter test of ppm_cell folds to one comparison and the order occupies no register.
 template <int ROLE, int PART, bool M8 = false, bool FD = false, int HC = 0>
-static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi, int tile_sel = 0) {
-  // tile_sel = 1 (interior launches only; 2: the same on the full launch grid): run only the (strip, segment) tiles that touch a cube corner of their sub-domain; the others are the
-  // round-5 march's (fv3_tp4x.hip, q4_corner_tile in fv3_ops.h)
+static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int k_lo, int k_hi) {
   static_assert(!FD || (ROLE != Q4_QUAD && PART != Q4_ALL && !M8), "the fused del-n chains exist for the two-tracer interior / edge marches");
   constexpr int Q4_NT = ROLE == Q4_QUAD ? 4 : 2;
   constexpr bool HAS_AIR = ROLE != Q4_TRC;  // slot 0 is the air mass: its flux is the mass flux of the other slots
@@ -156,28 +154,7 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
   unsigned long long *const st_buf = fv3_stamp_buf();
   constexpr unsigned long long st_kid = 1000ull + 100ull * ROLE + 10ull * PART + (FD ? 1ull : 0ull) + 10000ull * HC;
 #endif
-  // tile_sel = 1: a COMPACT launch -- only the (strip, segment) tiles that are a corner tile for some sub-domain of this context are launched
-  // (the list is made here on the host; a sub-domain for which a listed tile is not a corner tile returns at once).  Launching the full grid and
-  // returning from 27 tiles of 28 cost 1.2 ms per march at C768: 50 000 workgroups that do nothing still have to be dispatched.
-  struct TileList {
-    int n;
-    short id[24];
-  } tiles;
-  tiles.n = 0;
-  if (PART == Q4_INTERIOR && tile_sel == 1) {
-    if (!KB) return dsw_scalars_t<ROLE, PART, M8, FD, HC>(c, s, a_, k_lo, k_hi, 2);  // (plane-major A/B geometry: the full grid with the in-kernel test)
-    for (int by = 0; by < nseg && tiles.n < 24; ++by)
-      for (int bx = 0; bx < nstrip && tiles.n < 24; ++bx) {
-        const int l0 = 1 + bx * Q4_OUT, ca = 1 + by * seg, fb = by == nseg - 1 ? nM + 1 : ca + seg - 1, r_end_ = fb + 3 < nM + nh ? fb + 3 : nM + nh;
-        bool any = false;
-        for (int t = 0; t < g.nsub; ++t) any = any || q4_corner_tile(g.flags[t], l0, ca, r_end_, nL, nM);
-        if (any) tiles.id[tiles.n++] = (short)(by * nstrip + bx);
-      }
-    if (tiles.n == 0) return;
-    if (tiles.n >= 24) return dsw_scalars_t<ROLE, PART, M8, FD, HC>(c, s, a_, k_lo, k_hi, 2);  // (does not happen: at most 4 corners x a few tiles)
-  }
-  const bool compact = tiles.n > 0;
-  launch_waves<WPE>(c, s, KB ? KB : nstrip, compact ? tiles.n : (KB ? nstrip * nseg : nseg), KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+  launch_waves<WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
     Blk blk = blk_;
     int t, k;
     if (KB) {
@@ -185,9 +162,8 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       const int kk = (blk_.bz - t * nblk) * KB + blk_.bx;
       if (kk >= nk) return;
       k = k_lo + kk;
-      const int tid_ = compact ? (int)tiles.id[blk_.by] : blk_.by;
-      blk.by = tid_ / nstrip;
-      blk.bx = tid_ - blk.by * nstrip;
+      blk.by = blk_.by / nstrip;
+      blk.bx = blk_.by - blk.by * nstrip;
     } else {
       t = blk.bz / nk;
       k = k_lo + (blk.bz - t * nk);
@@ -210,10 +186,6 @@ static void dsw_scalars_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a_, int 
       cb = fb < nM ? fb : nM;
     }
     const int Led = nL + nh, Msd = 1 - nh, Med = nM + nh;
-    if (PART == Q4_INTERIOR && tile_sel != 0) {
-      const int r_end_ = fb + 3 < Med ? fb + 3 : Med;
-      if (!q4_corner_tile(fl, l0, ca, r_end_, nL, nM)) return;
-    }
     Real *lq[Q4_NT], *lqi[Q4_NT], *exp_[Q4_NT], *exf[Q4_NT];
     {
       Real *p = (Real *)smem_;
@@ -978,8 +950,8 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
       dsw_scalars_t<Q4_TRC, Q4_INTERIOR, false, true, 6>(c, s, a, kf, nz1);
       if (edges) dsw_scalars_t<Q4_TRC, Q4_EDGE, false, true>(c, s, a, kf, nz1);
     } else {
-      // Round 5: the tiles without a cube corner run the branch-free march of fv3_tp4x.hip (PPM order 6 only), the corner tiles the round-4
-      // kernel (tile_sel = 1).  FV3_DSW_MARCH=old: the round-4 kernel on every tile (A/B; read per call: the parity test flips it).
+      // Round 5: EVERY tile runs the march of fv3_tp4x.hip (PPM order 6 only; W / E one-sided formulas in the lanes, cube-corner remaps and patch
+      // fluxes in its general steps).  FV3_DSW_MARCH=old: the round-4 kernels on every tile (A/B; read per call: the parity test flips it).
       const char *me = getenv("FV3_DSW_MARCH");
       const bool px_on = !(me && !strcmp(me, "old")) && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6;
       // (measured and dropped: the transposed tile-edge marches on the auxiliary stream beside the interior ones -- d_sw 51.5 ms either way)

@@ -7,12 +7,13 @@
 // fp64 arithmetic -- the rest were loop-carried register copies of the rolled march (~6 000), 64-bit address arithmetic (~4 000), reloads
 // of spilled SGPRs (~4 000: 106 live scalars, most of them the state of rare paths) and DPP moves (7 300).  This file is the march
 // with those removed by construction:
-//   * NO RARE PATH IN THE ROW STEP.  The (strip, segment) tiles that touch a cube corner of their sub-domain (corner-halo remaps, 8 x 8
-//     del-n patches: 1 tile of 28 at C768 layout 2 x 2) are left to the round-4 kernel (tile_sel, fv3_tp4.hip), the W / E tile-edge columns
-//     were a launch of their own already (Q4_EDGE).  What is left of "rare" -- the one-sided PPM formulas on the three rows either side
-//     of a S / N tile edge, the rows a segment does not own while its windows fill and drain -- lives in a GENERAL form of the step
-//     (template argument GEN) that runs the first six and the last few rows of a segment; the rows between run the form without a
-//     single branch, ownership test or clamp.
+//   * NO RARE PATH IN THE BRANCH-FREE ROW STEP.  What is rare -- the one-sided PPM formulas on the three rows either side of a S / N tile edge, the rows a
+//     segment does not own while its windows fill and drain, and, on the (strip, segment) tiles that touch a cube corner of their sub-domain (1 tile of 28
+//     at C768 layout 2 x 2), the corner-halo remaps and the faces whose del-n fluxes come from the staged chain's 8 x 8 patches -- lives in a GENERAL form of
+//     the step (template argument GEN) that runs the first six (fifteen next to a S corner patch) and the last few rows of a segment; the rows between run
+//     the form without a single branch, ownership test or clamp.  The W / E one-sided formulas are evaluated in the lanes of a tile-edge strip (px_al_edge).
+//     The march therefore serves EVERY tile of the levels that run their chains inside it (the round-4 kernels of fv3_tp4.hip only serve the sponge levels,
+//     other PPM orders and the A/B switch).
 //   * STATIC ROTATION.  The march is unrolled by three: the three register sets of the rows in flight, the optional inputs and the
 //     del-n metric rows fetched one step ahead rotate by the step's static index Q instead of being copied, and the own-lane LDS ring
 //     of the delay lines has three slots addressed by Q too (immediate offsets: no address arithmetic).

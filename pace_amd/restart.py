@@ -85,15 +85,23 @@ def _unmasked(a, path, name, fill=()):
             raise MissingValuesError(f"{path}: variable {name} has {int(np.ma.count_masked(a))} masked (missing / _FillValue) entries")
         a = a.filled()  # (nothing masked: filled() only drops the mask)
     a = np.asarray(a)
+    if a.dtype.kind not in "fiu":  # (character / string variables -- time stamps, names -- carry no numeric fill value to compare)
+        return a
+    is_float = np.issubdtype(a.dtype, np.floating)
     for f in fill:
         if f is None:
             continue
         try:
-            fv = np.asarray(f, dtype=a.dtype).ravel()
-        except (TypeError, ValueError):
+            raw = np.asarray(f).ravel()
+            if raw.dtype.kind not in "fiu":
+                continue
+            fv = raw.astype(a.dtype)
+        except (TypeError, ValueError, OverflowError):
             continue
-        for v in fv:
-            n = int(np.count_nonzero(a == v)) if not np.isnan(v) else int(np.count_nonzero(np.isnan(a)))
+        for v0, v in zip(raw, fv):
+            if not is_float and (not np.isfinite(v0) or int(v0) != int(v)):  # (a fill value the variable's own integer type cannot hold cannot occur in it)
+                continue
+            n = int(np.count_nonzero(np.isnan(a))) if (is_float and np.isnan(v)) else int(np.count_nonzero(a == v))
             if n:
                 raise MissingValuesError(f"{path}: variable {name} has {n} masked (missing / _FillValue = {v!r}) entries")
     return a

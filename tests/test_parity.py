@@ -416,7 +416,7 @@ def test_del_n_chains_inside_the_marches_are_bitwise_the_del6_launches(backend, 
 @pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (65, (1, 1), "0"), (200, (1, 1), "96"), (200, (1, 1), "32")])
 def test_pair_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout, seg):
     """d_sw's two-tracer marches in their round-5 form (fv3_tp4x.hip: branch-free row step unrolled by three, general steps at the ends
-    of a segment, cube-corner tiles left to the round-4 kernel) against the round-4 kernel on every tile (FV3_DSW_MARCH=old): the same
+    of a segment and on the cube-corner patches; every tile) against the round-4 kernels on every tile (FV3_DSW_MARCH=old): the same
     expressions in the same order, so every field is bitwise equal -- on sub-domains with interior strips between tile-edge strips,
     with S / N tile edges in the first / last segment, with several segments (whole triples, and segment lengths that leave one or
     two rows to the general steps) and on 2 x 2 ranks (one cube corner per sub-domain)."""
@@ -437,8 +437,8 @@ def test_pair_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout,
 @pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (200, (1, 1), "96"), (200, (1, 1), "32"), (250, (2, 2), "0")])
 def test_single_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout, seg):
     """The single-tracer transports with their del-n chain inside -- d_sw's vorticity transport with the wind update, update_dz_d's
-    interface-height transport -- in their round-5 form (fv3_tp2x.hip; the strips at a W / E tile edge and the cube-corner tiles left to
-    the round-4 kernel, launched on exactly those tiles) against the round-4 kernel on every tile (FV3_TP2D_MARCH=old): bitwise equal
+    interface-height transport -- in their round-5 form (fv3_tp2x.hip; every tile: W / E one-sided formulas in the lanes, cube-corner
+    remaps and patch fluxes in the general steps) against the round-4 kernel on every tile (FV3_TP2D_MARCH=old): bitwise equal
     states, on sub-domains with interior strips between tile-edge strips, several row segments and 2 x 2 ranks."""
     nz = 6
     part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
@@ -471,6 +471,28 @@ def test_damping_heat_in_the_vorticity_march_is_bitwise_the_heat_kernel(backend,
     for r in range(part.total_ranks):
         for name in STATE:
             assert np.array_equal(res["fused"][r][name], res["separate"][r][name]), f"{name} rank {r}"
+
+
+@pytest.mark.parametrize("n, layout, seg, kw", [(24, (2, 2), "0", {}), (130, (1, 1), "0", {}), (140, (2, 2), "32", {}), (48, (1, 1), "0", dict(nord=2)), (12, (1, 1), "0", {}),
+                                                (70, (1, 1), "0", dict(nord=1, dddmp=0.0)), (16, (2, 2), "0", {})])
+def test_fused_wind_stage_is_bitwise_the_staged_kernels(backend, monkeypatch, n, layout, seg, kw):
+    """d_sw's wind-branch stage kernels -- cell-mean vorticity, corner kinetic energy, the divergence-damping iteration, the corner interpolation of the vorticity
+    and the Smagorinsky-type damping -- as ONE march (fv3_wind.hip; the tile-edge corners by one per-point launch, the chain's cube-corner patches from the staged
+    chain) against the five staged launches (FV3_DSW_WINDSTAGE=staged): every field bitwise equal over two calls.  wk feeds the vorticity transport, ke and the
+    damping field the wind update and the damping heat, so a wrong or missing cell / corner shows in u / v / pt.  Sub-domains with and without tile edges on
+    every side (2 x 2 layouts), one and several strips / row segments, damping orders 1 - 3, the Smagorinsky term switched off."""
+    nz = 6  # (levels 0..2 are the sponge layers: staged kernels either way; 3..5 run the fused march)
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2, **kw))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("fused", "staged"):
+        monkeypatch.setenv("FV3_DSW_WINDSTAGE", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["fused"][r][name], res["staged"][r][name]), f"{name} rank {r}"
 
 
 @pytest.mark.parametrize("n, layout, seg", [(24, (2, 2), "0"), (130, (1, 1), "0"), (140, (2, 2), "32"), (48, (1, 1), "0")])
@@ -551,6 +573,39 @@ def test_first_sub_step_store_of_the_flux_accumulators_is_bitwise_zero_plus_accu
         for name in STATE:
             assert np.array_equal(res["1"][r][name], res["0"][r][name]), f"{name} rank {r}"
         assert np.abs(res["1"][r]["mfxd"]).max() > 0.0 and np.abs(res["1"][r]["cxd"]).max() > 0.0
+
+
+@pytest.mark.parametrize("n, layout, kw", [(24, (2, 2), dict(n_split=3)), (12, (1, 1), dict(n_split=2)), (70, (1, 1), dict(n_split=1))])
+def test_acoustic_call_does_not_depend_on_what_the_accumulators_held(backend, monkeypatch, n, layout, kw):
+    """Statelessness of the call [REF tests/main/fv3core/test_dycore_call.py:169-190]: the reference empties mfxd / mfyd / cxd / cyd (and its heat_source work
+    array) in full at the start of every call.  Here the first sub-step stores 0 + flux on the cells d_sw writes and the sequencer zeroes the REST of every plane
+    (frame, padding level) on every call -- no "already zeroed" flag.  Between two calls the host overwrites the whole storages with NaN (a restart load, a
+    debugger's poison, an allocator handing the address to someone else in between): the second call must leave every element of the storages -- halos, the 3 x 3
+    blocks beyond a cube corner, the padding level -- bitwise what zero + accumulate (FV3_ACC_STORE=0) leaves, and no NaN anywhere."""
+    from pace_amd.dyn_core import AcousticDynamics, DycoreState
+    from pace_amd.halo import Layout
+
+    nz = 5
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, kw)
+    init = [dict({k: v.copy() for k, v in s.items()}, phis=p) for s, p in zip(ost, phis)]
+    raw = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV3_ACC_STORE", mode)
+        sf = stencil_factory_for(backend)(grids, cfg, get_constants())
+        st = DycoreState.from_arrays(sf.quantity_factory, init)
+        dyn = AcousticDynamics(Layout(part, 1, 0), grids, sf, config=cfg, phis=st.phis, state=st)
+        dyn(st, 60.0, n_map=1)
+        for q in (st.mfxd, st.mfyd, st.cxd, st.cyd, dyn._heat_source):
+            q.storage.fill_(float("nan"))
+        dyn(st, 60.0, n_map=2)
+        if backend != "hostemu":
+            torch.cuda.synchronize()
+        raw[mode] = {name: getattr(st, name).storage.cpu().numpy().copy() for name in STATE}
+        raw[mode]["heat_source"] = dyn._heat_source.storage.cpu().numpy().copy()
+    for name, a in raw["1"].items():
+        assert np.all(np.isfinite(a)), f"{name}: the call left cells it did not define"
+        assert np.array_equal(a, raw["0"][name]), f"{name}: differs from zero + accumulate somewhere in the storage"
+    assert np.abs(raw["1"]["mfxd"]).max() > 0.0 and np.abs(raw["1"]["cyd"]).max() > 0.0
 
 
 @pytest.mark.parametrize("n, layout", [(130, (1, 1)), (140, (2, 2)), (24, (2, 2))])

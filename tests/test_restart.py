@@ -105,6 +105,12 @@ def test_restart_refuses_masked_values():
     assert restart._unmasked(raw, "f.nc", "u", restart._fill_attrs({"units": "m"})) is not None
     with pytest.raises(restart.MissingValuesError):
         restart._unmasked(np.array([1.0, np.nan]), "f.nc", "u", (np.nan,))
+    # a character variable with a _FillValue (time stamps, names) is passed through, not compared; a fill value its integer type cannot hold cannot occur in it
+    chars = np.array([b"a", b"b"], dtype="S1")
+    assert restart._unmasked(chars, "f.nc", "stamp", (b" ",)) is chars
+    assert restart._unmasked(np.array([1, 2], dtype=np.int8), "f.nc", "flag", (np.int64(-32767),)) is not None
+    with pytest.raises(restart.MissingValuesError):
+        restart._unmasked(np.array([1, -127], dtype=np.int8), "f.nc", "flag", (np.int8(-127),))
 
 
 def test_restart_shape_mismatch_is_refused(hostemu, tmp_path):

@@ -63,18 +63,61 @@ def window(path, counter, first, last):
     return sum(sel), len(sel)
 
 
+# One acoustic sub-step in launch order (the counter passes profile exactly one: --k-split 1 --n-split 1): an operator's window opens at the first launch whose
+# name starts with one of its markers and closes where the next operator's opens; launches of the sequencer's glue (halo gathers, copies, zero launches) and
+# of PyTorch's set-up are left out of every window.
+OPERATORS = [
+    ("c_sw", ("fv3_c_sw", "csw_")),
+    ("update_dz_c", ("fv3_update_dz_c",)),
+    ("riem_solver_c", ("fv3_riem_solver_c",)),
+    ("p_grad_c", ("fv3_p_grad_c",)),
+    ("d_sw", ("fxadv",)),
+    ("update_dz_d", ("edge_profile", "fv3_update_dz_d")),
+    ("riem_solver3", ("fv3_riem_solver3",)),
+    ("pk3_halo_edge_pe", ("fv3_edge_pe", "fv3_pk3_halo")),
+    ("nh_p_grad", ("nh_pgf", "fv3_nh_p_grad")),
+    ("ray_fast", ("fv3_ray_fast",)),
+    ("diffusive_heating", ("d2_launch", "fv3_del2", "del2_", "fv3_apply_diffusive")),
+]
+GLUE = ("fv3_gather_kernel", "copy_frames", "copy_part", "fv3_zero", "zero_unwritten", "fv3_set_gz", "fv3_copy", "void at::", "__amd_rocclr", "void  ", "void rocblas")
+
+
+def operator_windows(path, counter):
+    """{operator: [counter sum, launches, ns]} over the launches of one sub-step, attributed as described above"""
+    rows = [(int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort()
+    out = {name: [0.0, 0, 0.0] for name, _ in OPERATORS}
+    cur, nxt = None, 0
+    for _, n, v, ns in rows:
+        for q in range(nxt, len(OPERATORS)):
+            if n.startswith(OPERATORS[q][1]):
+                cur, nxt = OPERATORS[q][0], q + 1
+                break
+        if cur is None or n.startswith(GLUE):
+            continue
+        e = out[cur]
+        e[0] += v
+        e[1] += 1
+        e[2] += ns
+    return out
+
+
 def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, json_out=None):
     rd = load(fetch_csv, "FETCH_SIZE")
     wr = load(write_csv, "WRITE_SIZE")
     names = sorted(set(rd) | set(wr), key=lambda n: -(rd.get(n, [0, 0, 0])[2]))
     kb = 1024.0
     rs = ws = 1.0
+    copy_gbps = None
     cp = [n for n in names if n.startswith("fv3_copy")]
     if cp and copy_bytes:
         c = cp[0]
         raw_r = rd[c][1] / rd[c][0] * kb
         raw_w = wr[c][1] / wr[c][0] * kb
         rs, ws = copy_bytes / raw_r, copy_bytes / raw_w
+        copy_ms = rd[c][2] / rd[c][0] / 1e6
+        copy_gbps = 2.0 * copy_bytes / (copy_ms * 1e-3) / 1e9
         print(f"calibration on {c}: known {copy_bytes / 1e6:.1f} MB each way per launch; raw FETCH_SIZE {raw_r / 1e6:.1f} MB (scale {rs:.3f}), raw WRITE_SIZE {raw_w / 1e6:.1f} MB (scale {ws:.3f})\n")
     elif copy_bytes:
         # (the sequencer's default order has no fv3_copy launch any more: the counter passes run with FV3_GZ_FIRST=copy to have one -- tools/collect_profiles.sh)
@@ -90,9 +133,25 @@ def main(fetch_csv, write_csv, top=40, copy_bytes=None, first=None, last=None, j
                 import json
 
                 json.dump({"csrc_hash": _src_hash(), "window": [first, last], "launches": n1, "read_bytes": r * kb * rs, "write_bytes": w * kb * ws, "bytes": r * kb * rs + w * kb * ws,
-                           "read_scale": rs, "write_scale": ws, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"
+                           "read_scale": rs, "write_scale": ws, "copy_GBps": copy_gbps, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), calibrated on fv3_copy"
                            + ("; " + os.environ["FV3_PMC_NOTE"] if os.environ.get("FV3_PMC_NOTE") else "")},
                           open(json_out, "w"))
+    if json_out and copy_gbps:
+        # every operator of the sub-step from the same two passes (bench.py: roofline_operators[*].traffic_GB); next to traffic_d_sw.json
+        import json
+
+        ro, wo = operator_windows(fetch_csv, "FETCH_SIZE"), operator_windows(write_csv, "WRITE_SIZE")
+        ops = {k: {"read_GB": ro[k][0] * kb * rs / 1e9, "write_GB": wo[k][0] * kb * ws / 1e9, "traffic_GB": (ro[k][0] * kb * rs + wo[k][0] * kb * ws) / 1e9,
+                   "launches": ro[k][1], "ms_serialized_pmc_pass": ro[k][2] / 1e6} for k in ro if ro[k][1]}
+        json.dump({"csrc_hash": _src_hash(), "copy_GBps": copy_gbps, "operators": ops, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of ONE acoustic "
+                   "sub-step, calibrated on fv3_copy; windows by launch order (tools/pmc_traffic.py OPERATORS), sequencer glue and halo gathers left out"
+                   + ("; " + os.environ["FV3_PMC_NOTE"] if os.environ.get("FV3_PMC_NOTE") else "")},
+                  open(os.path.join(os.path.dirname(json_out), "traffic_operators.json"), "w"), indent=1)
+        print("| operator | launches | ms (serialized pmc pass) | read GB | write GB | total GB |")
+        print("|---|---:|---:|---:|---:|---:|")
+        for k, v in ops.items():
+            print(f"| {k} | {v['launches']} | {v['ms_serialized_pmc_pass']:.2f} | {v['read_GB']:.2f} | {v['write_GB']:.2f} | {v['traffic_GB']:.2f} |")
+        print(f"\nfv3_copy in this pass: {copy_gbps:.0f} GB/s (read + write) -- the measured-copy ceiling `roofline.frac_of_measured_copy` is taken against\n")
     print("| kernel | calls | avg ms (pmc run) | read GB/launch | write GB/launch | GB/s |")
     print("|---|---:|---:|---:|---:|---:|")
     for n in names[:top]:
