@@ -1291,21 +1291,40 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       (ke + b)[p] += vd;
     });
     // ---- the fused wind stage on the levels kfz .. nz1 (fv3_wind.hip).  Order: the damping chain's cube-corner patches first (the march reads their values
-    //      where its own chain is wrong; their work arrays are scratch here -- the march still reads the C-grid winds), the march, then ONE per-point launch on
-    //      the three outermost corner rows / columns next to a cube-tile edge: kinetic energy (ke_value), corner vorticity (a2b_point on the wk the march has
+    //      where its own chain is wrong; their work arrays are scratch here -- the march still reads the C-grid winds), the march, then two per-point launches on
+    //      the three outermost corner rows / columns next to a cube-tile edge: kinetic energy (ke_point), then corner vorticity (a2b_point on the wk the march has
     //      stored) and the damping, with the iterated divergence the march exported there.
     if (kfz <= nz1) {
       divdamp_patches(c, s, divgd, dnew, c->scratch[SC_TP_FY2], c->scratch[SC_TP_FX2], c->scratch[SC_M], nord_max, kfz, nz1);
       const WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
       wind_stage_march(c, s, ws);
+      // (two launches: with ke_value and a2b_point in one closure the geometry block went to scratch memory -- 1600 B per lane, 7 ms for these 3 % of the corners)
       launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, kfz, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
                      [=] FV3_HD(int w_, int t, int k, int i, int j) {
         const int fl = g.flags[t];
         if (!(fl & (w_ == 0 ? FV3_W : w_ == 1 ? FV3_E : w_ == 2 ? FV3_S : FV3_N))) return;
         if (w_ >= 2 && (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2))) return;  // covered by the column windows
+        ke_point(t, k, i, j);
+      });
+      const int nfr = g.nx + 1 > g.ny + 1 ? g.nx + 1 : g.ny + 1;
+      launch3(c, s, Box{1, nfr, 1, 12, kfz, nz1}, [=] FV3_HD(int t, int k, int a_, int side) {
+        const int fl = g.flags[t];
+        int i, j;
+        // side 1..3: columns 1..3 (W)   4..6: columns npx-2..npx (E)   7..9: rows 1..3 (S)   10..12: rows npy-2..npy (N)
+        if (side <= 6) {
+          if (a_ > g.ny + 1) return;
+          if (!(fl & (side <= 3 ? FV3_W : FV3_E))) return;
+          i = side <= 3 ? side : g.npx - 6 + side;
+          j = a_;
+        } else {
+          if (a_ > g.nx + 1) return;
+          if (!(fl & (side <= 9 ? FV3_S : FV3_N))) return;
+          j = side <= 9 ? side - 6 : g.npy - 12 + side;
+          i = a_;
+          if (((fl & FV3_W) && i <= 3) || ((fl & FV3_E) && i >= g.npx - 2)) return;  // covered by the column sides
+        }
         const long b = t * g.st + k * g.sk;
         const unsigned p = IX(i, j);
-        const Real kev = ke_value(t, k, i, j);
         const Real wkbv = a2b_point(g, wk + b, t, i, j);
         const Real dpc = (divgd + b)[p];
         Real vo = (Real)0;
@@ -1313,7 +1332,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         const Real damp2 = g.da_min_c * fv3_max(g.d2_divg[k], fv3_min((Real)0.20, dddmp * vo));
         const Real vd = damp2 * dpc + tab.dd8[k] * (dnew + b)[p];
         (vdamp + b)[p] = vd;
-        (ke + b)[p] = kev + vd;
+        (ke + b)[p] += vd;
       });
       // (the operator's own contract leaves the iterated divergence in divgd; inside the sequencer nobody reads it)
       if (keep_divgd) launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kfz, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
