@@ -1067,6 +1067,35 @@ inline void launch_wave_groups(const fv3_ctx *c, fv3_stream_t s, int gx, int gz,
 #endif
 }
 
+// ... on a three-dimensional launch grid, the wave's index in its group handed to the body: f(blk, smem, wave).  Workgroups whose waves run DIFFERENT roles
+// on the same tile and hand rows to each other through LDS (the coupled two-tracer marches of d_sw, fv3_tp4x.hip).  Device only: the host emulation runs its
+// "waves" one after the other to completion, so a hand-over between concurrently running waves has no emulation -- callers keep an uncoupled form for it.
+#ifndef FV3_HOST_EMU
+template <int WPE, int NW, class F>
+__global__ void __launch_bounds__(FV3_WAVE * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) fv3_kwg3(GridMap m, F f) {
+  extern __shared__ __attribute__((aligned(16))) char fv3_smem[];
+  int bx, by, bz;
+  if (!fv3_tile(m, bx, by, bz)) return;
+  Blk b{(int)(threadIdx.x & (FV3_WAVE - 1)), FV3_WAVE, bx, by, bz};
+  f(b, fv3_smem, __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FV3_WAVE)));
+}
+template <int WPE, int NW, class F>
+inline void launch_wave_groups3(const fv3_ctx *c, fv3_stream_t s, int gx, int gy, int gz, size_t smem_bytes, F f) {
+  if (gx <= 0 || gy <= 0 || gz <= 0) return;
+  (void)c;
+  dim3 grid;
+  const GridMap m = fv3_grid(gx, gy, gz, &grid);
+  if (smem_bytes > 64 * 1024) {
+    static size_t granted = 0;
+    if (smem_bytes > granted) {
+      (void)hipFuncSetAttribute((const void *)fv3_kwg3<WPE, NW, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+      granted = smem_bytes;
+    }
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kwg3<WPE, NW, F>), grid, dim3(FV3_WAVE * NW, 1, 1), smem_bytes, s, m, f);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // cube-corner halo reads.  The reference fills the 3x3 corner block in place before every
 // directional sweep (copy_corners / fill_4corners / fill_corners); the fills are pure

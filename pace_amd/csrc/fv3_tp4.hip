@@ -956,8 +956,15 @@ void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mod
       const bool px_on = !(me && !strcmp(me, "old")) && a.hord_dp == 6 && a.hord_vt == 6 && a.hord_tm == 6;
       // (measured and dropped: the transposed tile-edge marches on the auxiliary stream beside the interior ones -- d_sw 51.5 ms either way)
       if (px_on) {  // (every tile: the W / E one-sided formulas in the lanes, the cube-corner remaps / patch fluxes in the general steps)
-        dsw_pair_march(c, s, a, 1, kf, nz1);
-        dsw_pair_march(c, s, a, 2, kf, nz1);
+        // Round 6, FV3_DSW_MARCH=coupled (measured, NOT the default): the two roles as coupled wave pairs -- one workgroup of two waves per tile, the air-mass
+        // fluxes / old air mass / shared rows handed over through LDS (fv3_tp4x.hip, PX_BOTH).  Bitwise equal and 27 GB lighter, but 24.7 ms against 14.8 for the
+        // two launches at C768: a role's waves in flight are halved and every row step costs the slower role's time (EXPERIMENTS R6-5).
+        if (me && !strcmp(me, "coupled")) {
+          dsw_pair_march(c, s, a, 3, kf, nz1);
+        } else {
+          dsw_pair_march(c, s, a, 1, kf, nz1);
+          dsw_pair_march(c, s, a, 2, kf, nz1);
+        }
       } else {
         dsw_scalars_t<Q4_AIR, Q4_INTERIOR, false, true>(c, s, a, kf, nz1);
         if (edges) dsw_scalars_t<Q4_AIR, Q4_EDGE, false, true>(c, s, a, kf, nz1);

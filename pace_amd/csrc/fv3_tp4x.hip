@@ -36,14 +36,18 @@ namespace {
 
 #define PX_OUT 58
 #define PX_ORD 6
-enum { PX_AIR = 1, PX_TRC = 2 };
+enum { PX_AIR = 1, PX_TRC = 2, PX_BOTH = 3 };
 #ifndef PX_WPE
 #define PX_WPE (sizeof(Real) == 4 ? 3 : 2)  // (fp32: 168 registers)
 #endif
 
-template <int ROLE>
+// MODE PX_AIR / PX_TRC: one role per launch (the round-5 form).  PX_BOTH (round 6, device only): workgroups of TWO waves on the same (strip, segment, level) tile --
+// wave 0 runs the delp + w role, wave 1 the q_con + pt role one row step behind it -- and what the second role used to read back from memory is handed over
+// through LDS: the air-mass fluxes of the sub-step (written by one march and read by the other: 9.4 GB at C768), the old air mass, and the five rows both
+// roles read (Courant numbers, area fluxes, cell areas: 11.7 GB).  One workgroup barrier per row step (`s_waitcnt lgkmcnt(0); s_barrier`: the prefetched rows
+// stay in flight); the hand-over block has three slots addressed by the step's static index like the rings.  Same expressions on the same values: the same bits.
+template <int MODE>
 void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int k_hi) {
-  constexpr bool AIR = ROLE == PX_AIR;
   const Geo g = c->g;
   const int nk = k_hi - k_lo + 1;
   if (nk <= 0) return;
@@ -59,17 +63,13 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
   const unsigned char *gflags = c->g_dev->flags;
   const MPtr garea = g.area, grarea = g.rarea, gd6L = g.del6_v, gd6M = g.del6_u, gdya = g.dya, gdxa = g.dxa;
   const Geo *gp = c->g_dev;
-  // the staged chain's damping fluxes on the cube-corner patches, per tracer slot (L faces, M faces)
-  const Real *const pL0 = AIR ? a.dpx : a.dqx, *const pL1 = AIR ? a.dwx : a.dtx, *const pM0 = AIR ? a.dpy : a.dqy, *const pM1 = AIR ? a.dwy : a.dty;
-  // what a wave reads / writes (ROLE folds the unused ones away)
-  const Real *const q0f = AIR ? a.delp : a.q_con, *const q1f = AIR ? a.w : a.pt;
   const Real *const crL = a.crx, *const crM = a.cry, *const afL = a.xfx, *const afM = a.yfx;
   Real *const accL = a.mfx, *const accM = a.mfy;          // AIR: accumulated air-mass fluxes (read + written)
-  const bool acc_first = AIR && a.acc_first && a.zeros;
+  const bool acc_first_ = a.acc_first && a.zeros;
   const Real *const zerosb = a.zeros;
-  Real *const flL = a.fx, *const flM = a.fy;              // air-mass fluxes of the sub-step: AIR writes, TRC reads
+  Real *const flL = a.fx, *const flM = a.fy;              // air-mass fluxes of the sub-step: AIR writes, TRC reads (uncoupled form)
   const Real *const oldm = a.delp;                        // TRC: the old air mass
-  Real *const out0 = AIR ? a.o_delp : a.o_q_con, *const out1 = AIR ? a.o_w : a.o_pt, *const heat = a.heat;
+  Real *const heat = a.heat;
   // per-level coefficients: d2 of iteration 0 = c0 * q (delp, w); the mass-weighted damping of q_con / pt
   const Deln dn_vt = a.dn_vt, dn_t = a.dn_t, dn_w = a.dn_w;
   const Real *ke_bg_k = g.ke_bg;
@@ -77,7 +77,20 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
   constexpr int NRING = 9;  // ring variables: del-n metric rows (M faces, L faces, 1 / area), Courant number, area flux, area, inner L flux x 2, cell width (tile-edge strips)
   enum { RG_DU = 0, RG_DV = 1, RG_RA = 2, RG_CX = 3, RG_XV = 4, RG_AR = 5, RG_FI = 6, RG_MX = 8 };
   const size_t smem = sizeof(Real) * (size_t)NRING * 3 * FV3_WAVE;
-  launch_waves<PX_WPE>(c, s, KB ? KB : nstrip, KB ? nstrip * nseg : nseg, KB ? g.nsub * nblk : g.nsub * nk, smem, [=] FV3_HD(const Blk &blk_, char *smem_) {
+  // hand-over block of the coupled form: [slot 3][variable 8][lane 64]
+  enum { XC_CX = 0, XC_XV = 1, XC_AR = 2, XC_CY = 3, XC_YV = 4, XC_FX = 5, XC_FY = 6, XC_OM = 7, NXCH = 8 };
+  auto body = [=] FV3_HD(auto role_tag, auto cpl_tag, const Blk &blk_, char *smem_, Real *xch) {
+    constexpr bool AIR = decltype(role_tag)::value == PX_AIR;
+    constexpr bool CPL = decltype(cpl_tag)::value;      // coupled: this wave shares its tile with the wave of the other role
+    constexpr bool XIN = CPL && !AIR;                   // ... and takes the shared rows / the air-mass fluxes / the old air mass from the hand-over block
+    (void)xch;
+    // the staged chain's damping fluxes on the cube-corner patches, per tracer slot (L faces, M faces)
+    const Real *const pL0 = AIR ? a.dpx : a.dqx, *const pL1 = AIR ? a.dwx : a.dtx, *const pM0 = AIR ? a.dpy : a.dqy, *const pM1 = AIR ? a.dwy : a.dty;
+    // what a wave reads / writes (the role folds the unused ones away)
+    const Real *const q0f = AIR ? a.delp : a.q_con, *const q1f = AIR ? a.w : a.pt;
+    Real *const out0 = AIR ? a.o_delp : a.o_q_con, *const out1 = AIR ? a.o_w : a.o_pt;
+    const bool acc_first = AIR && acc_first_;
+    auto XC = [&](int var, int slot) -> Real * { return xch + (slot * NXCH + var) * FV3_WAVE; };
     int t, k, bx, by;
     if (KB) {
       t = blk_.bz / nblk;
@@ -171,11 +184,16 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       Row w;
       w.q0 = px_ld3(q0b, p0);
       w.q1 = px_ld3(q1b, p0);
-      w.cx = px_ld3(crLb, p0);
-      w.xv = px_ld3(afLb, p0);
-      w.ar = px_ld(areab, p0);
-      w.cy = px_ld3(crMb, pf);
-      w.yv = px_ld3(afMb, pf);
+      if constexpr (XIN) {  // (the other role's wave hands these over: Row's slots are filled from the hand-over block at the top of the step)
+        w.cx = w.xv = w.ar = w.cy = w.yv = (Real)0;
+        (void)pf;
+      } else {
+        w.cx = px_ld3(crLb, p0);
+        w.xv = px_ld3(afLb, p0);
+        w.ar = px_ld(areab, p0);
+        w.cy = px_ld3(crMb, pf);
+        w.yv = px_ld3(afMb, pf);
+      }
       return w;
     };
     auto load_opt = [&](int q, int r, int l, auto gen_tag) {  // what step r consumes: row r-3, face r-2 (into set q)
@@ -185,10 +203,13 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       if constexpr (AIR) {
         Ox[q][l] = px_ld3(accLb_ld, p3);
         Oy[q][l] = px_ld3(accMb_ld, pf);
-      } else {
+      } else if constexpr (!XIN) {
         Ox[q][l] = px_ld3(flLb, p3);
         Oy[q][l] = px_ld3(flMb, pf);
         Om[q][l] = px_ld3(oldmb, pf);
+      } else {
+        (void)p3;
+        (void)pf;
       }
     };
     auto load_met = [&](int r, int l) -> Met {
@@ -259,6 +280,30 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
       const bool m_edge = GEN && ((Mlo && sy >= 0 && sy <= 2) || (Mhi && sy >= npM - 1 && sy <= npM + 1));
       const int jr = r - 3, jf = r - 2;
       const bool fx_row = !GEN || (jr >= ca && jr <= cb), fy_row = !GEN || (jf >= fa && jf <= fb);
+      if constexpr (CPL) {
+        if (GEN && XIN && r_ < r0) {  // (the lagging wave has no step in the first row step of its group)
+          blk_.group_sync();
+          return;
+        }
+        FV3_LANES(blk_, lane, l) {
+          if constexpr (XIN) {  // what the other role's wave left for this step: its slot Q
+            R[Q][l].cx = XC(XC_CX, Q)[lane];
+            R[Q][l].xv = XC(XC_XV, Q)[lane];
+            R[Q][l].ar = XC(XC_AR, Q)[lane];
+            R[Q][l].cy = XC(XC_CY, Q)[lane];
+            R[Q][l].yv = XC(XC_YV, Q)[lane];
+            Ox[Q][l] = XC(XC_FX, Q)[lane];
+            Oy[Q][l] = XC(XC_FY, Q)[lane];
+            Om[Q][l] = XC(XC_OM, Q)[lane];
+          } else {              // the five rows both roles read
+            XC(XC_CX, Q)[lane] = R[Q][l].cx;
+            XC(XC_XV, Q)[lane] = R[Q][l].xv;
+            XC(XC_AR, Q)[lane] = R[Q][l].ar;
+            XC(XC_CY, Q)[lane] = R[Q][l].cy;
+            XC(XC_YV, Q)[lane] = R[Q][l].yv;
+          }
+        }
+      }
 #if PX_ABL == 1
       FV3_LANES(blk_, lane, l) {
         const Met mc_ = MN[Q][l];
@@ -486,8 +531,9 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
             if (fx_row && own_x[l]) {
               const unsigned p = pcolB[l] + (unsigned)jr * rowB;
               FV3_MARCH_ST(*fv3_at(accLb, p), Ox[Q][l] + v);
-              FV3_MARCH_ST(*fv3_at(flLb, p), v);
+              if constexpr (!CPL) FV3_MARCH_ST(*fv3_at(flLb, p), v);
             }
+            if constexpr (CPL) XC(XC_FX, Q)[lane] = v;  // (every lane: the other role reads its own and the next lane's)
             vm = v;
           } else {  // riding on the air-mass flux; q_con / pt with the mass-weighted damping flux
             v = (Real)0.5 * (fxout + fi3) * vm;
@@ -542,7 +588,11 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
             if (fy_row && own_y[l]) {
               const unsigned p = pcolB[l] + (unsigned)jf * rowB;
               FV3_MARCH_ST(*fv3_at(accMb, p), Oy[Q][l] + v);
-              FV3_MARCH_ST(*fv3_at(flMb, p), v);
+              if constexpr (!CPL) FV3_MARCH_ST(*fv3_at(flMb, p), v);
+            }
+            if constexpr (CPL) {
+              XC(XC_FY, Q)[lane] = v;
+              XC(XC_OM, Q)[lane] = w3[0][l];  // the old air mass of (lc, r-2)
             }
             vm = v;
           } else {
@@ -600,6 +650,15 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
         RG(RG_AR, Q)[lane] = ar;
       }
       PX_FENCE();
+      if constexpr (CPL) blk_.group_sync();  // one barrier per row step of the group (LDS traffic complete; the vector-memory counter is NOT drained)
+    };
+    // a row step of the GROUP: the leading wave (delp + w) at row r, the lagging wave (q_con + pt) at row r - 1 with the rotation index that row has
+    auto gstep = [&](const int r_, auto q_tag, auto gen_tag) {
+      constexpr int Q = decltype(q_tag)::value;
+      if constexpr (XIN)
+        step(r_ - 1, std::integral_constant<int, (Q + 2) % 3>{}, gen_tag);
+      else
+        step(r_, q_tag, gen_tag);
     };
 
     // ---- the march: 6 general steps (windows fill; S tile edge), branch-free triples, general triples to the end (rows past r_end are
@@ -608,35 +667,61 @@ void pair_march_t(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int k_lo, int
     if (r_hi > r_end - 2) r_hi = r_end - 2;        // ... and requests no row past the segment's last
     if (Mhi && r_hi > nM) r_hi = nM;               // ... and meets no N tile-edge formula
     if (pz && r_hi > nM - FV3_D6_PATCH + 2) r_hi = nM - FV3_D6_PATCH + 2;  // ... and consumes no face of a N corner patch (first: r - 2 = nM + 2 - PATCH)
-    const int head = pz && r0 <= FV3_D6_PATCH + 3 ? 15 : 6;                // (S corner patch: faces up to r - 3 = PATCH)
+    // (coupled: both waves of a group run the SAME sequence of group steps -- one barrier each --, the lagging wave one row behind: one more general triple at
+    //  the head, so that its first branch-free row has its windows filled too, and one more row at the end)
+    const int head = (pz && r0 <= FV3_D6_PATCH + 3 ? 15 : 6) + (CPL ? 3 : 0);  // (S corner patch: faces up to r - 3 = PATCH)
     int r = r0;
 #pragma clang loop unroll(disable)
     for (int part = 0; part < 2; ++part) {  // (one copy of the general triple in the code: head and tail are two trips of this loop)
-      const int stop = part == 0 ? r0 + head - 1 : r_end;
+      const int stop = part == 0 ? r0 + head - 1 : r_end + (CPL ? 1 : 0);
 #pragma clang loop unroll(disable)
       for (; r <= stop; r += 3) {
-        step(r, std::integral_constant<int, 0>{}, std::true_type{});
-        step(r + 1, std::integral_constant<int, 1>{}, std::true_type{});
-        step(r + 2, std::integral_constant<int, 2>{}, std::true_type{});
+        gstep(r, std::integral_constant<int, 0>{}, std::true_type{});
+        gstep(r + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        gstep(r + 2, std::integral_constant<int, 2>{}, std::true_type{});
       }
       if (part == 0) {
 #pragma clang loop unroll(disable)
         for (; r + 2 <= r_hi; r += 3) {
-          step(r, std::integral_constant<int, 0>{}, std::false_type{});
-          step(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
-          step(r + 2, std::integral_constant<int, 2>{}, std::false_type{});
+          gstep(r, std::integral_constant<int, 0>{}, std::false_type{});
+          gstep(r + 1, std::integral_constant<int, 1>{}, std::false_type{});
+          gstep(r + 2, std::integral_constant<int, 2>{}, std::false_type{});
         }
       }
     }
-  });
+  };
+  const int gx = KB ? KB : nstrip, gy = KB ? nstrip * nseg : nseg, gz = KB ? g.nsub * nblk : g.nsub * nk;
+  if constexpr (MODE == PX_BOTH) {
+#ifndef FV3_HOST_EMU
+    launch_wave_groups3<PX_WPE, 2>(c, s, gx, gy, gz, 2 * smem + sizeof(Real) * 3 * NXCH * FV3_WAVE, [=] FV3_HD(const Blk &blk, char *smem_, int wave) {
+      Real *xch = (Real *)(smem_ + 2 * smem);
+      if (wave == 0)
+        body(std::integral_constant<int, PX_AIR>{}, std::true_type{}, blk, smem_, xch);
+      else
+        body(std::integral_constant<int, PX_TRC>{}, std::true_type{}, blk, smem_ + smem, xch);
+    });
+#endif
+  } else {
+    launch_waves<PX_WPE>(c, s, gx, gy, gz, smem, [=] FV3_HD(const Blk &blk, char *smem_) { body(std::integral_constant<int, MODE>{}, std::false_type{}, blk, smem_, (Real *)nullptr); });
+  }
 }
 
 }  // namespace
 
+// role 1 = delp + w, 2 = q_con + pt, 3 = both as coupled wave pairs (device only; the host emulation runs the two roles one after the other: a hand-over
+// between concurrently running waves has no emulation)
 void dsw_pair_march(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int role, int k_lo, int k_hi) {
-  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] round-5 pair march, role %d, levels %d..%d\n", role, k_lo, k_hi);
+  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] pair march, role %d, levels %d..%d\n", role, k_lo, k_hi);
   if (role == PX_AIR)
     pair_march_t<PX_AIR>(c, s, a, k_lo, k_hi);
-  else
+  else if (role == PX_TRC)
     pair_march_t<PX_TRC>(c, s, a, k_lo, k_hi);
+  else {
+#ifdef FV3_HOST_EMU
+    pair_march_t<PX_AIR>(c, s, a, k_lo, k_hi);
+    pair_march_t<PX_TRC>(c, s, a, k_lo, k_hi);
+#else
+    pair_march_t<PX_BOTH>(c, s, a, k_lo, k_hi);
+#endif
+  }
 }

@@ -34,6 +34,9 @@ namespace {
 #define WS_WPE 2
 #endif
 #define WS_NMAX 3
+#ifndef WS_PF3
+#define WS_PF3 2  // steps the 3-D rows are requested ahead (1: with the metric rows -- ten registers less, for the three-waves-per-SIMD experiment)
+#endif
 
 // HC: 0 = the PPM order of xtp_u / ytp_v is a run-time value; 6 = the constant 6 (the reference configurations): the limiter test folds to one comparison
 template <int HC>
@@ -216,7 +219,10 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
       const bool prow = GEN && patch_cols && jf >= 1 && ((jf <= P && (c_ll || c_hl)) || (jf >= ny + 2 - P && jf <= ny + 1 && (c_hh || c_lh)));
       // ---- phase 1a (own lane): the requests; what the neighbouring lanes will read of this step's rows
       FV3_LANES(blk_, lane, l) {
-        R[Q2][l] = load3(r + 2, l, gen_tag);
+        if (WS_PF3 == 2)
+          R[Q2][l] = load3(r + 2, l, gen_tag);
+        else
+          R[Q1][l] = load3(r + 1, l, gen_tag);
         M[Q1][l] = loadm(r + 1, l, gen_tag);
         const Row3 cu = R[Q][l];
         const RowM cm = M[Q][l];

@@ -426,12 +426,15 @@ def test_pair_march_is_bitwise_the_round4_march(backend, monkeypatch, n, layout,
     if seg != "0":
         monkeypatch.setenv("FV3_SEG", seg)
     res = {}
-    for mode in ("new", "old"):
+    # "coupled" (round 6, measured and not the default): the two roles as wave pairs of one workgroup per tile on the device, the air-mass fluxes / the old air
+    # mass / the rows both roles read handed over through LDS (the host emulation runs the two roles one after the other)
+    for mode in ("new", "coupled", "old"):
         monkeypatch.setenv("FV3_DSW_MARCH", mode)
         res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0)
     for r in range(part.total_ranks):
         for name in STATE:
             assert np.array_equal(res["new"][r][name], res["old"][r][name]), f"{name} rank {r}"
+            assert np.array_equal(res["coupled"][r][name], res["old"][r][name]), f"{name} rank {r} (coupled wave pairs)"
 
 
 @pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "0"), (24, (2, 2), "0"), (200, (1, 1), "96"), (200, (1, 1), "32"), (250, (2, 2), "0")])
