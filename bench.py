@@ -153,6 +153,10 @@ def main():
                     "the other GPUs.  A separately named workload, never the headline value")
     ap.add_argument("--remap", action="store_true", help="also run the Lagrangian-to-Eulerian vertical remap after every acoustic call (+ tracer advection): "
                     "with --tracers the body of DynamicalCore.step_dynamics; a separate, clearly named workload")
+    ap.add_argument("--graph", action="store_true", help="capture one model step into a HIP graph after the warm-up and REPLAY it in the timed region (one process only: "
+                    "device-local or looped-back halo transport -- nothing in a step touches the host there; the RCCL launch path of an N-GPU run stays exactly as "
+                    "tested).  Same kernels, same values; what it removes is the launch path (~110 launches per sub-step), which matters for the small per-GPU shares. "
+                    "Implies --no-op-timing (event pairs are not part of a replay); the line says graph_replay: true")
     a = ap.parse_args()
 
     from pace_amd.harness import CONFIGS, DycoreHarness
@@ -203,6 +207,14 @@ def main():
     if (6 * kw["layout"][0] * kw["layout"][1]) % world:
         sys.exit(f"{a.config} has {6 * kw['layout'][0] * kw['layout'][1]} sub-domains: not divisible over {world} GPUs")
     dtype = torch.float64 if a.precision == 64 else torch.float32
+    graph_stream = None
+    if a.graph:
+        if world != 1:
+            sys.exit("--graph: one process only (device-local / looped-back halo transport); the N-GPU launch path is not replayed from a graph")
+        a.no_op_timing = True
+        a.warmup = max(a.warmup, 2)  # (the sequencer's lazy allocations happen in the first two steps; a capture must not allocate)
+        graph_stream = torch.cuda.Stream()  # (a capture needs a side stream; everything from the harness on runs on it)
+        torch.cuda.set_stream(graph_stream)
     share = a.emulate_share if (a.emulate_share and world == 1) else 0
     if share and (6 * kw["layout"][0] * kw["layout"][1]) % share:
         sys.exit(f"--emulate-share {share}: {6 * kw['layout'][0] * kw['layout'][1]} sub-domains do not divide")
@@ -241,9 +253,19 @@ def main():
     barrier()
     if not a.no_op_timing:
         h.sf.profile(reset=True)
+    graph = None
+    if a.graph:
+        graph = torch.cuda.CUDAGraph()
+        graph.capture_begin()
+        h.step()
+        graph.capture_end()
+        barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        h.step()
+        if graph is not None:
+            graph.replay()
+        else:
+            h.step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -311,6 +333,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "sub_domains_per_gpu": len(h.grids),
             "pingpong_scalars": os.environ.get("FV3_PINGPONG", "1") != "0",
+            "graph_replay": bool(a.graph),
         }
         if a.tracers or a.remap:
             line["metric"] = ("simulated-days/day of the step_dynamics body (acoustic dynamics"

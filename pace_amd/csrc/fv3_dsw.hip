@@ -795,19 +795,16 @@ static void divdamp_stream(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *
 // The chain's cube-corner patches: the DD_PATCH^2 corners next to every cube corner of the context's sub-domains, recomputed by the staged form on a private
 // copy (tmp) of a window around them and written into `out` (all corners in one chained launch when their windows are disjoint).  uc / vc: the work arrays
 // of the iteration (the reference uses the dead C-grid winds; the fused wind stage, whose march still reads them, hands in scratch).
-static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
-  const Geo g = c->g;
+// the windows (patch + margin) around the cube corners of the context's sub-domains, the patches themselves, and the corner each belongs to
+static void dd_windows(const Geo &g, int k0, int k1, Wins &wins, Wins &patches, int needs[4]) {
   int any = 0;
   for (int t = 0; t < g.nsub; ++t) any |= g.flags[t];
-  const int *nk_ = g.nord;
   const int P = DD_PATCH, M = 4;
   struct Corner {
     int need;
     bool west, south;
   };
   const Corner corners[4] = {{FV3_W | FV3_S, true, true}, {FV3_E | FV3_S, false, true}, {FV3_E | FV3_N, false, false}, {FV3_W | FV3_N, true, false}};
-  Wins wins, patches;
-  int needs[4];
   wins.n = patches.n = 0;
   for (const Corner &cn : corners) {
     if ((any & cn.need) != cn.need) continue;
@@ -817,6 +814,31 @@ static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real 
     wins.w[wins.n++] = w;
     patches.w[patches.n++] = pb;
   }
+}
+// (a, b) -> (a2, b2) on the chain's windows: the fused wind stage runs the patch chain on scratch copies of the C-grid winds (its march still reads them) and puts
+// the chain's work values back afterwards -- the reference's iteration leaves them in uc / vc (FVDynamics-Out carries uc / vc), and so does the staged form
+static void dd_copy_windows(fv3_ctx *c, fv3_stream_t s, const Real *a, const Real *b, Real *a2, Real *b2, int k0, int k1) {
+  const Geo g = c->g;
+  Wins wins, patches;
+  int needs[4];
+  dd_windows(g, k0, k1, wins, patches, needs);
+  for (int w = 0; w < wins.n; ++w) {
+    Wins one;
+    one.n = 1;
+    one.w[0] = wins.w[w];
+    launch3w(c, s, Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, one, [=] FV3_HD(int t, int k, int i, int j) {
+      const long p = t * g.st + k * g.sk + IX(i, j);
+      a2[p] = a[p];
+      b2[p] = b[p];
+    });
+  }
+}
+static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {
+  const Geo g = c->g;
+  const int *nk_ = g.nord;
+  Wins wins, patches;
+  int needs[4];
+  dd_windows(g, k0, k1, wins, patches, needs);
   if (wins.n == 0) return;
   auto run = [&](const Wins &ws, const Wins &ps, const int *nd) {
     // private copy of the windows (the staged form works in place), the iteration and the copy of the patches into
@@ -1295,7 +1317,9 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     //      the three outermost corner rows / columns next to a cube-tile edge: kinetic energy (ke_point), then corner vorticity (a2b_point on the wk the march has
     //      stored) and the damping, with the iterated divergence the march exported there.
     if (kfz <= nz1) {
-      divdamp_patches(c, s, divgd, dnew, c->scratch[SC_TP_FY2], c->scratch[SC_TP_FX2], c->scratch[SC_M], nord_max, kfz, nz1);
+      Real *const wuc = c->scratch[SC_TP_FY2], *const wvc = c->scratch[SC_TP_FX2];
+      dd_copy_windows(c, s, uc, vc, wuc, wvc, kfz, nz1);
+      divdamp_patches(c, s, divgd, dnew, wuc, wvc, c->scratch[SC_M], nord_max, kfz, nz1);
       const WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
       wind_stage_march(c, s, ws);
       // (two launches: with ke_value and a2b_point in one closure the geometry block went to scratch memory -- 1600 B per lane, 7 ms for these 3 % of the corners)
@@ -1334,6 +1358,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         (vdamp + b)[p] = vd;
         (ke + b)[p] += vd;
       });
+      dd_copy_windows(c, s, wuc, wvc, uc, vc, kfz, nz1);  // (the chain's work values, where the staged form leaves them)
       // (the operator's own contract leaves the iterated divergence in divgd; inside the sequencer nobody reads it)
       if (keep_divgd) launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kfz, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
         const long pp = t * g.st + k * g.sk + IX(i, j);

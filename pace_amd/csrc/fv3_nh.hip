@@ -1139,9 +1139,11 @@ static void edge_profile_wave(fv3_ctx *c, fv3_stream_t s, const Real *crx, const
                               Real *yfx_a) {
   // one launch per field: the field pointers stay kernel arguments (selecting among them inside the kernel
   // turns every access into a flat load through a scratch copy of the argument block)
-  // Round 5 (review item 2): FV3_EP_ONE_LAUNCH=1 runs the four solves as ONE launch -- the field of a wave is a wave-uniform ELEMENT OFFSET from
-  // the first field's pointer (four integers among the kernel arguments), so every access stays a global load off one base.  Experiment R5-22.
-  static const bool one = getenv("FV3_EP_ONE_LAUNCH") && getenv("FV3_EP_ONE_LAUNCH")[0] == '1';
+  // Round 5 (review item 2): the four solves as ONE launch -- the field of a wave is a wave-uniform ELEMENT OFFSET from the first field's pointer (four
+  // integers among the kernel arguments), so every access stays a global load off one base.  Experiment R5-22 (update_dz_d -0.18 ms, but d_sw +0.5 ms in the
+  // same processes: left off); re-measured in round 6 on the fused wind stage (R6-8: update_dz_d -0.11 / -0.20 ms, d_sw -0.0 / -0.4): the default now.
+  // FV3_EP_ONE_LAUNCH=0: four launches (A/B; bitwise equal).
+  static const bool one = !(getenv("FV3_EP_ONE_LAUNCH") && getenv("FV3_EP_ONE_LAUNCH")[0] == '0');
   if (one) {
     const EpSet set{{0, (long)(xfx - crx), (long)(cry - crx), (long)(yfx - crx)}, {0, (long)(xfx_a - crx_a), (long)(cry_a - crx_a), (long)(yfx_a - crx_a)}, 4};
     edge_profile_wave1<NZ>(c, s, crx, crx_a, true, set);

@@ -53,6 +53,12 @@ BUDGETS = [
     # round-5 marches (fv3_tp4x.hip / fv3_tp2x.hip): two waves per SIMD, nothing spilled in the product forms
     (("pair_march_tILi1E",), 1, 256, 8, 40),     # delp + w (a few spills in the general steps are tolerated: they run 9 of 102 rows)
     (("pair_march_tILi2E",), 1, 256, 8, 40),     # q_con + pt
+    # round 6: d_sw's wind stage as one march (fv3_wind.hip): no LDS, nothing spilled, room to spare at two waves per SIMD
+    (("wind_stage_march_tILi6E",), 1, 192, 0, 0),   # PPM order 6 as a constant (the product form)
+    (("wind_stage_march_tILi0E",), 1, 192, 0, 0),   # run-time order
+    # ... the two roles of the pair march as coupled wave pairs (FV3_DSW_MARCH=coupled: measured, NOT the default -- DESIGN §7; the merged kernel spills in the
+    #     second role's loop, which is one of the three reasons it lost): pinned so that a change shows
+    (("pair_march_tILi3E", "fv3_kwg3ILi2ELi2E"), 1, 256, 160, 320),
     (("single_march_tILi1ELb0E",), 1, 224, 0, 0),   # vorticity transport + winds
     (("single_march_tILi1ELb1E",), 1, 256, 0, 128), # ... with the damping-heat epilogue
     (("single_march_tILi2ELb0E",), 1, 208, 0, 0),   # interface heights

@@ -98,6 +98,9 @@ def main():
     res, snaps, areas = {}, {}, {}
     for nx in a.nx:
         res[nx], snaps[nx], areas[nx] = run(nx, a.days, a.device, nz=a.nz)
+        if a.out:  # (partial results survive a time limit on the finest run)
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+            json.dump({"runs": [res[n_] for n_ in res]}, open(a.out + ".partial", "w"), indent=1)
     out = {"case": "JW2006 baroclinic wave, perturbed, dry, acoustic dynamics + tracer advection + vertical remap of this build (no physics)", "runs": [res[nx] for nx in a.nx]}
     # self-convergence: the coarser run against the finer one averaged onto the coarser cells (area-weighted cell means)
     conv = []

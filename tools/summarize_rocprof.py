@@ -22,6 +22,12 @@ def is_fv3(name):
     return bool(re.search(r"fv3_k|fv3_gather_kernel|fv3_kchain", name))
 
 
+# Launches the sequencer puts on its AUXILIARY stream beside the big marches of the main stream (the sponge-level transports and their del-n chains, the
+# cube-corner patch chains): their durations in a kernel trace are elapsed times while SHARING the chip -- a round-4 sponge-level march at one wave per SIMD
+# shows 6 - 7 ms beside the marches and 0.13 ms alone (serialized PMC pass) --, so they are not additive with the rows around them.
+CONCURRENT = re.compile(r"^(dsw_scalars_t<|tp2d_stream_t<|del6_stream|void fv3_kchain<|fv3_c_sw#[1356])")
+
+
 def main(path, top=45):
     allrows = list(csv.DictReader(open(path)))
     rows = [r for r in allrows if is_fv3(r["Name"])]
@@ -31,8 +37,15 @@ def main(path, top=45):
           f"(set-up kernels of PyTorch -- grid generation, synthetic state; outside the timed region -- excluded: {other / 1e6:.1f} ms)\n")
     print("| kernel (operator#launch) | calls | avg ms | total ms | % |")
     print("|---|---:|---:|---:|---:|")
+    conc = 0.0
     for r in rows[:top]:
-        print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {float(r['TotalDurationNs']) / 1e6:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
+        nm = short(r["Name"])
+        mark = " †" if CONCURRENT.search(nm) else ""
+        if mark:
+            conc += float(r["TotalDurationNs"])
+        print(f"| {nm}{mark} | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | {float(r['TotalDurationNs']) / 1e6:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
+    print(f"\n† launched on the auxiliary stream BESIDE kernels of the main stream: elapsed time while sharing the chip, not additive with the other rows "
+          f"({conc / 1e6:.1f} ms of the {tot / 1e6:.1f} ms above; per-operator sums that add up are the HIP-event timings of the bench line and the serialized PMC pass)")
     agg = {}
     for r in rows:
         op = short(r["Name"]).split("#")[0]
