@@ -817,7 +817,9 @@ static void dd_windows(const Geo &g, int k0, int k1, Wins &wins, Wins &patches, 
 }
 // (a, b) -> (a2, b2) on the chain's windows: the fused wind stage runs the patch chain on scratch copies of the C-grid winds (its march still reads them) and puts
 // the chain's work values back afterwards -- the reference's iteration leaves them in uc / vc (FVDynamics-Out carries uc / vc), and so does the staged form
-static void dd_copy_windows(fv3_ctx *c, fv3_stream_t s, const Real *a, const Real *b, Real *a2, Real *b2, int k0, int k1) {
+// grow: the copy covers that many cells beyond each window (the chain reads its work arrays one cell outside its window -- stale values that only reach the
+// discarded margin of its result, but do reach the work values it leaves: the scratch copies must hold what uc / vc hold there)
+static void dd_copy_windows(fv3_ctx *c, fv3_stream_t s, const Real *a, const Real *b, Real *a2, Real *b2, int k0, int k1, int grow) {
   const Geo g = c->g;
   Wins wins, patches;
   int needs[4];
@@ -826,6 +828,10 @@ static void dd_copy_windows(fv3_ctx *c, fv3_stream_t s, const Real *a, const Rea
     Wins one;
     one.n = 1;
     one.w[0] = wins.w[w];
+    one.w[0].i0 -= grow;
+    one.w[0].i1 += grow;
+    one.w[0].j0 -= grow;
+    one.w[0].j1 += grow;
     launch3w(c, s, Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, one, [=] FV3_HD(int t, int k, int i, int j) {
       const long p = t * g.st + k * g.sk + IX(i, j);
       a2[p] = a[p];
@@ -1318,7 +1324,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     //      stored) and the damping, with the iterated divergence the march exported there.
     if (kfz <= nz1) {
       Real *const wuc = c->scratch[SC_TP_FY2], *const wvc = c->scratch[SC_TP_FX2];
-      dd_copy_windows(c, s, uc, vc, wuc, wvc, kfz, nz1);
+      dd_copy_windows(c, s, uc, vc, wuc, wvc, kfz, nz1, 2);
       divdamp_patches(c, s, divgd, dnew, wuc, wvc, c->scratch[SC_M], nord_max, kfz, nz1);
       const WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
       wind_stage_march(c, s, ws);
@@ -1358,7 +1364,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         (vdamp + b)[p] = vd;
         (ke + b)[p] += vd;
       });
-      dd_copy_windows(c, s, wuc, wvc, uc, vc, kfz, nz1);  // (the chain's work values, where the staged form leaves them)
+      dd_copy_windows(c, s, wuc, wvc, uc, vc, kfz, nz1, 0);  // (the chain's work values, where the staged form leaves them)
       // (the operator's own contract leaves the iterated divergence in divgd; inside the sequencer nobody reads it)
       if (keep_divgd) launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kfz, nz1}, [=] FV3_HD(int t, int k, int i, int j) {
         const long pp = t * g.st + k * g.sk + IX(i, j);
