@@ -266,6 +266,11 @@ struct fv3_ctx {
   // nothing yet, so d_sw forms 0 + flux with the zero read from `zeros` (one level plane of zeros, 1.2 MB at C768: it stays in L2) instead of the field, and the sequencer
   // zeroes only the cells d_sw never writes (zero_unwritten, fv3_step.hip: every call, no cached state; FV3_ACC_STORE=0: zero + accumulate on every sub-step, as the reference does -- same values).
   bool seq_acc_first = false;
+  // set by fv3_acoustic_step around c_sw: the operator may leave its last boundary-window launches (stages D and E: they write window cells of delpc / ptc / wc /
+  // ke / vort / uc / vc, which update_dz_c does not touch) RUNNING on the auxiliary stream when it returns; csw_pending then says that the join (event 7) is still
+  // owed -- the sequencer pays it before riem_solver_c, the first reader (fv3_csw_join).  The stand-alone operator always joins before it returns.
+  bool seq_csw_defer = false;
+  bool csw_pending = false;
   bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step
   Real *zeros = nullptr;
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};

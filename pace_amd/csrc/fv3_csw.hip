@@ -1146,9 +1146,18 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
     }
   };
+  // Round 6: inside the sequencer the eight window launches of stages D and E (1.15 ms of small launches behind the march) go to the auxiliary stream and the
+  // operator returns without waiting for them: update_dz_c, which follows, reads ut / vt / zh only, and riem_solver_c -- the first reader of the windows' delpc /
+  // ptc / wc -- is where the sequencer joins (fv3_csw_join).  FV3_CSW_DEFER=0: in program order (A/B; same values).  Events 6 = fork, 7 = join.
+  static const bool defer_on = !(getenv("FV3_CSW_DEFER") && getenv("FV3_CSW_DEFER")[0] == '0');
+  fv3_stream_t sd_ = (fused && defer_on && c->seq_csw_defer) ? fv3_aux(c, s) : s;
+  if (sd_ != s) {
+    fv3_signal(c, s, 6);
+    fv3_wait(c, sd_, 6);
+  }
   if (fused) {  // the four windows along the sub-domain boundary
     const int e0 = g.nx - 4;
-    launch_frame(c, s, Frame{{Box{0, 6, 0, g.ny + 1, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 0, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_d);
+    launch_frame(c, sd_, Frame{{Box{0, 6, 0, g.ny + 1, 0, nkc - 1}, Box{e0, e0 + 5, 0, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 0, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_d);
   } else {
     launch3(c, s, Box{0, g.nx + 1, 0, g.ny + 1, 0, nkc - 1}, stage_d);
   }
@@ -1190,10 +1199,23 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     const int nke = (nz1 + KC) / KC - 1;
     if (fused) {
       const int e0 = g.nx - 4;
-      launch_frame(c, s, Frame{{Box{1, 6, 1, g.ny + 1, 0, nke}, Box{e0, e0 + 5, 1, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 1, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_e);
+      launch_frame(c, sd_, Frame{{Box{1, 6, 1, g.ny + 1, 0, nke}, Box{e0, e0 + 5, 1, g.ny + 1, 0, 0}, Box{7, g.nx - 5, 1, 6, 0, 0}, Box{7, g.nx - 5, g.ny - 4, g.ny + 1, 0, 0}}}, stage_e);
     } else {
       launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, nke}, stage_e);
     }
   }
+  if (sd_ != s) {
+    fv3_signal(c, sd_, 7);
+    c->csw_pending = true;  // (the sequencer joins: fv3_csw_join)
+  }
   return fv3_post(c, s, "c_sw");
+}
+
+// the join c_sw left to the sequencer (seq_csw_defer): the caller's stream waits for the stage D / E windows on the auxiliary stream
+int fv3_csw_join(fv3_ctx *c, void *stream) {
+  if (c && c->csw_pending) {
+    fv3_wait(c, (fv3_stream_t)stream, 7);
+    c->csw_pending = false;
+  }
+  return FV3_OK;
 }

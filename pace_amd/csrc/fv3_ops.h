@@ -190,6 +190,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc, const fv3_field *delp, cons
                  const fv3_field *yfx, const fv3_field *q_con, const fv3_field *zh, const fv3_field *heat_source, const fv3_field *diss_est, double dt,
                  void *stream, const fv3_field *o_delp, const fv3_field *o_pt, const fv3_field *o_w, const fv3_field *o_q_con, int (*after_scalars)(void *) = nullptr,
                  void *after_user = nullptr);  // after_scalars: called once the four new scalars are final (the winds still to come)
+int fv3_csw_join(fv3_ctx *c, void *stream);  // (fv3_csw.hip) the join of c_sw's deferred stage D / E windows (fv3_ctx::seq_csw_defer)
 // nh_p_grad as one marching kernel (fv3_pgf.hip); pass = the sequencer's frame-first pass (0 all, 1 sub-domain frames, 2 the rest)
 void nh_pgf_fused(fv3_ctx *c, fv3_stream_t s, const Real *pp, const Real *pk3, const Real *gz, const Real *delp, Real *u, Real *v, Real dt, Real top, Real gz_scale,
                   int pass);

@@ -278,6 +278,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_divgd_dead = false;
       c->seq_acc_first = false;
       c->seq_heat_first = false;
+      c->seq_csw_defer = false;
     }
   } pp_guard{c};
 
@@ -330,8 +331,12 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     }
     HALO(FV3_HALO_U__V, 1);
     HALO(FV3_HALO_W, 1);
+    // (its last window launches may still run on the auxiliary stream beside update_dz_c: joined before riem_solver_c.  Only beside the one-kernel zh -> gz form of
+    //  update_dz_c: the in-place form of the reference's first sub-step order works in the scratch field c_sw keeps its kinetic energy in)
+    c->seq_csw_defer = (gz_direct || it > 0) && c->g.nz >= 3;
     RUN(FV3_OP_C_SW, fv3_c_sw(c, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
                               &ws->delpc, &ws->ptc, dt2, stream));
+    c->seq_csw_defer = false;
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 0);
     if (it == 0 && gz_direct) {
       HALO(FV3_HALO_ZH, 1);
@@ -344,6 +349,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       // (the reference copies zh into gz first; update_dz_c reads zh directly instead)
       RUN(FV3_OP_UPDATE_DZ_C, fv3_update_dz_c_from(c, &ws->zs, &ws->ut, &ws->vt, &ws->zh, &ws->gz, &ws->ws3, dt2, stream));
     }
+    RUN(FV3_OP_GLUE, fv3_csw_join(c, stream));  // (what is left of c_sw's deferred windows when update_dz_c is done: timed as glue)
     RUN(FV3_OP_RIEM_SOLVER_C,
         fv3_riem_solver_c(c, dt2, &st->cappa, ptop, &st->phis, &ws->ws3, &ws->ptc, &f_qc[cur], &ws->delpc, &ws->gz, &ws->pkc, &st->omga, stream));
     if (frame_first) {
