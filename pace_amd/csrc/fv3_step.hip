@@ -270,9 +270,11 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   if (const char *e = getenv("FV3_FRAME_FIRST")) frame_first = !halo && e[0] == '1';
   bool w_started = false;
   c->frame_pass = 0;
-  struct PpGuard {  // (no early return leaves the halo translation switched on)
+  struct PpGuard {  // (no early return leaves the halo translation switched on, or c_sw's deferred windows unjoined)
     fv3_ctx *c;
+    void *stream;
     ~PpGuard() {
+      (void)fv3_csw_join(c, stream);
       c->pp_n = 0;
       c->frame_pass = 0;
       c->seq_divgd_dead = false;
@@ -280,7 +282,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_heat_first = false;
       c->seq_csw_defer = false;
     }
-  } pp_guard{c};
+  } pp_guard{c, stream};
 
   if (pingpong) {
     // cells no operator and no halo update ever writes (the 3 x 3 blocks beyond a cube corner, the allocation padding) keep the
