@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round-5 study of c_sw's run-to-run drift on one box: N consecutive bench processes, rocm-smi sampled twice a second beside
-# each (shader / memory clock, power, edge / junction / HBM temperature), per-operator times of every run -> gpurun_out/r05_variance/summary.md
+# each (shader / memory clock, power, edge / junction / HBM temperature), per-operator times of every run -> gpurun_out/${FV3_VARIANCE_TAG:-r06_variance}/summary.md
 set -u
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/r05_variance
+out=$R/gpurun_out/${FV3_VARIANCE_TAG:-r06_variance}
 mkdir -p "$out"
 cd "$R"
 N=${1:-5}
