@@ -4,7 +4,7 @@
 set -u
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$R/gpurun_out/r05_configs
+out=$R/gpurun_out/${FV3_CONFIGS_TAG:-r06_configs}
 mkdir -p "$out"
 cd "$R"
 run() {
@@ -23,6 +23,6 @@ run fp32_l127 --precision 32 --nz 127
 run fp64_l127 --nz 127
 run c384 --config c384
 run c192 --config c192
-run share8 --emulate-share 8
+run share8 --emulate-share 8 --steps 3 --warmup 1
 run share4 --emulate-share 4
 run dynamics --tracers 4 --remap
