@@ -1,3 +1,4 @@
+# Per-operator times (HIP-event pairs of the bench line) of a few run-time variants, one line each: the whole problem, the one-launch edge_profile switch, the emulated 1/8 share and its segment lengths.
 cd ${GRAFT_REPO_ROOT:-.}
 run() { name=$1; shift; env "$@" > gpurun_out/ops_$name.log 2>&1; grep '^{' gpurun_out/ops_$name.log | tail -1 | python3 -c "
 import sys, json

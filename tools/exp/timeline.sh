@@ -1,3 +1,4 @@
+# Kernel timeline (rocprofv3 --kernel-trace -> tools/share_timeline.py) of the emulated 1/8 share and of the whole problem: launches per sub-step, idle time between kernels, short launches.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/r06_timeline
