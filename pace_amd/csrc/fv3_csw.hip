@@ -1146,10 +1146,11 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
     }
     }
   };
-  // Round 6: inside the sequencer the eight window launches of stages D and E (1.15 ms of small launches behind the march) go to the auxiliary stream and the
-  // operator returns without waiting for them: update_dz_c, which follows, reads ut / vt / zh only, and riem_solver_c -- the first reader of the windows' delpc /
-  // ptc / wc -- is where the sequencer joins (fv3_csw_join).  FV3_CSW_DEFER=0: in program order (A/B; same values).  Events 6 = fork, 7 = join.
-  static const bool defer_on = !(getenv("FV3_CSW_DEFER") && getenv("FV3_CSW_DEFER")[0] == '0');
+  // Round 6, FV3_CSW_DEFER=1 (measured, NOT the default: R6-11): inside the sequencer the eight window launches of stages D and E (1.15 ms of small launches behind
+  // the march) go to the auxiliary stream and the operator returns without waiting for them: update_dz_c, which follows, reads ut / vt / zh only, and
+  // riem_solver_c -- the first reader of the windows' delpc / ptc / wc -- is where the sequencer joins (fv3_csw_join).  Same values; c_sw shrinks by 1.1 ms and
+  // update_dz_c, bandwidth-bound beside the windows, grows by 0.85: four same-box pairs gave -0.7 / -0.0 / +0.6 / +0.1 ms per sub-step.  Events 6 = fork, 7 = join.
+  static const bool defer_on = getenv("FV3_CSW_DEFER") && getenv("FV3_CSW_DEFER")[0] == '1';
   fv3_stream_t sd_ = (fused && defer_on && c->seq_csw_defer) ? fv3_aux(c, s) : s;
   if (sd_ != s) {
     fv3_signal(c, s, 6);
