@@ -62,6 +62,16 @@ BUDGETS = [
     (("single_march_tILi1ELb0E",), 1, 224, 0, 0),   # vorticity transport + winds
     (("single_march_tILi1ELb1E",), 1, 256, 0, 128), # ... with the damping-heat epilogue
     (("single_march_tILi2ELb0E",), 1, 208, 0, 0),   # interface heights
+    # the rest of what the reference configurations launch per sub-step (round 6: every kernel of the default path has a row)
+    (("edge_profile_wave1ILi79E", "fv3_kwILi2E"), 1, 256, 0, 0),   # update_dz_d's interface interpolation, L79: the column in registers at two waves per SIMD
+    ((_q4(Q4_AIR, 2, False, False),), 1, 256, 0, 0, -1),           # sponge levels: the transposed tile-edge marches of round 4 (one wave per SIMD on the auxiliary
+    ((_q4(Q4_TRC, 2, False, False),), 1, 256, 0, 0, -1),           # stream: the compiler parks ~80 values in accumulation registers -- any number of them, no memory spill)
+    ((_tp(24),), 1, 256, 0, 0),                                    # sponge levels: interface heights (TF_EPI | TF_AREA) ...
+    ((_tp(32),), 1, 256, 0, 0),                                    # ... and the vorticity transport (TF_WIND) without the chain
+    (("del6_stream", "fv3_kwILi3E"), 1, 168, 0, 0),                # del-n fluxes of the sponge levels: three waves per SIMD
+    (("divdamp_stream", "fv3_kwILi4E"), 1, 128, 0, 0),             # damping chain of the levels under the fused wind stage: four waves per SIMD
+    (("a2b_ord4_tILi8E", "fv3_kwILi8E"), 2, 64, 0, 0),             # corner interpolation marches (plain store / d_sw's damping epilogue): eight waves per SIMD
+    (("fv3_update_dz_c_from", "fv3_k2I", "EUliiiE_E"), 1, 96, 0, 0),  # update_dz_c, one-kernel zh -> gz form: five waves per SIMD
     # the LDS-tile smoothing of the damping-heat tail (fv3_del2x.hip): three workgroups of four waves per CU need <= 170 registers
     (("d2_launchILb0ELb0E",), 1, 168, 0, 0),        # plain tiles, heating as its own launch (the product form)
     (("d2_launchILb1ELb0E",), 1, 256, 0, 0),        # tiles with a cube corner (six LDS offsets per cell; 4 workgroups per sub-domain and level block)
@@ -98,7 +108,7 @@ def test_kernel_stays_inside_its_register_budget(kernel_table, budget):
     assert len(hits) == n_expected, f"{keys} matches {len(hits)} kernels, expected {n_expected}: {[n[:90] for n in hits]}"
     for n, k in hits.items():
         arch = k["vgpr"] - k["agpr"]
-        assert arch <= vgpr and k["agpr"] == agpr and k["spill"] <= spill and k["scratch"] <= scratch, (
+        assert arch <= vgpr and (agpr < 0 or k["agpr"] == agpr) and k["spill"] <= spill and k["scratch"] <= scratch, (
             f"{n[:100]}: {k} (budget: {vgpr} architectural VGPRs, {agpr} accumulation registers, {spill} spilled, {scratch} B scratch)")
 
 
