@@ -487,7 +487,7 @@ inline void launch3(const fv3_ctx *c, fv3_stream_t s, Box b, F f) {
 // The frame of a sub-domain (the windows along its W / E / S / N boundary that the interior marching kernels leave to the
 // generic per-point stage kernels): f(t, k, i, j) on w[0], w[1] (W / E: a few columns wide: 8 x 32 workgroups, fv3_k3n) and on
 // w[2], w[3] (S / N: the usual 64 x 4 workgroups).  k runs over b.k0 .. b.k1 of
-// w[0] (the level chunks).  One launch per window; FV3_FRAME_MERGED: all four in one launch (slower, kept for A/B).
+// w[0] (the level chunks).  ONE launch for the four windows (round 6); FV3_FRAME_LAUNCH=split: one launch per window (rounds 3 - 5, A/B).
 // ---------------------------------------------------------------------------------------------
 struct Frame {
   Box w[4];
@@ -504,17 +504,52 @@ __global__ void __launch_bounds__(256) fv3_k3n(Box b, int nkc, GridMap m, F f) {
   const int i = b.i0 + (int)(bx * 8 + (threadIdx.x & 7)), j = b.j0 + (int)(by * 32 + (threadIdx.x >> 3));
   if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
 }
-template <class F>
-__global__ void __launch_bounds__(256) fv3_kfr(Frame fr, int nkc, GridMap m, F f) {
+// the four windows in ONE launch (round 6): the workgroups of a plane are the 8 x 32 tiles of W, those of E, then the 64 x 4 tiles of S and of N -- each window
+// in the thread layout its separate launch has.  (The merged launch of round 3 -- every window as 64 x 4 with the W / E lanes along j -- was slower than four.)
+struct FrameMap {
+  Box w[4];
+  int first[4];  // first workgroup of the window within a plane
+  int gx[4];     // the window's workgroups along i
+};
+inline int fv3_frame_map(const Frame &fr, FrameMap *fm) {
+  int n = 0;
+  for (int w = 0; w < 4; ++w) {
+    Box b = fr.w[w];
+    b.k0 = fr.w[0].k0;
+    b.k1 = fr.w[0].k1;
+    const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1;
+    const int tx = ni <= 0 || nj <= 0 ? 0 : w < 2 ? (ni + 7) / 8 : (ni + 63) / 64, ty = ni <= 0 || nj <= 0 ? 0 : w < 2 ? (nj + 31) / 32 : (nj + 3) / 4;
+    fm->w[w] = b;
+    fm->first[w] = n;
+    fm->gx[w] = tx > 0 ? tx : 1;
+    n += tx * ty;
+  }
+  return n;
+}
+template <bool WIDX, class F>
+__global__ void __launch_bounds__(256) fv3_kfr(FrameMap fm, int nkc, GridMap m, F f) {
   int bx, by, kz;
   if (!fv3_tile(m, bx, by, kz)) return;
-  const int wi = kz & 3, tk = kz >> 2;
-  const int t = tk / nkc;
-  const int k = fr.w[0].k0 + (tk - t * nkc);
-  const Box b = fr.w[wi];
-  const int a = (int)(bx * 64 + threadIdx.x), bb = (int)(by * 4 + threadIdx.y);
-  const int i = wi < 2 ? b.i0 + bb : b.i0 + a, j = wi < 2 ? b.j0 + a : b.j0 + bb;
-  if (i <= b.i1 && j <= b.j1) f(t, k, i, j);
+  const int t = kz / nkc;
+  const int k = fm.w[0].k0 + (kz - t * nkc);
+  const int wi = bx >= fm.first[2] ? (bx >= fm.first[3] ? 3 : 2) : (bx >= fm.first[1] ? 1 : 0);
+  const int lt = bx - fm.first[wi];
+  const int ty = lt / fm.gx[wi], tx = lt - ty * fm.gx[wi];
+  const Box b = fm.w[wi];
+  const int tid = (int)threadIdx.x;
+  const int i = wi < 2 ? b.i0 + tx * 8 + (tid & 7) : b.i0 + tx * 64 + (tid & 63);
+  const int j = wi < 2 ? b.j0 + ty * 32 + (tid >> 3) : b.j0 + ty * 4 + (tid >> 6);
+  if (i <= b.i1 && j <= b.j1) {
+    if constexpr (WIDX)
+      f(wi, t, k, i, j);
+    else
+      f(t, k, i, j);
+  }
+}
+// FV3_FRAME_LAUNCH=split: one launch per window (A/B; read once)
+inline bool fv3_frame_split() {
+  static const bool v = getenv("FV3_FRAME_LAUNCH") && !strcmp(getenv("FV3_FRAME_LAUNCH"), "split");
+  return v;
 }
 #endif
 template <class F>
@@ -527,39 +562,29 @@ inline void launch_frame(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f)
     launch3(c, s, b, f);
   }
 #else
-#ifndef FV3_FRAME_MERGED  // default: one right-sized launch per window (measured at C768: c_sw 13.1 ms against 15.1 ms for the merged launch)
+  if (!fv3_frame_split()) {
+    FrameMap fm;
+    const int nt = fv3_frame_map(fr, &fm), nkc = fr.w[0].k1 - fr.w[0].k0 + 1;
+    if (nt <= 0 || nkc <= 0) return;
+    dim3 grid;
+    const GridMap m = fv3_grid(nt, 1, c->g.nsub * nkc, &grid);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kfr<false, F>), grid, dim3(256, 1, 1), 0, s, fm, nkc, m, f);
+    return;
+  }
   for (int w = 0; w < 4; ++w) {
     Box b = fr.w[w];
     b.k0 = fr.w[0].k0;
     b.k1 = fr.w[0].k1;
     if (w < 2) {
-#ifdef FV3_FRAME_TRANSPOSED  // A/B form: lanes along j
-      launch3(c, s, Box{b.j0, b.j1, b.i0, b.i1, b.k0, b.k1}, [=] FV3_HD(int t, int k, int a, int bb) { f(t, k, bb, a); });
-#else
       const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1, nkc = b.k1 - b.k0 + 1;
       if (ni <= 0 || nj <= 0 || nkc <= 0) continue;
       dim3 grid;
       const GridMap m = fv3_grid((ni + 7) / 8, (nj + 31) / 32, c->g.nsub * nkc, &grid);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_k3n<F>), grid, dim3(256, 1, 1), 0, s, b, nkc, m, f);
-#endif
     } else {
       launch3(c, s, b, f);
     }
   }
-  return;
-#endif
-  int nl = 0, nw = 0;
-  for (int w = 0; w < 4; ++w) {
-    const Box &b = fr.w[w];
-    const int ni = b.i1 - b.i0 + 1, nj = b.j1 - b.j0 + 1;
-    nl = std::max(nl, w < 2 ? nj : ni);
-    nw = std::max(nw, w < 2 ? ni : nj);
-  }
-  const int nkc = fr.w[0].k1 - fr.w[0].k0 + 1;
-  if (nl <= 0 || nw <= 0 || nkc <= 0) return;
-  dim3 block(64, 4, 1), grid;
-  const GridMap m = fv3_grid((nl + 63) / 64, (nw + 3) / 4, 4 * c->g.nsub * nkc, &grid);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kfr<F>), grid, block, 0, s, fr, nkc, m, f);
 #endif
 }
 
@@ -567,6 +592,17 @@ inline void launch_frame(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f)
 // test the sub-domain's tile-edge flag of their side and leave the corner cells to the column windows.  KCH 1 (k = level).
 template <class F>
 inline void launch_frame_w(const fv3_ctx *c, fv3_stream_t s, const Frame &fr, F f) {
+#ifndef FV3_HOST_EMU
+  if (!fv3_frame_split()) {
+    FrameMap fm;
+    const int nt = fv3_frame_map(fr, &fm), nkc = fr.w[0].k1 - fr.w[0].k0 + 1;
+    if (nt <= 0 || nkc <= 0) return;
+    dim3 grid;
+    const GridMap m = fv3_grid(nt, 1, c->g.nsub * nkc, &grid);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(fv3_kfr<true, F>), grid, dim3(256, 1, 1), 0, s, fm, nkc, m, f);
+    return;
+  }
+#endif
   for (int w = 0; w < 4; ++w) {
     Box b = fr.w[w];
     b.k0 = fr.w[0].k0;

@@ -1081,6 +1081,11 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   Real *vdamp = c->scratch[SC_DN_D2];  // damping field "vort" on corners
   int fdw_k0 = g.nz;
   bool keep_uv_dx = false;
+  const char *he = getenv("FV3_DSW_HEAT");
+  bool heat_in_march = false;  // the vorticity march forms the damping heat (set with fdw_k0 below)
+  const fv3_stream_t s_main = s;
+  bool sponge_forked = false;  // the sponge levels' wind chain runs on the auxiliary stream (forked at the top of wind_branch, joined after the vorticity march)
+  int side_from = 1 << 30;  // first level whose damping-heat side copies the fused wind stage has stored (see WindStage::u_side)
   auto wind_branch = [&](fv3_stream_t s) {
   // ---- cell-mean relative vorticity (+ absolute vorticity)
   // Levels that form the damping heat (d_con > 1e-5) WITHOUT vorticity damping (damp_vt <= 1e-5) read the
@@ -1100,6 +1105,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         fdw_k0 = k;
       }
   }
+  heat_in_march = cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1);
   // Round 5, FV3_DSW_VORT_IN_KE=1 (experiment R5-30, off by default): the corner-KE march, which reads u and v anyway, forms the vorticity of the cells under
   // its corners -- columns 4 .. nx - 2, rows 3 .. ny - 3 at least -- and this launch only serves the four windows of the frame around them (sub-domains
   // without a tile edge on a side get those cells from both: the same values).  Same bits; measured neutral: the launch goes from 1.61 to 0.25 ms, the march
@@ -1121,6 +1127,22 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       }
   }
   const int ks1 = kfz - 1;  // last level of the staged kernels
+  // Round 6: with the fused stage on every other level, the staged kernels only serve the sponge layers (3 of 79 levels: launches of a few dozen waves, 0.05 -
+  // 0.3 ms each, ~0.8 ms in a row with the gaps between them).  Their whole chain -- vorticity, corner KE, divergence + damping, corner interpolation, the
+  // vorticity's del-n fluxes, the vorticity transport with the wind update -- touches no level the march works on, so it goes to the auxiliary stream and runs
+  // BESIDE the fused stage and the vorticity march (events 2 = fork here, 4 = the staged fields are there: levels from fdw_k0 on feed the vorticity march,
+  // 3 = join after the march).  FV3_DSW_SPONGE_WIND=serial: program order (A/B; per call).
+  fv3_stream_t ss = s;
+  {
+    const char *spe = getenv("FV3_DSW_SPONGE_WIND");
+    if (kfz <= nz1 && ks1 >= 0 && fdw_k0 <= kfz && s == s_main && !(spe && !strcmp(spe, "serial"))) ss = fv3_aux(c, s);
+    if (ss != s) {
+      fv3_signal(c, s, 2);
+      fv3_wait(c, ss, 2);
+      sponge_forked = true;
+    }
+    if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] sponge levels' wind chain: levels 0..%d (fdw_k0 %d) %s\n", ks1, fdw_k0, ss != s ? "on the auxiliary stream" : "in program order");
+  }
   if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] fused wind stage on levels %d..%d of %d\n", kfz, nz1, g.nz);
   // (two levels per thread: the six metric terms are read once)
   auto vort_cells = [=] FV3_HD(int t, int kp, int i, int j) {
@@ -1148,9 +1170,9 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     const int nkc = (ks1 + FV3_KC) / FV3_KC;
     if (nkc <= 0) {
     } else if (vort_in_ke)
-      launch_frame(c, s, Frame{{Box{isd, 3, jsd, jed, 0, nkc - 1}, Box{g.nx - 1, ied, jsd, jed, 0, 0}, Box{4, g.nx - 2, jsd, 2, 0, 0}, Box{4, g.nx - 2, g.ny - 2, jed, 0, 0}}}, vort_cells);
+      launch_frame(c, ss, Frame{{Box{isd, 3, jsd, jed, 0, nkc - 1}, Box{g.nx - 1, ied, jsd, jed, 0, 0}, Box{4, g.nx - 2, jsd, 2, 0, 0}, Box{4, g.nx - 2, g.ny - 2, jed, 0, 0}}}, vort_cells);
     else
-      launch3(c, s, Box{isd, ied, jsd, jed, 0, nkc - 1}, vort_cells);
+      launch3(c, ss, Box{isd, ied, jsd, jed, 0, nkc - 1}, vort_cells);
   }
   // ---- kinetic energy on corners (vb * ytp_v + ub * xtp_u)
   static const bool ke_staged = getenv("FV3_KE_STAGED") != nullptr;  // A/B switch for profiling
@@ -1218,12 +1240,12 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   auto ke_point = [=] FV3_HD(int t, int k, int i, int j) { (ke + t * g.st + k * g.sk)[IX(i, j)] = ke_value(t, k, i, j); };
   if (ks1 < 0) {
   } else if (ke_staged) {
-    launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, 0, ks1}, ke_point);
+    launch3(c, ss, Box{1, g.nx + 1, 1, g.ny + 1, 0, ks1}, ke_point);
   } else {
-    ke_stream(c, s, u, v, uc, vc, ke, dt, cf.hord_mt, 0, ks1, vort_in_ke ? wk : nullptr, vabs, fdw_k0);
+    ke_stream(c, ss, u, v, uc, vc, ke, dt, cf.hord_mt, 0, ks1, vort_in_ke ? wk : nullptr, vabs, fdw_k0);
     // frame: the 3 outermost corner rows / columns next to a cube-tile edge
     // (W / E: columns 1..3 / npx-2..npx as narrow windows, S / N: rows 1..3 / npy-2..npy; the corner cells belong to the column windows)
-    launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, 0, ks1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
+    launch_frame_w(c, ss, Frame{{Box{1, 3, 1, g.ny + 1, 0, ks1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
                    [=] FV3_HD(int w_, int t, int k, int i, int j) {
       const int fl = g.flags[t];
       if (!(fl & (w_ == 0 ? FV3_W : w_ == 1 ? FV3_E : w_ == 2 ? FV3_S : FV3_N))) return;
@@ -1250,7 +1272,8 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
         kd1 = std::max(kd1, k);
       }
   }
-  launch3(c, s, Box{1, g.nx + 1, 1, g.ny + 1, kd0, kd1}, [=] FV3_HD(int t, int k, int i, int j) {
+  // (ss: with the fused stage on, dd_sep holds and the levels kd0 .. kd1 -- those without the iteration -- are sponge levels)
+  launch3(c, ss, Box{1, g.nx + 1, 1, g.ny + 1, kd0, kd1}, [=] FV3_HD(int t, int k, int i, int j) {
     const int fl = g.flags[t];
     const long b = t * g.st + k * g.sk, m2 = t * g.st2;
     const bool W = fl & FV3_W, E = fl & FV3_E, S = fl & FV3_S, N = fl & FV3_N;
@@ -1291,7 +1314,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       divdamp_staged(c, s, divgd, uc, vc, nord_max, 0, nz1, nullptr);
     } else if (nord_max > 0) {
       dnew = c->scratch[SC_L];
-      if (ks1 >= 0) divdamp_stream(c, s, divgd, dnew, uc, vc, c->scratch[SC_M], nord_max, 0, ks1);
+      if (ks1 >= 0) divdamp_stream(c, ss, divgd, dnew, uc, vc, c->scratch[SC_M], nord_max, 0, ks1);
     }
   }
   // Smagorinsky-type coefficient from the corner-interpolated vorticity, levels with nord > 0
@@ -1304,7 +1327,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // next c_sw overwrites the workspace field -- the sequencer says so (seq_divgd_dead) and the copy of the iteration's result into divgd
     // (one field write per call) is skipped when the iteration wrote beside it.
     const bool keep_divgd = !(c->seq_divgd_dead && dd_sep);
-    if (ks1 >= 0) a2b_ord4_t<8>(c, s, wk, 0, 0, ks1 + 1, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
+    if (ks1 >= 0) a2b_ord4_t<8>(c, ss, wk, 0, 0, ks1 + 1, (Real)1, [=] FV3_HD(int t, int k, unsigned p, Real wkbv) {
       const int nord = g.nord[k];
       if (nord == 0) return;
       const long b = t * g.st + k * g.sk;
@@ -1318,6 +1341,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       (vdamp + b)[p] = vd;
       (ke + b)[p] += vd;
     });
+    if (ss != s) fv3_signal(c, ss, 4);  // (ke, the damping field and wk of the staged levels are final)
     // ---- the fused wind stage on the levels kfz .. nz1 (fv3_wind.hip).  Order: the damping chain's cube-corner patches first (the march reads their values
     //      where its own chain is wrong; their work arrays are scratch here -- the march still reads the C-grid winds), the march, then two per-point launches on
     //      the three outermost corner rows / columns next to a cube-tile edge: kinetic energy (ke_point), then corner vorticity (a2b_point on the wk the march has
@@ -1326,7 +1350,18 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       Real *const wuc = c->scratch[SC_TP_FY2], *const wvc = c->scratch[SC_TP_FX2];
       dd_copy_windows(c, s, uc, vc, wuc, wvc, kfz, nz1, 2);
       divdamp_patches(c, s, divgd, dnew, wuc, wvc, c->scratch[SC_M], nord_max, kfz, nz1);
-      const WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
+      WindStage ws{u, v, uc, vc, divgd, ke, vdamp, wk, dnew, tab.dd8, dt, dddmp, cf.hord_mt, keep_divgd, kfz, nz1};
+      // The vorticity march's damping-heat epilogue wants copies of the winds on its segment / strip boundaries, made before it updates them in place: this
+      // march has every row of u and v in registers, so it stores them (sx_side_copy then only serves the levels under kfz).  Not beside the scalar marches:
+      // the arrays hold their new fields then.  FV3_DSW_SIDE=copy: the separate copies (A/B; read per call).
+      const char *sd = getenv("FV3_DSW_SIDE");
+      if (heat_in_march && s == s_main && !(sd && !strcmp(sd, "copy"))) {
+        ws.u_side = c->scratch[SC_N];
+        ws.v_side = c->scratch[SC_O];
+        ws.side_seg = sx_march_seg(c, nz1 - fdw_k0 + 1);
+        side_from = kfz;
+      }
+      if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] side copies by the wind stage: %s (segment %d)\n", ws.u_side ? "yes" : "no", ws.side_seg);
       wind_stage_march(c, s, ws);
       // (two launches: with ke_value and a2b_point in one closure the geometry block went to scratch memory -- 1600 B per lane, 7 ms for these 3 % of the corners)
       launch_frame_w(c, s, Frame{{Box{1, 3, 1, g.ny + 1, kfz, nz1}, Box{g.npx - 2, g.npx, 1, g.ny + 1, 0, 0}, Box{1, g.nx + 1, 1, 3, 0, 0}, Box{1, g.nx + 1, g.npy - 2, g.npy, 0, 0}}},
@@ -1398,13 +1433,14 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     fv3_wait(c, s, 6);
   else
     wind_branch(s);
+  if (sponge_forked) fv3_wait(c, s, 4);  // (the staged levels from fdw_k0 on feed the march below: level 2 of the 79 -- no divergence-damping chain there, but the vorticity's)
 
   // ---- del-n damping fluxes of the relative vorticity (they depend on wk alone): ahead of the transport, whose wind
   //      epilogue applies them
   Real *utd = c->scratch[SC_E], *vtd = c->scratch[SC_F];  // (the tracer-flux slots: free since the tracer transports are done)
   {
     Deln dn_v{g.nord_v, tab.d6_vt, g.damp_vt, 0, (Real)0, false, (Real)1.0e-5, nord_max_v};
-    del6_vt_flux(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, fdw_k0 - 1);
+    del6_vt_flux(c, sponge_forked ? fv3_aux(c, s) : s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, 0, fdw_k0 - 1);
     if (tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1))  // (the round-5 march runs the chain on every strip: only the cube-corner patches come from the staged chain)
       del6_vt_flux_patches(c, s, wk, c->scratch[SC_TP_QI], utd, vtd, dn_v, false, fdw_k0, nz1);
     else
@@ -1420,7 +1456,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     TpEpi e{nullptr, nullptr, false, nullptr, nullptr, u, v, ke, false, nullptr, nullptr, nullptr, nullptr, nullptr, vtd, utd, g.damp_vt, u_pre, v_pre};
     // (the levels without the chain: a small launch, on the auxiliary stream beside the others -- events 2 = fork, 3 = join)
     fv3_stream_t sv = fdw_k0 > 0 && fdw_k0 <= nz1 ? fv3_aux(c, s) : s;
-    if (sv != s) {
+    if (sv != s && !sponge_forked) {  // (forked: the stream already carries the sponge levels' chain, which is all this launch depends on)
       fv3_signal(c, s, 2);
       fv3_wait(c, sv, 2);
     }
@@ -1432,9 +1468,9 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     // Round 5: on these levels the damping heat is the epilogue of the march (fv3_tp2x.hip, HEAT): the pre-damping winds and the two damping
     // increments are not stored and the damping-heat kernel below only serves the levels under fdw_k0.  FV3_DSW_HEAT=separate: the round-4
     // sequence (A/B; read per call).
-    const char *he = getenv("FV3_DSW_HEAT");
-    const TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source, c->seq_heat_first ? c->zeros : nullptr};
-    if (cf.d_con > 1.0e-5 && !(he && !strcmp(he, "separate")) && fdw_k0 <= nz1 && tp2d_fd_lean(c, cf.hord_vt, fdw_k0, nz1)) e.heat = &th;
+    TpHeat th{vdamp, o_delp, heat_s, g.d_con, heat_source, c->seq_heat_first ? c->zeros : nullptr};
+    th.side_from = side_from;
+    if (heat_in_march) e.heat = &th;
     tp2d(c, s, wk, crx, cry, xfx, yfx, fx, fy, nullptr, nullptr, nullptr, cf.hord_vt, nullptr, fdw_k0, nz1, &e);
     // (whether the march took the heat over is what the dispatch DID, not what was predicted above: a form that ignores TpEpi::heat leaves every level to the kernel below)
     if (th.consumed) heat_k1 = fdw_k0 - 1;

@@ -142,6 +142,7 @@ struct TpHeat {
   // set by the dispatch that actually launches the HEAT march (tp2d_single_march): the caller derives the level range its damping-heat kernel still has to serve
   // from THIS, not from a prediction of the dispatch (the two predicates -- d_sw's and tp2d_stream's -- could drift apart silently otherwise)
   mutable bool consumed = false;
+  int side_from = 1 << 30;  // levels >= side_from already have their side copies (the fused wind stage stored them): sx_side_copy serves the levels under it
 };
 void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, const Real *crx, const Real *cry, const Real *xfx, const Real *yfx, int k0, int k1,
                        const TpEpi *epi, const TpHeat *heat = nullptr);
@@ -163,8 +164,14 @@ struct WindStage {
   int hord;
   bool store_dn;
   int k0, k1;
+  // side copies for the damping-heat epilogue of the vorticity march (fv3_tp2x.hip: sx_side_copy): u on the first row of every row segment of THAT march but
+  // the first (rows 1 + m * side_seg) and v on the first column of every strip but the first (columns 1 + b * 58), before the march updates the winds in place.
+  // This march holds both rows anyway: side_seg > 0 makes it store them (null / 0: the copies stay a launch of their own).
+  Real *u_side = nullptr, *v_side = nullptr;
+  int side_seg = 0;
 };
 void wind_stage_march(fv3_ctx *c, fv3_stream_t s, const WindStage &a);
+int sx_march_seg(const fv3_ctx *c, int nk);  // (fv3_tp2x.hip) rows per segment of the single-tracer marches on nk levels
 
 // two tracers riding on given mass fluxes (the TRC march alone: tracer_2d_1l): a.q_con / a.pt = the two tracers, a.delp = the
 // old air mass, a.o_delp = the new one, a.fx / a.fy = the mass fluxes, outputs a.o_q_con / a.o_pt; no damping (dn_* off)

@@ -579,12 +579,13 @@ void single_march_t(fv3_ctx *c, fv3_stream_t s, const SxArgs &a, int k_lo, int k
 
 // The winds on the faces between segments / strips, copied before the HEAT march updates the winds in place: u on the first face row of every
 // segment but the first, v on the first face column of every strip but the first (the geometry of single_march_t's launch).
-void sx_side_copy(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, Real *u_side, Real *v_side, int k_lo, int k_hi) {
+// (seg_nk: the level count the march itself is launched on -- its segment length depends on it; the copies may serve fewer levels)
+void sx_side_copy(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, Real *u_side, Real *v_side, int k_lo, int k_hi, int seg_nk) {
   const Geo g = c->g;
   const int nk = k_hi - k_lo + 1;
   if (nk <= 0) return;
   const int nstrip = (g.nx + 1 + SX_OUT - 1) / SX_OUT;
-  const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
+  const int seg = sx_march_seg(c, seg_nk);
   const int nseg = (g.ny + seg - 1) / seg;
   launch3(c, s, Box{1, g.nx, 1, nseg - 1, k_lo, k_hi}, [=] FV3_HD(int t, int k, int i, int js) {
     const long p = t * g.st + k * g.sk + IX(i, 1 + js * seg);
@@ -597,6 +598,12 @@ void sx_side_copy(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, Real
 }
 
 }  // namespace
+
+int sx_march_seg(const fv3_ctx *c, int nk) {
+  const Geo &g = c->g;
+  const int nstrip = (g.nx + 1 + SX_OUT - 1) / SX_OUT;
+  return fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, 2);
+}
 
 // kind 1: the vorticity transport of d_sw with the wind update (epi: wind_u / wind_v / wind_ke / wind_du / wind_dv / wind_u_pre / wind_v_pre, fd_coef,
 // fd_add); kind 2: the interface-height transport of update_dz_d (epi: out, fd_coef).  Levels k0 .. k1 all run their del-n chain inside the march.
@@ -630,7 +637,7 @@ void tp2d_single_march(fv3_ctx *c, fv3_stream_t s, int kind, const Real *q, cons
       a.dcon = heat->dcon;
       a.u_side = epi->wind_u_pre;  // (the arrays the epilogue makes redundant serve as the side copies)
       a.v_side = epi->wind_v_pre;
-      sx_side_copy(c, s, epi->wind_u, epi->wind_v, epi->wind_u_pre, epi->wind_v_pre, k0, k1);
+      sx_side_copy(c, s, epi->wind_u, epi->wind_v, epi->wind_u_pre, epi->wind_v_pre, k0, k1 < heat->side_from - 1 ? k1 : heat->side_from - 1, k1 - k0 + 1);
       single_march_t<SX_WIND, true>(c, s, a, k0, k1);
       heat->consumed = true;
     } else {

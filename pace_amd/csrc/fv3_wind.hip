@@ -60,6 +60,8 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
   const Real dt = a.dt, dddmp = a.dddmp, da_min_c = g.da_min_c;
   const int hord = HC ? HC : a.hord;
   const bool store_dn = a.store_dn;
+  Real *const fus = a.u_side, *const fvs = a.v_side;
+  const int side_seg = (a.u_side && a.v_side) ? a.side_seg : 0;
   static const int kb_env = getenv("FV3_KE_KB") ? atoi(getenv("FV3_KE_KB")) : 16;
   const int KB = kb_env > 0 ? (kb_env < nk ? kb_env : nk) : 0;
   const int nblk = KB ? (nk + KB - 1) / KB : 0;
@@ -102,6 +104,7 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
     // uniform bases
     const Real *const ub_ = fu + b, *const vb_ = fv + b, *const ucb = fuc + b, *const vcb = fvc + b, *const dgb = fdg + b;
     Real *const keb = fke + b, *const vdb = fvd + b, *const wkb_ = fwk + b, *const dnb = fdn + b;
+    Real *const usb = side_seg > 0 ? fus + b : nullptr, *const vsb = side_seg > 0 ? fvs + b : nullptr;
     const Real *const cob = (const Real *)m_cosa + m2, *const rsb = (const Real *)m_rsina + m2, *const rdxb = (const Real *)m_rdx + m2, *const rdyb = (const Real *)m_rdy + m2;
     const Real *const dxb = (const Real *)m_dx + m2, *const dyb = (const Real *)m_dy + m2, *const rab = (const Real *)m_ra + m2;
     const Real *const dub = (const Real *)m_du + m2, *const dvb = (const Real *)m_dv + m2, *const racb = (const Real *)m_rac + m2;
@@ -125,7 +128,7 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
     Row3 R[3][FV3_LPT];
     RowM M[3][FV3_LPT];
     unsigned pcolB[FV3_LPT];
-    bool own_e[FV3_LPT], own_c[FV3_LPT], own_w[FV3_LPT];
+    bool own_e[FV3_LPT], own_c[FV3_LPT], own_w[FV3_LPT], own_us[FV3_LPT], own_vs[FV3_LPT];
     // KE (ke_stream; xtp_u with the reconstruction shared between neighbouring lanes as in fv3_tp4x.hip)
     Real w2[FV3_LPT], w3[FV3_LPT], w4[FV3_LPT], w5[FV3_LPT], al_v[FV3_LPT], uc_prev[FV3_LPT], ry_prev[FV3_LPT];
     PpmCell cv[FV3_LPT];
@@ -179,6 +182,13 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
     // last step: corner row jb at step jb + 2; the last segment also owns the wk rows up to jed (row jed at step jed + 1)
     int r_last = jb + 2;
     if (seg_last && jed + 1 > r_last) r_last = jed + 1;
+    // side copies (see WindStage): the next row >= ja of the form 1 + m * side_seg, m >= 1
+    int next_us = 1 << 30;
+    if (side_seg > 0) {
+      int m = (ja - 1 + side_seg - 1) / side_seg;
+      if (m < 1) m = 1;
+      next_us = 1 + m * side_seg;
+    }
 
     FV3_LANES(blk_, lane, l) {
       const int i = i0 - 3 + lane, ic = i < imax ? i : imax;
@@ -186,6 +196,8 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
       own_c[l] = i >= i0 && i < i0 + WS_OUT && i <= nx + 1;                    // a corner column of this strip
       own_e[l] = own_c[l] && i >= ia && i <= ib;                               // ... that takes the interior formulas
       own_w[l] = (i >= i0 && i < i0 + WS_OUT && i <= ied) || (strip_first && i >= isd && i < i0) || (strip_last && i >= i0 + WS_OUT && i <= ied);  // a wk column of this strip
+      own_us[l] = own_c[l] && i <= nx;          // side copies: u on the compute columns of this strip ...
+      own_vs[l] = i == i0 && bx > 0;            // ... v on the first column of every strip but the first
       w2[l] = w3[l] = w4[l] = w5[l] = al_v[l] = uc_prev[l] = ry_prev[l] = u1[l] = u2[l] = a_prev[l] = (Real)0;
       cv[l] = PpmCell{(Real)0, (Real)0, (Real)0, false};
       s_vcc[l] = s_ucs[l] = s_co[l] = s_rs[l] = s_ry[l] = s_rx[l] = s_du[l] = s_u[l] = (Real)0;
@@ -217,6 +229,9 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
       const int jw = r - 1;                                                                // the wk cell row of this step
       const bool row_w = !GEN || (jw >= ja && jw <= jb && jw <= jed) || (seg_first && jw >= jsd && jw < ja) || (seg_last && jw > jb && jw <= jed);
       const bool prow = GEN && patch_cols && jf >= 1 && ((jf <= P && (c_ll || c_hl)) || (jf >= ny + 2 - P && jf <= ny + 1 && (c_hh || c_lh)));
+      const bool side_now = side_seg > 0 && r >= ja && r <= jb && r >= 1 && r <= ny;  // this step's row r of u / v is one the side copies may want
+      const bool side_u = side_now && r == next_us;
+      if (side_seg > 0 && r >= next_us) next_us += side_seg;
       // ---- phase 1a (own lane): the requests; what the neighbouring lanes will read of this step's rows
       FV3_LANES(blk_, lane, l) {
         if (WS_PF3 == 2)
@@ -226,6 +241,11 @@ void wind_stage_march_t(fv3_ctx *c, fv3_stream_t s, const WindStage &a) {
         M[Q1][l] = loadm(r + 1, l, gen_tag);
         const Row3 cu = R[Q][l];
         const RowM cm = M[Q][l];
+        if (side_now) {  // (wave-uniform; rows of this segment only: every row belongs to one segment)
+          const unsigned ps = pcolB[l] + (unsigned)r * rowB;
+          if (side_u && own_us[l]) *fv3_at(usb, ps) = cu.u;
+          if (own_vs[l]) *fv3_at(vsb, ps) = cu.v;
+        }
         s_vcc[l] = cu.vcc;
         s_ucs[l] = uc_prev[l] + cu.ucc;
         uc_prev[l] = px_move(cu.ucc);

@@ -498,6 +498,26 @@ def test_fused_wind_stage_is_bitwise_the_staged_kernels(backend, monkeypatch, n,
             assert np.array_equal(res["fused"][r][name], res["staged"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, seg", [(130, (1, 1), "0"), (140, (2, 2), "32"), (70, (1, 1), "16")])
+def test_side_copies_by_the_wind_stage_are_bitwise_the_copy_launches(backend, monkeypatch, n, layout, seg):
+    """The damping-heat epilogue of d_sw's vorticity march differentiates the winds as they were before the march updates them in place; on the boundaries
+    between its row segments / column strips it reads copies of them.  Default: the fused wind stage, which has every row of u and v in registers, stores
+    those rows / columns (WindStage::u_side; the levels under it by sx_side_copy); FV3_DSW_SIDE=copy: two copy launches on every level.  Every field bitwise
+    equal over two calls -- several strips (n = 130), several row segments of either march, both with different lengths (FV3_SEG), 2 x 2 sub-domains."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    if seg != "0":
+        monkeypatch.setenv("FV3_SEG", seg)
+    res = {}
+    for mode in ("march", "copy"):
+        monkeypatch.setenv("FV3_DSW_SIDE", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["march"][r][name], res["copy"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout, seg", [(24, (2, 2), "0"), (130, (1, 1), "0"), (140, (2, 2), "32"), (48, (1, 1), "0")])
 def test_vorticity_inside_the_corner_ke_march_is_bitwise_the_vorticity_launch(backend, monkeypatch, n, layout, seg):
     """d_sw's cell-mean relative vorticity formed by the corner-KE march for the cells under its corners (the march reads u and v anyway; the vorticity

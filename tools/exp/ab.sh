@@ -17,7 +17,7 @@ if [ -n "$kexpr" ]; then
   grep -E "passed|failed|error" "$out/pytest.log" | tail -2
 fi
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-for rep in a b; do
+for rep in ${AB_REPS:-a b}; do
   for v in "$@"; do
     name=${v%%:*}; envs=${v#*:}
     env ${envs//,/ } X_=1 $B > "$out/bench_${name}_$rep.log" 2>&1
