@@ -299,6 +299,15 @@ struct fv3_gather_plan {
   int64_t *src_off;
   signed char *sign;
 };
+// one gather of a batch (fv3_gather_run_jobs: the pack / local / unpack gathers of ONE halo update as one launch per FV3_GATHER_MAXOPS of them)
+struct fv3_gather_job {
+  const fv3_gather_plan *plan;
+  void *dst;
+  const void *src;
+  int64_t dks, sks;
+  int nk;
+};
+int fv3_gather_run_jobs(fv3_ctx *c, const fv3_gather_job *jobs, int n, void *stream);  // fv3_ctx.hip
 
 // ---------------------------------------------------------------------------------------------
 // Two-stream helpers.  fv3_aux(c, s): the stream helper kernels go to (the caller's stream itself when

@@ -582,6 +582,48 @@ __global__ void __launch_bounds__(256) fv3_gather_kernel(int64_t n, const int64_
 }
 #endif
 
+#ifndef FV3_HOST_EMU
+// Round 6: the gathers of one halo update (per field group: the device-local copies; per peer and component: a pack, an unpack) as ONE launch.  With 3 sub-domains
+// per process an update is ~ 12 gathers of 5 - 15 us each (131 launches, 2.1 ms per sub-step of the 1/8 share); the batch's workgroups are those of its gathers one
+// after the other, a workgroup finds its gather by comparing its index with the gathers' first workgroups (the descriptors are kernel arguments, selected with
+// scalar compares -- no indexed read of them).
+#ifndef FV3_GATHER_MAXOPS
+#define FV3_GATHER_MAXOPS 12
+#endif
+struct GatherOp {
+  int64_t n, dks, sks;
+  const int64_t *dst_off, *src_off;
+  const signed char *sign;
+  Real *dst;
+  const Real *src;
+  int nk;
+  unsigned first, nbx;  // first workgroup of this gather in the launch; its workgroups along the element index
+};
+struct GatherBatch {
+  int n;
+  GatherOp op[FV3_GATHER_MAXOPS];
+};
+__global__ void __launch_bounds__(256) fv3_gather_kernel_batch(const GatherBatch b) {
+  GatherOp g = b.op[0];
+#pragma unroll
+  for (int i = 1; i < FV3_GATHER_MAXOPS; ++i)
+    if (i < b.n && blockIdx.x >= b.op[i].first) g = b.op[i];
+  const unsigned lb = blockIdx.x - g.first;
+  const unsigned by = lb / g.nbx, bx = lb - by * g.nbx;
+  const int64_t e = (int64_t)bx * 256 + threadIdx.x;
+  const int k0 = (int)by * FV3_GATHER_KPT;
+  if (e >= g.n) return;
+  const int64_t d = g.dst_off[e], so = g.src_off[e];
+  const Real sg = (Real)g.sign[e];
+  Real v[FV3_GATHER_KPT];
+#pragma unroll
+  for (int kk = 0; kk < FV3_GATHER_KPT; ++kk) v[kk] = k0 + kk < g.nk ? g.src[so + (k0 + kk) * g.sks] : (Real)0;
+#pragma unroll
+  for (int kk = 0; kk < FV3_GATHER_KPT; ++kk)
+    if (k0 + kk < g.nk) g.dst[d + (k0 + kk) * g.dks] = sg * v[kk];
+}
+#endif
+
 int fv3_gather_run(fv3_ctx *c, const fv3_gather_plan *p, void *dst, int64_t dks, const void *src, int64_t sks, int nk, void *stream) {
   if (!c || !p || !dst || !src) return FV3_ERR_ARG;
   if (p->n == 0 || nk <= 0) return FV3_OK;
@@ -601,3 +643,43 @@ int fv3_gather_run(fv3_ctx *c, const fv3_gather_plan *p, void *dst, int64_t dks,
 }
 
 }  // extern "C"
+
+// The gathers of a batch must be independent of one another (the halo plans': every one reads compute cells or a message buffer and writes halo cells or a
+// message buffer).  FV3_GATHER_BATCH=0: one launch per gather (A/B; read once).  The host emulation runs them one by one.
+int fv3_gather_run_jobs(fv3_ctx *c, const fv3_gather_job *jobs, int n, void *stream) {
+  if (!c || (n && !jobs) || n < 0) return FV3_ERR_ARG;
+#ifndef FV3_HOST_EMU
+  static const bool batch_off = getenv("FV3_GATHER_BATCH") && getenv("FV3_GATHER_BATCH")[0] == '0';
+  if (!batch_off) {
+    GatherBatch b;
+    b.n = 0;
+    unsigned nblk = 0;
+    auto flush = [&]() -> int {
+      if (b.n == 0) return FV3_OK;
+      for (int i = b.n; i < FV3_GATHER_MAXOPS; ++i) b.op[i] = b.op[0];  // (never selected: i < b.n fails)
+      hipLaunchKernelGGL(fv3_gather_kernel_batch, dim3(nblk, 1, 1), dim3(256, 1, 1), 0, (hipStream_t)stream, b);
+      b.n = 0;
+      nblk = 0;
+      return fv3_post(c, (fv3_stream_t)stream, "gather");
+    };
+    for (int i = 0; i < n; ++i) {
+      const fv3_gather_job &j = jobs[i];
+      if (!j.plan || !j.dst || !j.src) return FV3_ERR_ARG;
+      if (j.plan->n == 0 || j.nk <= 0) continue;
+      const unsigned nbx = (unsigned)((j.plan->n + 255) / 256), nby = (unsigned)((j.nk + FV3_GATHER_KPT - 1) / FV3_GATHER_KPT);
+      b.op[b.n++] = GatherOp{j.plan->n, j.dks, j.sks, j.plan->dst_off, j.plan->src_off, j.plan->sign, (Real *)j.dst, (const Real *)j.src, j.nk, nblk, nbx};
+      nblk += nbx * nby;
+      if (b.n == FV3_GATHER_MAXOPS) {
+        const int st = flush();
+        if (st != FV3_OK) return st;
+      }
+    }
+    return flush();
+  }
+#endif
+  for (int i = 0; i < n; ++i) {
+    const int st = fv3_gather_run(c, jobs[i].plan, jobs[i].dst, jobs[i].dks, jobs[i].src, jobs[i].sks, jobs[i].nk, stream);
+    if (st != FV3_OK) return st;
+  }
+  return FV3_OK;
+}

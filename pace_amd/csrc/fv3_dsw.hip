@@ -824,19 +824,28 @@ static void dd_copy_windows(fv3_ctx *c, fv3_stream_t s, const Real *a, const Rea
   Wins wins, patches;
   int needs[4];
   dd_windows(g, k0, k1, wins, patches, needs);
+  if (wins.n == 0) return;
+  for (int w = 0; w < wins.n; ++w) {
+    wins.w[w].i0 -= grow;
+    wins.w[w].i1 += grow;
+    wins.w[w].j0 -= grow;
+    wins.w[w].j1 += grow;
+  }
+  auto body = [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    a2[p] = a[p];
+    b2[p] = b[p];
+  };
+  const Box nat{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1};
+  if (fv3_wins_disjoint(wins)) {  // (one launch for the four corners; tiny sub-domains, whose windows overlap: one corner at a time)
+    launch3w(c, s, nat, wins, body);
+    return;
+  }
   for (int w = 0; w < wins.n; ++w) {
     Wins one;
     one.n = 1;
     one.w[0] = wins.w[w];
-    one.w[0].i0 -= grow;
-    one.w[0].i1 += grow;
-    one.w[0].j0 -= grow;
-    one.w[0].j1 += grow;
-    launch3w(c, s, Box{1 - g.nh, g.nx + g.nh + 1, 1 - g.nh, g.ny + g.nh + 1, k0, k1}, one, [=] FV3_HD(int t, int k, int i, int j) {
-      const long p = t * g.st + k * g.sk + IX(i, j);
-      a2[p] = a[p];
-      b2[p] = b[p];
-    });
+    launch3w(c, s, nat, one, body);
   }
 }
 static void divdamp_patches(fv3_ctx *c, fv3_stream_t s, const Real *divgd, Real *out, Real *uc, Real *vc, Real *tmp, int nord_max, int k0, int k1) {

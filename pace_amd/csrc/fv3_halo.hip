@@ -80,6 +80,8 @@ Rccl &rccl() {
 }
 
 int run_ops(fv3_ctx *c, fv3_halo_plan *p, int kind, void *stream) {
+  std::vector<fv3_gather_job> jobs;  // (the gathers of one kind of an update are independent of one another: one batch)
+  jobs.reserve(p->ops.size());
   for (const fv3_halo_op &o : p->ops) {
     if (o.kind != kind) continue;
     void *dst = o.dst;
@@ -96,10 +98,10 @@ int run_ops(fv3_ctx *c, fv3_halo_plan *p, int kind, void *stream) {
       src = (const char *)p->recv_buf[o.peer] + (size_t)o.buf_off * sizeof(Real);
       sks = o.buf_kstride;
     }
-    const int st = fv3_gather_run(c, o.plan, dst, dks, src, sks, o.nk, stream);
-    if (st != FV3_OK) return st;
+    if (!dst || !src) return FV3_ERR_ARG;
+    jobs.push_back(fv3_gather_job{o.plan, dst, src, dks, sks, o.nk});
   }
-  return FV3_OK;
+  return fv3_gather_run_jobs(c, jobs.data(), (int)jobs.size(), stream);
 }
 
 }  // namespace

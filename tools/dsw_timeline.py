@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize_rocprof import short  # noqa: E402
 
 
-def main(path, which=14, whole=False):
+def main(path, which=14, whole=False, per=1):
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
@@ -25,7 +25,7 @@ def main(path, which=14, whole=False):
     t0 = starts[which]
     t1 = next((s for s, e, n, q in rows if s > t0 and "edge_profile" in n), rows[-1][1])
     if whole:  # the whole sub-step that starts with this d_sw: up to the end of the next p_grad_c
-        t1 = starts[which + 1] if which + 1 < len(starts) else rows[-1][1]
+        t1 = starts[which + per] if which + per < len(starts) else rows[-1][1]  # (per: p_grad_c launches per sub-step -- 2 with the frame-first passes)
     win = [x for x in rows if x[0] >= t0 and x[0] < t1]
     queues = sorted({q for *_, q in win})
     print(f"{'sub-step from the d_sw' if whole else 'd_sw window'} of sub-step {which}: {(t1 - t0) / 1e6:.3f} ms, {len(win)} launches on {len(queues)} queues")
@@ -40,4 +40,4 @@ def main(path, which=14, whole=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 14, len(sys.argv) > 3 and sys.argv[3] == "substep")
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 14, len(sys.argv) > 3 and sys.argv[3] == "substep", int(sys.argv[4]) if len(sys.argv) > 4 else 1)

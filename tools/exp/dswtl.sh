@@ -11,10 +11,10 @@ for v in "$@"; do
   (
     for e in ${envs//,/ }; do export "$e"; done
     cd /tmp && export TMPDIR=/tmp
-    timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$out/$name" -o t -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-op-timing > "$out/bench_$name.log" 2>&1
+    timeout 900 rocprofv3 --kernel-trace --output-format csv -d "$out/$name" -o t -- python3 "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-op-timing ${BENCH_ARGS:-} > "$out/bench_$name.log" 2>&1
   )
   f=$(find "$out/$name" -name "t_kernel_trace.csv" | head -1)
   echo "== $name"
-  python3 "$R/tools/dsw_timeline.py" "$f" 14 ${TL_MODE:-} | tee "$out/timeline_$name.md"
+  python3 "$R/tools/dsw_timeline.py" "$f" ${TL_WHICH:-14} ${TL_MODE:-} ${TL_PER:-} | tee "$out/timeline_$name.md"
   find "$out/$name" -name "*kernel_trace.csv" -delete
 done

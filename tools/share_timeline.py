@@ -43,6 +43,21 @@ def main(path, n_sub):
           f"= {sum(gaps) / 1e6 / n_sub:.3f} ms per sub-step (median gap {sorted(gaps)[len(gaps) // 2] / 1e3:.1f} us, largest {max(gaps) / 1e3:.1f} us)" if gaps else "no gaps")
     print(f"launches shorter than 20 us: {len(short)} ({len(short) / n_sub:.1f} per sub-step), {sum(short) / 1e6:.3f} ms in all = {sum(short) / 1e6 / n_sub:.4f} ms per sub-step")
     print(f"sum of the kernel durations {sum(dur) / 1e6:.2f} ms = {sum(dur) / wall:.2f} x the wall time (two streams)")
+    # who the short launches are (by kernel, per sub-step), and the kernels by total time
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from summarize_rocprof import short as short_name
+    by = {}
+    for s_, e, n in rows:
+        k = short_name(n)[:70]
+        c = by.setdefault(k, [0, 0, 0])
+        c[0] += 1
+        c[1] += e - s_
+        c[2] += 1 if e - s_ < 20000 else 0
+    print("| kernel | launches per sub-step | of them < 20 us | ms per sub-step |")
+    print("|---|---:|---:|---:|")
+    for k, c in sorted(by.items(), key=lambda kv: -kv[1][0])[:28]:
+        print(f"| {k} | {c[0] / n_sub:.1f} | {c[2] / n_sub:.1f} | {c[1] / 1e6 / n_sub:.3f} |")
 
 
 if __name__ == "__main__":
