@@ -271,6 +271,12 @@ struct fv3_ctx {
   // owed -- the sequencer pays it before riem_solver_c, the first reader (fv3_csw_join).  The stand-alone operator always joins before it returns.
   bool seq_csw_defer = false;
   bool csw_pending = false;
+  // Round 6: inside the sequencer update_dz_d leaves its last kernel -- the bottom-up scan that keeps the marched interface heights dz_min apart and forms
+  // the surface vertical velocity -- to riem_solver3, whose wave form runs it as a pre-sweep of each column (fv3_nh.hip: PRE).  seq_dz_scan: the sequencer
+  // allows it for the update_dz_d call it is about to make; dz_scan_src: the marched heights of a scan still to be done (null: none); dz_scan_min: dz_min.
+  bool seq_dz_scan = false;
+  Real *dz_scan_src = nullptr;
+  Real dz_scan_min = (Real)0;
   bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step
   Real *zeros = nullptr;
   const void *pp_from[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -251,9 +251,11 @@ struct Sim1W {
   // thickness comes from; wout (optional, may alias w1) receives the new w.
   // GL: the gam arrays live in a second LDS line B (2 waves / CU at L79) instead of the scratch field GAM.
   // RA: gam lives in the lane's accumulation registers (KREG_*; nz <= FV3_KREG_LEVELS): four field passes less per call.
-  template <bool GL, bool RA, class C>
+  // ZL: sweep 1 takes the interface heights from the LDS line A instead of zint -- z(k + 1) in slot k, z(0) = z0 (riem_solver3's pre-sweep put them
+  //     there; slot m is read at step m and overwritten with PP at step m + 1); sweep 3 reads zint as always.
+  template <bool GL, bool RA, bool ZL = false, class C>
   FV3_HD void run(Real *A, Real *B, long tb, unsigned pix, Real dt, const Real *delp, const Real *cappa, const Real *pt, const Real *qcon, const Real *zint, const Real *w1,
-                  Real ws, Real *PM, Real *GAM, Real *wout, C &cl) const {
+                  Real ws, Real *PM, Real *GAM, Real *wout, C &cl, Real z0 = (Real)0) const {
     const Real t1g = (Real)2.0 * dt * dt, rdt = (Real)1.0 / dt, r3 = (Real)(1.0 / 3.0);
     constexpr int U = FV3_RIEM_U, U1 = FV3_RIEM_U1;
     constexpr int UB = RA ? 1 : U1;  // the back substitutions: nothing to prefetch when gam is in registers (one access site)
@@ -288,22 +290,23 @@ struct Sim1W {
     // ---- sweep 1 (up): layer pressures, forward elimination for pp.  PP(k+1) -> slot k
     {
       Real g_prev = (Real)0, dm_k = (Real)0, pe_k = (Real)0, bet = (Real)0, pp_k = (Real)0;  // g_prev = dm(k-1) / dm(k) = the previous step's g_rat
-      Real z_top = KW_(zint, 0);
+      Real z_top = ZL ? z0 : KW_(zint, 0);
       auto ld = [&](int k) {
         KRec<5> q;
         q.v[0] = KW_(delp, k);
         q.v[1] = KW_(cappa, k);
         q.v[2] = KW_(pt, k);
         q.v[3] = KW_(qcon, k);
-        q.v[4] = KW_(zint, k + 1);
+        q.v[4] = ZL ? (Real)0 : KW_(zint, k + 1);
         return q;
       };
       KWALK_E(5, U, true, ld, GAM_FLUSH4(), {
         const int m = K;
         const Real pm_n = cl.pm(m, r.v[0], r.v[3]);
         KW_(PM, m) = pm_n;
-        const Real dz_n = r.v[4] - z_top;
-        z_top = r.v[4];
+        const Real z_lo = ZL ? A[m * FV3_WAVE] : r.v[4];  // (ZL: before this step's PP goes to slot m - 1)
+        const Real dz_n = z_lo - z_top;
+        z_top = z_lo;
         const Real dm_n = r.v[0] * rgrav;
         const Real pe_n = fv3_exp(fv3_div((Real)1.0, (Real)1.0 - r.v[1]) * fv3_log(fv3_div(-dm_n, dz_n) * rgas * r.v[2])) - pm_n;
         if (m >= 1) {
@@ -779,9 +782,13 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const int nwave = (ncol + FV3_WAVE - 1) / FV3_WAVE;
     const int nwave_frame = c->frame_pass != 0 ? (ord.n_frame() + FV3_WAVE - 1) / FV3_WAVE : 0;
     const int w_lo = c->frame_pass == 2 ? nwave_frame : 0, w_hi = c->frame_pass == 1 ? nwave_frame : nwave;  // waves [w_lo, w_hi)
-    auto go_ = [&](auto last_tag, auto ra_tag) {
+    Real *const zn = c->dz_scan_src;  // (update_dz_d left its scan to this call: see fv3_ctx::seq_dz_scan)
+    const bool pre = zn != nullptr;
+    const Real dzm = c->dz_scan_min;
+    auto go_ = [&](auto last_tag, auto ra_tag, auto pre_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     constexpr bool RA = decltype(ra_tag)::value;
+    constexpr bool PRE = decltype(pre_tag)::value;
     launch_waves<1>(c, s, w_hi - w_lo, 1, g.nsub, sizeof(Real) * nz * FV3_WAVE * (gl ? 2 : 1), [=] FV3_HD(const Blk &blk, char *smem_) {
       const int t = blk.bz;
       const long tb = t * st;
@@ -829,20 +836,54 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           KW_(pe, 0) = ptop;
         }
         KW_(ppe, 0) = (Real)0;
-        sw.run<FV3_RIEM_GL != 0, RA>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt, delp, cappa, pt, q_con, zh, w, wsd[t * st2 + pix], PM, GAM, w, cl);
+        Real ws_v, z0 = (Real)0;
+        if constexpr (PRE) {
+          // update_dz_d's last kernel as a pre-sweep (bottom-up): interface k stays dz_min above interface k + 1; the limited heights go to the LDS line for
+          // sweep 1 (z(k + 1) in slot k) and -- only where the limit changed them -- back into the marched field, which sweep 3 reads; the surface vertical
+          // velocity from the lowest interface.  Same expressions as the scan kernel (fv3_update_dz_d): bitwise the separate form.
+          Real *A_ = (Real *)smem_ + lane;
+          Real below = KW_(zn, nz);
+          A_[(nz - 1) * FV3_WAVE] = below;
+          ws_v = (z_bot - below) / dt;
+          wsd[t * st2 + pix] = ws_v;
+          auto ldz = [&](int k) {
+            KRec<1> q;
+            q.v[0] = KW_(zn, k);
+            return q;
+          };
+          KWALK(1, FV3_RIEM_U1, false, ldz, {
+            const Real zk = r.v[0];
+            const Real v = fv3_max(zk, below + dzm);
+            if (v != zk) KW_(zn, K) = v;
+            if (K >= 1)
+              A_[(K - 1) * FV3_WAVE] = v;
+            else
+              z0 = v;
+            below = v;
+          })
+        } else {
+          ws_v = wsd[t * st2 + pix];
+        }
+        sw.run<FV3_RIEM_GL != 0, RA, PRE>((Real *)smem_ + lane, (Real *)smem_ + nz * FV3_WAVE + lane, tb, pix, dt, delp, cappa, pt, q_con, PRE ? (const Real *)zn : (const Real *)zh, w, ws_v, PM, GAM, w, cl, z0);
         KW_(zh, nz) = z_bot;
       }
     });
     };
     const bool ra = riem_reg_arrays(g);
-    if (last && ra)
-      go_(std::true_type{}, std::true_type{});
+    if (pre) {  // (the pre-sweep exists in the register-array forms only: fv3_update_dz_d defers under the same predicate)
+      if (last)
+        go_(std::true_type{}, std::true_type{}, std::true_type{});
+      else
+        go_(std::false_type{}, std::true_type{}, std::true_type{});
+      if (c->frame_pass != 1) c->dz_scan_src = nullptr;  // (frame-first passes: both take the pre-sweep, each on its own columns)
+    } else if (last && ra)
+      go_(std::true_type{}, std::true_type{}, std::false_type{});
     else if (last)
-      go_(std::true_type{}, std::false_type{});
+      go_(std::true_type{}, std::false_type{}, std::false_type{});
     else if (ra)
-      go_(std::false_type{}, std::true_type{});
+      go_(std::false_type{}, std::true_type{}, std::false_type{});
     else
-      go_(std::false_type{}, std::false_type{});
+      go_(std::false_type{}, std::false_type{}, std::false_type{});
     return fv3_post(c, s, "riem_solver3");
   }
   launch2_pass(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, c->frame_pass, [=] FV3_HD(int t, int i, int j) {
@@ -1389,7 +1430,11 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
     del6_vt_flux_patches(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);
   else
     del6_vt_flux_edge_strips(c, s, zh, d2, fx2, fy2, dn, false, fd_k0, nz);
-  Real *znew = fx;
+  // Round 6: inside the sequencer (fv3_ctx::seq_dz_scan) the scan at the end of this operator becomes the pre-sweep of riem_solver3's wave form, which reads the
+  // marched heights where this call leaves them (the free slot SC_F: riem_solver3's scratch fields are SC_A / C / D / E).  FV3_DZ_SCAN=separate: the kernel below (A/B).
+  const char *zse = getenv("FV3_DZ_SCAN");
+  const bool scan_deferred = c->seq_dz_scan && riem_wave_ok(g, true) && riem_reg_arrays(g) && !(zse && !strcmp(zse, "separate"));
+  Real *znew = scan_deferred ? fy : fx;
   {
     TpEpi e{znew, nullptr, false, nullptr, nullptr, nullptr, nullptr, nullptr, true, fx2, fy2, g.damp_vt, nullptr, nullptr};
     tp2d(c, sa, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, 0, fd_k0 - 1, &e);
@@ -1398,6 +1443,12 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, const fv3_field *zs_, const fv3_field
     e.fd_coef = dz_coef;
     tp2d(c, s, zh, crx_a, cry_a, xfx_a, yfx_a, c->scratch[SC_J], c->scratch[SC_K], nullptr, nullptr, nullptr, c->cfg.hord_tm, nullptr, fd_k0, nz, &e);
     if (sa != s) fv3_wait(c, s, 3);
+  }
+  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[update_dz_d] closing scan: %s\n", scan_deferred ? "left to riem_solver3's pre-sweep" : "own kernel");
+  if (scan_deferred) {
+    c->dz_scan_src = znew;
+    c->dz_scan_min = dz_min;
+    return fv3_post(c, s, "update_dz_d");
   }
   launch2(c, s, Box{1, g.nx, 1, g.ny, 0, 0}, [=] FV3_HD(int t, int i, int j) {
     const long tb = t * g.st;

@@ -281,6 +281,8 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_acc_first = false;
       c->seq_heat_first = false;
       c->seq_csw_defer = false;
+      c->seq_dz_scan = false;
+      c->dz_scan_src = nullptr;
     }
   } pp_guard{c, stream};
 
@@ -413,7 +415,9 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     }
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);
+    c->seq_dz_scan = true;  // (its closing scan becomes riem_solver3's pre-sweep: nothing between the two reads zh or wsd)
     RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
+    c->seq_dz_scan = false;
     if (frame_first) {
       // the frame columns of the new zh / pkc first, their updates start, the interior columns follow beside the messages
       c->frame_pass = 1;

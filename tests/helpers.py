@@ -100,12 +100,12 @@ def oracle_cube(nx_tile, layout, nz, cfg_kw=None, seed=7, noise=0.01):
     return part, cfg, grids, ost, phis, dyn
 
 
-def run_device_cube(backend, part, cfg, grids, ost_init, phis, timestep, n_calls=1, dtype=torch.float64, native=True):
+def run_device_cube(backend, part, cfg, grids, ost_init, phis, timestep, n_calls=1, dtype=torch.float64, native=True, constants=None):
     """Run AcousticDynamics on every rank of the cube in one context; returns per-rank arrays."""
     from pace_amd.dyn_core import AcousticDynamics, DycoreState
     from pace_amd.halo import Layout
 
-    sf = stencil_factory_for(backend)(grids, cfg, get_constants(), dtype=dtype)
+    sf = stencil_factory_for(backend)(grids, cfg, constants or get_constants(), dtype=dtype)
     per_rank = [dict(s, phis=p) for s, p in zip(ost_init, phis)]
     st = DycoreState.from_arrays(sf.quantity_factory, per_rank)
     dyn = AcousticDynamics(Layout(part, 1, 0), grids, sf, config=cfg, phis=st.phis, state=st)

@@ -555,6 +555,32 @@ def test_heights_of_a_call_straight_into_zh_is_bitwise_the_reference_order(backe
             assert np.array_equal(res["direct"][r][name], res["copy"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, dz_min", [(24, (2, 2), None), (48, (1, 1), None), (24, (1, 1), 2500.0), (70, (1, 1), 4000.0)])
+def test_height_scan_as_the_pre_sweep_of_riem_solver3_is_bitwise_the_scan_kernel(backend, monkeypatch, n, layout, dz_min):
+    """Inside fv3_acoustic_step update_dz_d leaves its closing kernel -- the bottom-up scan that keeps the marched interface heights dz_min apart and forms the
+    surface vertical velocity -- to riem_solver3, whose wave form runs it as a pre-sweep of each column: the limited heights go to the solver's LDS line for its
+    first sweep and, only where the limit changed them, back into the marched field its third sweep reads (FV3_DZ_SCAN=separate: the scan kernel).  Every field
+    bitwise equal over two calls; with the reference's dz_min (2 m: the limit never acts on these states) and with dz_min of the order of the layer thickness,
+    where it acts in most columns (the case that exercises the conditional write-back)."""
+    import dataclasses
+
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=2))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    cst = dataclasses.replace(get_constants(), DZ_MIN=dz_min) if dz_min else None
+    res = {}
+    for mode in ("presweep", "separate"):
+        monkeypatch.setenv("FV3_DZ_SCAN", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2, constants=cst)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["presweep"][r][name], res["separate"][r][name], equal_nan=True), f"{name} rank {r}"
+    if dz_min:  # (the limit must have acted: the same run with the reference's dz_min gives other heights)
+        ref, *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+        assert any(not np.array_equal(res["presweep"][r]["delz"], ref[r]["delz"]) for r in range(part.total_ranks))
+        assert all(np.isfinite(res["presweep"][r]["delz"]).all() for r in range(part.total_ranks))
+
+
 @pytest.mark.parametrize("n, layout, alt", [(12, (1, 1), ""), (24, (2, 2), ""), (59, (1, 1), ""), (140, (2, 2), ""), (130, (1, 1), ""), (24, (1, 1), "heat_zero_first_call")])
 def test_fused_smoothing_and_heating_is_bitwise_the_staged_operators(backend, monkeypatch, n, layout, alt):
     """fv3_acoustic_step's damping-heat tail as one pass (fv3_del2x.hip: three del2_cubed iterations in LDS + apply_diffusive_heating) against the staged
