@@ -275,6 +275,8 @@ struct fv3_ctx {
   // the surface vertical velocity -- to riem_solver3, whose wave form runs it as a pre-sweep of each column (fv3_nh.hip: PRE).  seq_dz_scan: the sequencer
   // allows it for the update_dz_d call it is about to make; dz_scan_src: the marched heights of a scan still to be done (null: none); dz_scan_min: dz_min.
   bool seq_dz_scan = false;
+  bool seq_uava_thin = false;  // the sequencer: this c_sw call is not the last of the acoustic call -- its A-grid winds are read by d_sw's divergence on the levels without a damping chain and by c_sw's own boundary windows next to the march's rectangle, nowhere else
+  bool seq_delz_dead = false;  // the sequencer: this riem_solver3 call is not the last of the acoustic call -- nobody reads the layer thickness it would store (the next sub-step works from zh)
   Real *dz_scan_src = nullptr;
   Real dz_scan_min = (Real)0;
   bool seq_heat_first = false;  // ... the same for the accumulated damping heat (heat_source): d_sw's two heat sites form 0 + heat on the call's first sub-step

@@ -330,10 +330,11 @@ static void csw_abc_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real
 #define CSWF_STE(base, idx, val) (FV3_EL(base, idx) = (val))
 #endif
 static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Real *v, const Real *delp, const Real *pt, const Real *w, Real *ua, Real *va, Real *uc,
-                             Real *vc, Real *ut, Real *vt, Real *divgd, Real *delpc, Real *ptc, Real *omga, Real *ke, Real *vort, Real dt2, bool do_div) {
+                             Real *vc, Real *ut, Real *vt, Real *divgd, Real *delpc, Real *ptc, Real *omga, Real *ke, Real *vort, Real dt2, bool do_div, bool uava_thin) {
   const Geo g = c->g;
   const Geo *gp = c->g_dev;
   const int nk = g.nz;
+  const int *nord_tab = g.nord;  // (per level: 0 = d_sw forms the divergence from ua / va there)
   const int nstrip = (g.nx + 2 + CSWF_OUT - 1) / CSWF_OUT;
   const int seg = fv3_pick_seg((long)nstrip * ((g.ny + 63) / 64) * g.nsub * nk, CSWF_WPE);
   const int nseg = (g.ny + 2 + seg - 1) / seg;
@@ -350,6 +351,9 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
     const int k_ = blk.bx * CSWF_NW + blk.by, t = blk.bz / ntile, tile = blk.bz - t * ntile;
     const bool live = k_ < nk;
     const int k = live ? k_ : nk - 1;
+    // Round 6 (uava_thin: inside the sequencer, not the last sub-step of a call): ua / va of this level are stored in full only where d_sw reads them (no damping
+    // chain on the level); elsewhere only the two cells next to the rectangle's boundary, which the boundary-window kernels read -- two field writes less.
+    const bool sua = !uava_thin || nord_tab[k] == 0;
     const int tby = tile / nstrip, tbx = tile - tby * nstrip;
     const CswRect rc = csw_rect(gp->flags[t], nx, ny, npx, npy);
     const int c0 = rc.i_lo + tbx * CSWF_OUT;
@@ -553,8 +557,10 @@ static void csw_fused_stream(fv3_ctx *c, fv3_stream_t s, const Real *u, const Re
         const Real vt_o = vtv > (Real)0 ? dt2 * vtv * mc_dx[l] * mc_s4[l] : dt2 * vtv * mc_dx[l] * mc_s2[l];
         const unsigned pd = pcol[l] + (unsigned)(jd * sj32), pv = pcol[l] + (unsigned)(jv * sj32);
         if (c_r0[l] && seg_d) {
-          CSWF_STE(ua + b, pd, ua_);
-          CSWF_STE(va + b, pd, va_);
+          if (sua || c_kb[l] || kb_row) {
+            CSWF_STE(ua + b, pd, ua_);
+            CSWF_STE(va + b, pd, va_);
+          }
           CSWF_STE(ut + b, pd, ut_o);
           if (!(c_re[l] && r_re_d)) CSWF_STE(uc + b, pd, ucv);  // the rim of the rectangle: the stage E kernel finishes it
         }
@@ -748,7 +754,9 @@ extern "C" int fv3_c_sw(fv3_ctx *c, const fv3_field *delp_, const fv3_field *pt_
   // a lean kernel in which a thread owns TWO rows and shares the utmp / vtmp rows between them (20 loads per point);
   // the generic form then only runs on four windows along the sub-domain boundary (and skips the interior).
   if (fused) {
-    csw_fused_stream(c, s, u, v, delp, pt, w, ua, va, uc, vc, ut, vt, divgd, delpc, ptc, omga, ke, vort, dt2, nord > 0);
+    // (FV3_SEQ_UAVA=every: ua / va stored in full by every sub-step, A/B; read per call)
+    const char *uae = getenv("FV3_SEQ_UAVA");
+    csw_fused_stream(c, s, u, v, delp, pt, w, ua, va, uc, vc, ut, vt, divgd, delpc, ptc, omga, ke, vort, dt2, nord > 0, c->seq_uava_thin && !(uae && !strcmp(uae, "every")));
   } else if (march) {
     csw_abc_stream(c, s, u, v, ua, va, uc, vc, ut, vt, divgd, dt2, nord > 0);
   } else if (b_split) {

@@ -783,6 +783,10 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
     const int nwave_frame = c->frame_pass != 0 ? (ord.n_frame() + FV3_WAVE - 1) / FV3_WAVE : 0;
     const int w_lo = c->frame_pass == 2 ? nwave_frame : 0, w_hi = c->frame_pass == 1 ? nwave_frame : nwave;  // waves [w_lo, w_hi)
     Real *const zn = c->dz_scan_src;  // (update_dz_d left its scan to this call: see fv3_ctx::seq_dz_scan)
+    // Round 6: inside the sequencer only the LAST sub-step of an acoustic call stores the layer thickness -- the sub-steps between work from zh, and what reads delz
+    // (the heights of the next call, the diffusive heating, the remap) comes after the last one: one field write less in five of six sub-steps.  FV3_SEQ_DELZ=every: A/B.
+    const char *sde = getenv("FV3_SEQ_DELZ");
+    const bool store_delz = !(c->seq_delz_dead && !(sde && !strcmp(sde, "every")));
     const bool pre = zn != nullptr;
     const Real dzm = c->dz_scan_min;
     auto go_ = [&](auto last_tag, auto ra_tag, auto pre_tag) {
@@ -803,6 +807,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           unsigned pix;
           Real pem, peg, pelng_k, z, akap;
           Real *pk3, *peln, *pk, *pe, *ppe, *zh, *delz;
+          bool sdz;
           FV3_HD Real pm(int k, Real dm, Real qc) {
             pem = pem + dm;
             const Real peg_n = peg + dm * ((Real)1.0 - qc);
@@ -823,12 +828,12 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, int last_call, double dtd, const fv3
           FV3_HD void finish(int k, Real dz) {
             z = z - dz;
             FV3_ST_NT(KW_(zh, k), z);
-            FV3_ST_NT(KW_(delz, k), dz);
+            if (sdz) FV3_ST_NT(KW_(delz, k), dz);  // (wave-uniform: see store_delz)
           }
         };
         const Real z_bot = zs[t * st2 + pix];
         const Real peln0 = fv3_log(ptop);
-        Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, pk3, LAST ? peln : nullptr, LAST ? pk : nullptr, LAST ? pe : nullptr, ppe, zh, delz};
+        Cl cl{tb, sk, pix, ptop, ptop, peln0, z_bot, akap, pk3, LAST ? peln : nullptr, LAST ? pk : nullptr, LAST ? pe : nullptr, ppe, zh, delz, store_delz};
         KW_(pk3, 0) = fv3_exp(akap * peln0);
         if constexpr (LAST) {
           KW_(peln, 0) = peln0;

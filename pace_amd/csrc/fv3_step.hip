@@ -282,6 +282,8 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_heat_first = false;
       c->seq_csw_defer = false;
       c->seq_dz_scan = false;
+      c->seq_delz_dead = false;
+      c->seq_uava_thin = false;
       c->dz_scan_src = nullptr;
     }
   } pp_guard{c, stream};
@@ -338,9 +340,11 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     // (its last window launches may still run on the auxiliary stream beside update_dz_c: joined before riem_solver_c.  Only beside the one-kernel zh -> gz form of
     //  update_dz_c: the in-place form of the reference's first sub-step order works in the scratch field c_sw keeps its kinetic energy in)
     c->seq_csw_defer = (gz_direct || it > 0) && c->g.nz >= 3;
+    c->seq_uava_thin = it < n_split - 1;  // (ua / va: outputs of the call -- the last sub-step's; before that only d_sw's divergence and c_sw's own windows read them: fv3_csw.hip, sua)
     RUN(FV3_OP_C_SW, fv3_c_sw(c, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->ut, &ws->vt, &ws->divgd, &st->omga,
                               &ws->delpc, &ws->ptc, dt2, stream));
     c->seq_csw_defer = false;
+    c->seq_uava_thin = false;
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 0);
     if (it == 0 && gz_direct) {
       HALO(FV3_HALO_ZH, 1);
@@ -418,6 +422,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     c->seq_dz_scan = true;  // (its closing scan becomes riem_solver3's pre-sweep: nothing between the two reads zh or wsd)
     RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
     c->seq_dz_scan = false;
+    c->seq_delz_dead = it < n_split - 1;  // (delz is read after the last sub-step of a call only: fv3_nh.hip, store_delz)
     if (frame_first) {
       // the frame columns of the new zh / pkc first, their updates start, the interior columns follow beside the messages
       c->frame_pass = 1;
@@ -435,6 +440,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       HALO(FV3_HALO_ZH, 0);
       HALO(FV3_HALO_PKC, 0);
     }
+    c->seq_delz_dead = false;
     if (remap_step) RUN(FV3_OP_PK3_HALO, fv3_edge_pe(c, &st->pe, &f_delp[cur], ptop, stream));
     RUN(FV3_OP_PK3_HALO, fv3_pk3_halo(c, &ws->pk3, &f_delp[cur], ptop, akap, stream));
     HALO(FV3_HALO_ZH, 1);

@@ -555,6 +555,41 @@ def test_heights_of_a_call_straight_into_zh_is_bitwise_the_reference_order(backe
             assert np.array_equal(res["direct"][r][name], res["copy"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, n_split", [(24, (2, 2), 3), (48, (1, 1), 2)])
+def test_layer_thickness_stored_by_the_last_sub_step_only_is_bitwise_every_sub_step(backend, monkeypatch, n, layout, n_split):
+    """Inside fv3_acoustic_step riem_solver3 stores delz in the last sub-step of a call only: the sub-steps between work from zh, and everything that reads delz
+    (the heights of the next call, the diffusive heating, the remap) comes after the last one.  FV3_SEQ_DELZ=every: the store in every sub-step, as the
+    stand-alone operator does.  Every field -- delz included -- bitwise equal over two calls."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=n_split))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("last", "every"):
+        monkeypatch.setenv("FV3_SEQ_DELZ", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["last"][r][name], res["every"][r][name]), f"{name} rank {r}"
+
+
+@pytest.mark.parametrize("n, layout, n_split, kw", [(24, (2, 2), 3, {}), (48, (1, 1), 2, {}), (70, (1, 1), 2, dict(nord=0)), (32, (2, 2), 2, dict(nord=2))])
+def test_a_grid_winds_stored_in_full_by_the_last_sub_step_only_is_bitwise_every_sub_step(backend, monkeypatch, n, layout, n_split, kw):
+    """Inside fv3_acoustic_step the c_sw march of every sub-step but the last stores ua / va in full only on the levels where d_sw forms the divergence from
+    them (no damping chain there) and, on the others, on the two cells next to its rectangle's boundary (c_sw's own boundary windows read those); the last
+    sub-step stores everything -- ua / va are outputs of the call.  FV3_SEQ_UAVA=every: full stores in every sub-step.  Every field bitwise equal over two
+    calls, with damping chains of order 0 (every level reads ua / va), 1 (the reference's) and 2, on sub-domains with and without tile edges on every side."""
+    nz = 6
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=n_split, **kw))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("last", "every"):
+        monkeypatch.setenv("FV3_SEQ_UAVA", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE + ["uc", "vc"]:
+            assert np.array_equal(res["last"][r][name], res["every"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout, dz_min", [(24, (2, 2), None), (48, (1, 1), None), (24, (1, 1), 2500.0), (70, (1, 1), 4000.0)])
 def test_height_scan_as_the_pre_sweep_of_riem_solver3_is_bitwise_the_scan_kernel(backend, monkeypatch, n, layout, dz_min):
     """Inside fv3_acoustic_step update_dz_d leaves its closing kernel -- the bottom-up scan that keeps the marched interface heights dz_min apart and forms the
