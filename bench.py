@@ -134,6 +134,14 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def _hbm_used_gb():
+    try:
+        free, total = torch.cuda.mem_get_info()
+        return round((total - free) / 1.0e9, 1)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +337,7 @@ def main():
             },
             "finite": ok,
             "state_checksum": checksum,
+            "hbm_used_GB": _hbm_used_gb(),  # device memory in use on this rank when the timed region ended (hipMemGetInfo: fields, workspace, library scratch, torch)
             "halo_transport": transport,
             "rccl_ranks": rccl_ranks,
             "sub_domains_per_gpu": len(h.grids),

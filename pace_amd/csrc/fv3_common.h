@@ -275,6 +275,13 @@ struct fv3_ctx {
   // the surface vertical velocity -- to riem_solver3, whose wave form runs it as a pre-sweep of each column (fv3_nh.hip: PRE).  seq_dz_scan: the sequencer
   // allows it for the update_dz_d call it is about to make; dz_scan_src: the marched heights of a scan still to be done (null: none); dz_scan_min: dz_min.
   bool seq_dz_scan = false;
+  // Round 6, deferred accumulation of the Courant numbers (fv3_step.hip): inside the sequencer crx / cry of every sub-step of a call stay in their own arrays
+  // (acc_slots: crx, cry per sub-step -- fields fxadv writes anyway) and cx / cy are formed ONCE, at the end of the last d_sw of the call, as ((0 + s1) + s2) + ...
+  // in the order the read-modify-write of every sub-step would have used.  seq_acc_defer: the sequencer asks the d_sw call it is about to make not to touch cx / cy.
+  std::vector<Real *> acc_slots;
+  int acc_state = 0;  // -1: the slots could not be allocated (or FV3_ACC_DEFER=0): read-modify-write in every sub-step
+  bool seq_acc_defer = false;
+  int seq_acc_sum_n = 0;  // > 0: this d_sw call is the last of the acoustic call -- it ends with the sum of that many sub-steps' arrays into the accumulators
   bool seq_uava_thin = false;  // the sequencer: this c_sw call is not the last of the acoustic call -- its A-grid winds are read by d_sw's divergence on the levels without a damping chain and by c_sw's own boundary windows next to the march's rectangle, nowhere else
   bool seq_delz_dead = false;  // the sequencer: this riem_solver3 call is not the last of the acoustic call -- nobody reads the layer thickness it would store (the next sub-step works from zh)
   Real *dz_scan_src = nullptr;
@@ -318,6 +325,7 @@ struct fv3_gather_job {
 int fv3_gather_run_jobs(fv3_ctx *c, const fv3_gather_job *jobs, int n, void *stream);  // fv3_ctx.hip
 
 // ---------------------------------------------------------------------------------------------
+#define FV3_ACC_MAXSTEPS 12  // sub-steps per call the deferred accumulation handles (pointer table of its sum kernel)
 // Two-stream helpers.  fv3_aux(c, s): the stream helper kernels go to (the caller's stream itself when
 // the auxiliary stream is off or in the host emulation -- everything then runs in program order).
 // fv3_signal(c, from, e) / fv3_wait(c, to, e): event e recorded on `from`, later awaited by `to`.
@@ -344,6 +352,7 @@ inline bool fv3_alt(const char *name) {
   return false;
 }
 bool fv3_pp_ensure(fv3_ctx *c);  // (fv3_ctx.hip) the ping-pong buffers of fv3_acoustic_step, allocated on first use
+bool fv3_acc_slots_ensure(fv3_ctx *c, int n_sub_steps);  // (fv3_ctx.hip) the per-sub-step flux arrays of the deferred accumulation
 void fv3_h2d(void *dst, const void *src, size_t bytes);
 int fv3_post(fv3_ctx *c, fv3_stream_t s, const char *what);
 // validate one field against the context layout; returns typed base pointer or nullptr

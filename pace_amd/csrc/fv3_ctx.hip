@@ -35,6 +35,32 @@ void *fv3_dev_alloc(fv3_ctx *c, size_t bytes) {
   return p;
 }
 
+// the per-sub-step Courant-number arrays of the deferred accumulation (fv3_ctx::acc_slots): 2 fields per sub-step, allocated by the first call that can use them;
+// a failed allocation (or FV3_ACC_DEFER=0) leaves the read-modify-write form in place
+bool fv3_acc_slots_ensure(fv3_ctx *c, int n) {
+  if (n < 2 || c->acc_state < 0) return false;  // (one sub-step per call: nothing to defer)
+  if ((int)c->acc_slots.size() >= 2 * n) return true;
+  const char *e = getenv("FV3_ACC_DEFER");
+  if (e && e[0] == '0') {
+    c->acc_state = -1;
+    return false;
+  }
+  const size_t bytes = (size_t)c->g.st * c->g.nsub * sizeof(Real);
+  while ((int)c->acc_slots.size() < 2 * n) {
+    Real *p = (Real *)fv3_dev_alloc(c, bytes);
+    if (!p) {
+#ifndef FV3_HOST_EMU
+      (void)hipGetLastError();  // (the failed hipMalloc must not surface as the next launch's error)
+#endif
+      c->acc_state = -1;  // (what was allocated stays with the context; it is not used)
+      fprintf(stderr, "[fv3] Courant-number slots of the deferred accumulation (%d x %.2f GB) could not be allocated: cx / cy are updated in every sub-step\n", 2 * n, bytes / 1.0e9);
+      return false;
+    }
+    c->acc_slots.push_back(p);
+  }
+  return true;
+}
+
 // Alternate buffers of delp / pt / w / q_con for fv3_acoustic_step's ping-pong (four full 3-D fields: ~9 GB at C768 L79 fp64 on one
 // GPU).  Allocated on the first sequencer call that is eligible for the ping-pong, NOT with the context: contexts that only run
 // single operators, the Python sequencer or a host halo callback never need them.  FV3_PINGPONG=0 switches the ping-pong off; if the

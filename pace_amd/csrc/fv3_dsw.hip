@@ -899,6 +899,47 @@ bool dsw_honors_acc_first(const fv3_ctx *c) {
   return !(sc_env && !strcmp(sc_env, "separate")) && nmax <= 2 && c->zeros;
 }
 
+// Deferred accumulation of the Courant numbers (fv3_ctx::acc_slots): crx / cry of the n sub-steps of a call, each in its own array, summed ONCE into cx / cy on
+// their write sets -- ((0 + s1) + s2) + ..., the association the read-modify-write of every sub-step has (0 + s1: what the first sub-step's store computes on the
+// zeroed field, -0 included).  Per accumulator n reads and one write per call where fxadv read n - 1 times and wrote n times.  (The air-mass fluxes stay with the
+// read-modify-write of the air-mass march: measured, taking it out saves the march 0.8 ms per sub-step and the sum of twelve more arrays costs 1.15.)
+struct AccSlots {
+  const Real *crx[FV3_ACC_MAXSTEPS], *cry[FV3_ACC_MAXSTEPS];
+};
+static int acc_sum(fv3_ctx *c, Real *cx, Real *cy, int n, void *stream) {
+  if (n < 1 || n > FV3_ACC_MAXSTEPS || (int)c->acc_slots.size() < 2 * n) return fv3_fail(c, FV3_ERR_ARG, "acc_sum: no Courant-number slots for this many sub-steps");
+  AccSlots sl;
+  for (int q = 0; q < FV3_ACC_MAXSTEPS; ++q) {
+    const int m = q < n ? q : n - 1;
+    sl.crx[q] = c->acc_slots[2 * m];
+    sl.cry[q] = c->acc_slots[2 * m + 1];
+  }
+  const Geo g = c->g;
+  const int isd = 1 - g.nh, ied = g.nx + g.nh, jsd = 1 - g.nh, jed = g.ny + g.nh;
+  launch3<4>(c, (fv3_stream_t)stream, Box{isd, ied, jsd, jed, 0, g.nz - 1}, [=] FV3_HD(int t, int k, int i, int j) {
+    const long p = t * g.st + k * g.sk + IX(i, j);
+    if (i >= 1 && i <= g.nx + 1) {  // cx: [1, nx+1] x [jsd, jed]
+      Real a = (Real)0 + sl.crx[0][p];
+#pragma unroll
+      for (int q = 1; q < FV3_ACC_MAXSTEPS; ++q)
+        if (q < n) a = a + sl.crx[q][p];
+      cx[p] = a;
+    }
+    if (j >= 1 && j <= g.ny + 1) {  // cy: [isd, ied] x [1, ny+1]
+      Real a = (Real)0 + sl.cry[0][p];
+#pragma unroll
+      for (int q = 1; q < FV3_ACC_MAXSTEPS; ++q)
+        if (q < n) a = a + sl.cry[q][p];
+      cy[p] = a;
+    }
+  });
+  return fv3_post(c, (fv3_stream_t)stream, "acc_sum");
+}
+
+// Can d_sw leave cx / cy alone and keep the sub-step's Courant numbers in arrays of their own (fv3_ctx::seq_acc_defer)?  fxadv stores them exactly where it
+// accumulates them; the round-1 ("separate") scalar form does not go through it with the sequencer's flags.
+bool dsw_can_defer_acc(const fv3_ctx *c) { return dsw_honors_acc_first(c); }
+
 // o_*: where the new delp / pt / w / q_con go.  Null: in place (the operator's own contract: the marches write beside the old
 // fields, which their neighbours still read, and a copy-back follows); fv3_acoustic_step hands in the other half of its
 // ping-pong pair instead and the copy-back disappears.
@@ -957,6 +998,9 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
   const bool fused_scalars = !(sc_env && !strcmp(sc_env, "separate")) && nord_max_v <= 2 && nord_max_t <= 2 && nord_max_w <= 2;
   if (c->seq_acc_first && !fused_scalars) return fv3_fail(c, FV3_ERR_ARG, "d_sw: the sequencer's first-sub-step form of the accumulators needs the fused scalar marches");
   const int scalars_mode = sc_env && !strcmp(sc_env, "quad") ? 0 : 1;
+  // deferred accumulation of the Courant numbers (fv3_step.hip): cx / cy are not touched by fxadv; crx / cry are this sub-step's own arrays (the sequencer hands them in)
+  const bool acc_defer = c->seq_acc_defer;
+  if (acc_defer && !fused_scalars) return fv3_fail(c, FV3_ERR_ARG, "d_sw: the sequencer's deferred accumulation needs the fused scalar marches (fxadv with the Courant numbers)");
   if (fused_scalars) {
     // ---- air mass, vertical velocity, condensate, potential temperature: the four del-n chains (bandwidth-bound, the
     //      fields themselves are their only input) first, fxadv beside them, then ONE march for the four transports, the
@@ -978,7 +1022,7 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
     }
     if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[d_sw] fd_k0 = %d of %d\n", fd_k0, g.nz);
     fv3_signal(c, s, 0);
-    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, cx, cy, true);
+    fxadv(c, s, uc, vc, crx, cry, xfx, yfx, ut, vt, dt, acc_defer ? nullptr : cx, acc_defer ? nullptr : cy, true);
     fv3_signal(c, s, 5);  // (fxadv done: what the wind branch on the auxiliary stream waits for, see below)
     fv3_wait(c, s2, 0);
     // (the patches first: they are all the marches of the levels from fd_k0 on wait for; the chains of the sponge layers are read by
@@ -1517,6 +1561,11 @@ int fv3_d_sw_out(fv3_ctx *c, const fv3_field *delpc_, const fv3_field *delp_, co
       if (heat_on) FV3_ST_NT((heat_source + b)[p], (heat_first ? (Real)0 : (heat_source + b)[p]) + hs);
     }
   });
+  // (deferred accumulation: the last d_sw of an acoustic call forms cx / cy from the sub-steps' Courant numbers)
+  if (acc_defer && c->seq_acc_sum_n > 0) {
+    const int st_ = acc_sum(c, cx, cy, c->seq_acc_sum_n, s);
+    if (st_ != FV3_OK) return st_;
+  }
   return fv3_post(c, s, "d_sw");
 }
 

@@ -124,6 +124,7 @@ struct DswScalars {
 // mode 0: one march for the four tracers (one wave per SIMD); 1: delp + w, then q_con + pt on the stored air-mass fluxes
 void dsw_scalars_stream(fv3_ctx *c, fv3_stream_t s, const DswScalars &a, int mode);
 bool dsw_honors_acc_first(const fv3_ctx *c);  // (fv3_dsw.hip)
+bool dsw_can_defer_acc(const fv3_ctx *c);     // (fv3_dsw.hip)
 void del2_fill_corners(fv3_ctx *c, fv3_stream_t s, Real *qin);  // (fv3_nh.hip)
 // fv3_del2x.hip: del2_cubed (three iterations) + apply_diffusive_heating as one pass; 1 = no fused form for this configuration
 int fv3_del2_heat_fused(fv3_ctx *c, const fv3_field *q, double cd, int nmax, const fv3_field *delp, const fv3_field *delz, const fv3_field *cappa,

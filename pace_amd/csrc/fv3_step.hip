@@ -174,6 +174,7 @@ int zero_unwritten(fv3_ctx *c, const fv3_field *mfx_, const fv3_field *mfy_, con
   return fv3_post(c, (fv3_stream_t)stream, "zero_unwritten");
 }
 
+
 }  // namespace
 
 extern "C" int fv3_ctx_set_profiling(fv3_ctx *c, int on) {
@@ -284,6 +285,8 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_dz_scan = false;
       c->seq_delz_dead = false;
       c->seq_uava_thin = false;
+      c->seq_acc_defer = false;
+      c->seq_acc_sum_n = 0;
       c->dz_scan_src = nullptr;
     }
   } pp_guard{c, stream};
@@ -317,6 +320,10 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
   //  zero of a step's first call is what keeps those cells from drifting)
   const bool heat_store = acc_store && heat_reset && cf.d_con > 1.0e-5 && !fv3_alt("heat_zero_first_call");
   if (heat_reset && !heat_store) RUN(FV3_OP_GLUE, fv3_zero(c, &ws->heat_source, stream));
+  // Round 6: cx / cy are formed once, at the end of the last d_sw of the call, from the sub-steps' own Courant-number arrays (fv3_dsw.hip: acc_sum; fv3_ctx::acc_slots).
+  // FV3_ACC_DEFER=0 (or FV3_ACC_STORE=0, or a failed allocation of the 2 x n_split arrays): read-modify-write in every sub-step (A/B; same bits).
+  const bool acc_defer = acc_store && n_split >= 2 && n_split <= FV3_ACC_MAXSTEPS && dsw_can_defer_acc(c) && fv3_acc_slots_ensure(c, n_split);
+  if (getenv("FV3_DEBUG_FD")) fprintf(stderr, "[acoustic_step] accumulators: %s\n", acc_defer ? "cx / cy formed once per call from the sub-steps' Courant numbers, mfx / mfy read-modify-write" : acc_store ? "read-modify-write, first sub-step stores" : "zeroed, read-modify-write");
   if (acc_store)
     RUN(FV3_OP_GLUE, zero_unwritten(c, &st->mfxd, &st->mfyd, &st->cxd, &st->cyd, heat_store ? &ws->heat_source : nullptr, stream));
   RUN(FV3_OP_GLUE, fv3_zero(c, &st->diss_estd, stream));
@@ -373,6 +380,14 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
     }
     if (cf.nord > 0) HALO(FV3_HALO_DIVGD, 1);
     HALO(FV3_HALO_UC__VC, 1);
+    // (deferred accumulation: this sub-step's Courant numbers go to -- and are read from, by d_sw and update_dz_d -- arrays of its own)
+    fv3_field f_crx = ws->crx, f_cry = ws->cry;
+    if (acc_defer) {
+      f_crx.ptr = c->acc_slots[2 * it];
+      f_cry.ptr = c->acc_slots[2 * it + 1];
+      c->seq_acc_defer = true;
+      c->seq_acc_sum_n = it == n_split - 1 ? n_split : 0;  // (the last d_sw of the call ends with the sum of the sub-steps' arrays: fv3_dsw.hip, acc_sum)
+    }
     if (pingpong) {
       // d_sw writes the new delp / pt / w / q_con into the other half of the pair.  Their halo update STARTS inside the operator, as
       // soon as the scalar marches are done, and is waited for after it: with a communicator the exchange (communication stream)
@@ -402,7 +417,7 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_acc_first = acc_store && it == 0;
       c->seq_heat_first = heat_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw_out(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd,
-                                    &st->mfyd, &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
+                                    &st->mfyd, &st->cxd, &st->cyd, &f_crx, &f_cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt,
                                     stream, &f_delp[nxt], &f_pt[nxt], &f_w[nxt], &f_qc[nxt], +start_halo, &mid));
       c->seq_divgd_dead = false;
       c->seq_acc_first = false;
@@ -413,14 +428,16 @@ extern "C" int fv3_acoustic_step(fv3_ctx *c, const fv3_state *st, const fv3_work
       c->seq_acc_first = acc_store && it == 0;
       c->seq_heat_first = heat_store && it == 0;
       RUN(FV3_OP_D_SW, fv3_d_sw(c, &ws->dsw_delpc, &f_delp[cur], &f_pt[cur], &st->u, &st->v, &f_w[cur], &st->uc, &st->vc, &st->ua, &st->va, &ws->divgd, &st->mfxd, &st->mfyd,
-                                &st->cxd, &st->cyd, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
+                                &st->cxd, &st->cyd, &f_crx, &f_cry, &ws->xfx, &ws->yfx, &f_qc[cur], &ws->zh, &ws->heat_source, &st->diss_estd, dt, stream));
       c->seq_acc_first = false;
       c->seq_heat_first = false;
       HALO(FV3_HALO_DELP__PT__Q_CON, 0);
     }
+    c->seq_acc_defer = false;
+    c->seq_acc_sum_n = 0;
     HALO(FV3_HALO_DELP__PT__Q_CON, 1);
     c->seq_dz_scan = true;  // (its closing scan becomes riem_solver3's pre-sweep: nothing between the two reads zh or wsd)
-    RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &ws->crx, &ws->cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
+    RUN(FV3_OP_UPDATE_DZ_D, fv3_update_dz_d(c, &ws->zs, &ws->zh, &f_crx, &f_cry, &ws->xfx, &ws->yfx, &ws->wsd, dt, stream));
     c->seq_dz_scan = false;
     c->seq_delz_dead = it < n_split - 1;  // (delz is read after the last sub-step of a call only: fv3_nh.hip, store_delz)
     if (frame_first) {

@@ -149,7 +149,7 @@ def test_two_process_decomposition_is_bitwise_identical(tmp_path, nx, layout, wo
 @pytest.mark.gpu
 @pytest.mark.parametrize(
     "toggle",
-    ["FV3_RIEM_MODE=columns", "FV3_EDGE_PROFILE_LDS=1", "FV3_EDGE_PROFILE_REG=1", "FV3_EDGE_PROFILE_GENERIC=1", "FV3_TP2D_MODE=staged", "FV3_DEL6_MODE=staged", "FV3_SEG=96", "FV3_SEG=32", "FV3_CSW_B_GENERIC=1", "FV3_CSW_MARCH=0", "FV3_CSW_MARCH=abc", "FV3_DIVDAMP_STAGED=1", "FV3_KE_STAGED=1", "FV3_DSW_SCALARS=separate", "FV3_AUX_STREAM=0", "FV3_GRID_SPLIT=0", "FV3_PINGPONG=0", "FV3_DSW_WIND_OVERLAP=1", "FV3_TP2D_FA=0", "FV3_RIEM_REGS=0", "FV3_DSW_MARCH=old", "FV3_TP2D_MARCH=old", "FV3_DSW_HEAT=separate", "FV3_CSW_WIN_OVERLAP=0", "FV3_ACC_STORE=0", "FV3_EP_ONE_LAUNCH=0", "FV3_DSW_WINDSTAGE=staged", "FV3_DSW_MARCH=coupled", "FV3_CSW_DEFER=1", "FV3_DEL2_FUSED=0", "FV3_DEL2_HEAT=fused", "FV3_GZ_FIRST=copy", "FV3_DSW_VORT_IN_KE=1", "FV3_DSW_SIDE=copy", "FV3_DSW_SPONGE_WIND=serial", "FV3_FRAME_LAUNCH=split", "FV3_GATHER_BATCH=0", "FV3_DZ_SCAN=separate", "FV3_SEQ_DELZ=every", "FV3_SEQ_UAVA=every"],
+    ["FV3_RIEM_MODE=columns", "FV3_EDGE_PROFILE_LDS=1", "FV3_EDGE_PROFILE_REG=1", "FV3_EDGE_PROFILE_GENERIC=1", "FV3_TP2D_MODE=staged", "FV3_DEL6_MODE=staged", "FV3_SEG=96", "FV3_SEG=32", "FV3_CSW_B_GENERIC=1", "FV3_CSW_MARCH=0", "FV3_CSW_MARCH=abc", "FV3_DIVDAMP_STAGED=1", "FV3_KE_STAGED=1", "FV3_DSW_SCALARS=separate", "FV3_AUX_STREAM=0", "FV3_GRID_SPLIT=0", "FV3_PINGPONG=0", "FV3_DSW_WIND_OVERLAP=1", "FV3_TP2D_FA=0", "FV3_RIEM_REGS=0", "FV3_DSW_MARCH=old", "FV3_TP2D_MARCH=old", "FV3_DSW_HEAT=separate", "FV3_CSW_WIN_OVERLAP=0", "FV3_ACC_STORE=0", "FV3_EP_ONE_LAUNCH=0", "FV3_DSW_WINDSTAGE=staged", "FV3_DSW_MARCH=coupled", "FV3_CSW_DEFER=1", "FV3_DEL2_FUSED=0", "FV3_DEL2_HEAT=fused", "FV3_GZ_FIRST=copy", "FV3_DSW_VORT_IN_KE=1", "FV3_DSW_SIDE=copy", "FV3_DSW_SPONGE_WIND=serial", "FV3_FRAME_LAUNCH=split", "FV3_GATHER_BATCH=0", "FV3_DZ_SCAN=separate", "FV3_SEQ_DELZ=every", "FV3_SEQ_UAVA=every", "FV3_ACC_DEFER=0"],
 )
 def test_alternative_kernel_forms_agree(tmp_path, toggle):
     """Every operator that has two device implementations (wave Riemann solver vs thread-per-column, the

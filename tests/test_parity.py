@@ -590,6 +590,27 @@ def test_a_grid_winds_stored_in_full_by_the_last_sub_step_only_is_bitwise_every_
             assert np.array_equal(res["last"][r][name], res["every"][r][name]), f"{name} rank {r}"
 
 
+@pytest.mark.parametrize("n, layout, n_split, kw", [(24, (2, 2), 3, {}), (48, (1, 1), 2, {}), (130, (1, 1), 2, {}), (32, (2, 2), 4, dict(hord=5))])
+def test_accumulators_formed_once_per_call_are_bitwise_the_read_modify_write_of_every_sub_step(backend, monkeypatch, n, layout, n_split, kw):
+    """Inside fv3_acoustic_step the Courant numbers of every sub-step stay in arrays of their own and cxd / cyd are formed once, at the end of the last d_sw of the
+    call, as ((0 + s1) + s2) + ... (acc_sum); FV3_ACC_DEFER=0: fxadv reads and writes them in every sub-step.  Every field -- the accumulators on their whole
+    storages included -- bitwise equal over two calls; several strips / segments, sub-domains with and without tile edges, another PPM order."""
+    nz = 6
+    kw = dict(kw)
+    if "hord" in kw:
+        h = kw.pop("hord")
+        kw.update(hord_dp=h, hord_tm=h, hord_vt=h, hord_mt=h)
+    part, cfg, grids, ost, phis, _ = oracle_cube(n, layout, nz, dict(n_split=n_split, **kw))
+    init = [{k: v.copy() for k, v in s.items()} for s in ost]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FV3_ACC_DEFER", mode)
+        res[mode], *_ = run_device_cube(backend, part, cfg, grids, init, phis, 60.0, n_calls=2)
+    for r in range(part.total_ranks):
+        for name in STATE:
+            assert np.array_equal(res["1"][r][name], res["0"][r][name]), f"{name} rank {r}"
+
+
 @pytest.mark.parametrize("n, layout, dz_min", [(24, (2, 2), None), (48, (1, 1), None), (24, (1, 1), 2500.0), (70, (1, 1), 4000.0)])
 def test_height_scan_as_the_pre_sweep_of_riem_solver3_is_bitwise_the_scan_kernel(backend, monkeypatch, n, layout, dz_min):
     """Inside fv3_acoustic_step update_dz_d leaves its closing kernel -- the bottom-up scan that keeps the marched interface heights dz_min apart and forms the
